@@ -1,0 +1,184 @@
+"""oracle/pyoracle.py — TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for
+  * oracle/liboracle.so            (the plain-C restatement, oracle/ab_oracle.c)
+  * oracle/_ref/libaerobulk_ref.so (the UNMODIFIED reference Fortran, built by oracle/Makefile)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product (aerobulk_amd/) never does.
+
+The reference keeps sticky module globals (l_use_skin_schemes is never reset) and
+STOPs the process on errors, so every reference case is run in a *fresh child process*
+(`run_reference`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pickle
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libaerobulk_ref.so")
+
+ALGOS = {"coare3p0": 1, "coare3p6": 2, "ncar": 3, "ecmwf": 4, "andreas": 5}
+HUM = {"sh": 0, "dp": 1, "rh": 2}
+SKIN_ALGOS = ("coare3p0", "coare3p6", "ecmwf")
+
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    if a is None:
+        return C.cast(None, _dp)
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            raise RuntimeError(f"{ORACLE_SO} missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(ORACLE_SO)
+        L.abo_compute.restype = C.c_int
+        L.abo_compute.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, C.c_double, C.c_double, C.c_int,
+                                  C.c_int, C.c_int] + [_dp] * 8 + [_dp] * 6 + [_dp, C.c_int, _dp]
+        L.abo_init_checks.restype = C.c_int
+        L.abo_init_checks.argtypes = [C.c_long] + [_dp] * 8 + [C.POINTER(C.c_int), C.POINTER(C.c_long),
+                                                               C.POINTER(C.c_int)]
+        L.abo_synth_fields.restype = None
+        L.abo_synth_fields.argtypes = [C.c_int] * 4 + [_dp] * 8
+        for name, nargs in [("abo_e_sat", 1), ("abo_q_sat", 2), ("abo_theta_from_z_p0_t_q", 4),
+                            ("abo_rho_air", 3), ("abo_visc_air", 1), ("abo_one_on_l", 5),
+                            ("abo_ri_bulk", 6), ("abo_alpha_sw", 1), ("abo_psi_m_coare", 1),
+                            ("abo_psi_h_coare", 1), ("abo_psi_m_ecmwf", 1), ("abo_psi_h_ecmwf", 1),
+                            ("abo_psi_m_ncar", 1), ("abo_psi_h_ncar", 1), ("abo_psi_m_andreas", 1),
+                            ("abo_psi_h_andreas", 1), ("abo_cd_n10_ncar", 1), ("abo_charn_coare3p0", 1),
+                            ("abo_charn_coare3p6", 1), ("abo_u_star_andreas", 1), ("abo_q_air_rh", 3),
+                            ("abo_q_air_dp", 2), ("abo_phi_takaya", 1)]:
+            f = getattr(L, name)
+            f.restype = C.c_double
+            f.argtypes = [C.c_double] * nargs
+        L.abo_z0tq_lkb.restype = C.c_double
+        L.abo_z0tq_lkb.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.abo_delta_skin_layer.restype = C.c_double
+        L.abo_delta_skin_layer.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
+        _lib = L
+    return _lib
+
+
+def synth_fields(ni, nj, j0=0, nj_local=None):
+    """SURVEY §8d quasi-random inputs for rows j0..j0+nj_local-1 (0-based) of an ni x nj grid."""
+    if nj_local is None:
+        nj_local = nj - j0
+    n = ni * nj_local
+    out = {k: np.empty(n) for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")}
+    lib().abo_synth_fields(ni, nj, j0, nj_local, _p(out["sst"]), _p(out["t_zt"]), _p(out["hum_zt"]),
+                           _p(out["u_zu"]), _p(out["v_zu"]), _p(out["slp"]), _p(out["rad_sw"]), _p(out["rad_lw"]))
+    return out
+
+
+class OracleSession:
+    """CPU oracle counterpart of one aerobulk_model() time loop (jt = 1..nt)."""
+
+    def __init__(self, algo, n, nt=1, use_skin=False, hum_type="sh"):
+        self.algo, self.n, self.nt, self.use_skin = algo, int(n), int(nt), bool(use_skin)
+        self.hum_type = hum_type
+        self.wl = np.zeros(4 * self.n)
+
+    def compute(self, jt, zt, zu, niter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw=None, rad_lw=None,
+                isecday_utc=12, lon=None):
+        n = self.n
+        o = {k: np.empty(n) for k in ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")}
+        rc = lib().abo_compute(ALGOS[self.algo], jt, self.nt, n, zt, zu, niter, int(self.use_skin),
+                               HUM[self.hum_type], _p(sst), _p(t_zt), _p(hum_zt), _p(u_zu), _p(v_zu), _p(slp),
+                               _p(rad_sw), _p(rad_lw), _p(o["ql"]), _p(o["qh"]), _p(o["tau_x"]), _p(o["tau_y"]),
+                               _p(o["evap"]), _p(o["t_s"]), _p(self.wl), isecday_utc, _p(lon))
+        o["rc"] = rc
+        return o
+
+
+def init_checks(sst, t_air, hum, u, v, slp, rad_sw=None, rad_lw=None):
+    ht, nm, bad = C.c_int(-1), C.c_long(0), C.c_int(-1)
+    rc = lib().abo_init_checks(sst.size, _p(sst), _p(t_air), _p(hum), _p(u), _p(v), _p(slp), _p(rad_sw), _p(rad_lw),
+                               C.byref(ht), C.byref(nm), C.byref(bad))
+    inv = {v: k for k, v in HUM.items()}
+    return dict(rc=rc, hum_type=inv.get(ht.value), n_masked=nm.value, bad_field=bad.value)
+
+
+# ------------------------------------------------------------------ the real reference, in a child process
+def have_reference():
+    return os.path.exists(REF_SO)
+
+
+_CHILD = r"""
+import ctypes as C, pickle, sys, numpy as np
+so, fin, fout = sys.argv[1:4]
+case = pickle.load(open(fin, "rb"))
+L = C.CDLL(so)
+dp = C.POINTER(C.c_double)
+def p(a): return a.ctypes.data_as(dp)
+ci = lambda v: C.byref(C.c_int(v))
+cd = lambda v: C.byref(C.c_double(v))
+algo = case["algo"].encode()
+n = case["n"]; nt = case["nt"]
+res = []
+for jt in range(1, nt + 1):
+    f = case["records"][jt - 1]
+    o = {k: np.full(n, np.nan) for k in ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")}
+    if case["with_rad"]:
+        # reference declares l_skin as default LOGICAL (4 bytes): pass a 4-byte int
+        L.aerobulk_cxx_skin(ci(jt), ci(nt), C.c_char_p(algo), cd(case["zt"]), cd(case["zu"]),
+            p(f["sst"]), p(f["t_zt"]), p(f["hum_zt"]), p(f["u_zu"]), p(f["v_zu"]), p(f["slp"]),
+            p(o["ql"]), p(o["qh"]), p(o["tau_x"]), p(o["tau_y"]), p(o["evap"]),
+            ci(case["niter"]), ci(1 if case["use_skin"] else 0), p(f["rad_sw"]), p(f["rad_lw"]), p(o["t_s"]),
+            ci(len(algo)), ci(n))
+    else:
+        L.aerobulk_cxx_no_skin(ci(jt), ci(nt), C.c_char_p(algo), cd(case["zt"]), cd(case["zu"]),
+            p(f["sst"]), p(f["t_zt"]), p(f["hum_zt"]), p(f["u_zu"]), p(f["v_zu"]), p(f["slp"]),
+            p(o["ql"]), p(o["qh"]), p(o["tau_x"]), p(o["tau_y"]), p(o["evap"]),
+            ci(case["niter"]), ci(len(algo)), ci(n))
+    res.append(o)
+pickle.dump(res, open(fout, "wb"))
+"""
+
+
+def run_reference(algo, records, zt, zu, niter, use_skin=False, with_rad=None, timeout=3600):
+    """Run aerobulk_model(jt=1..nt) of the UNMODIFIED reference (through its own C entry points
+    aerobulk_cxx_skin / aerobulk_cxx_no_skin, src/mod_aerobulk_cxx.f90:29-95) in a fresh process.
+    `records` is a list (one per time record) of dicts of flat float64 arrays.
+    Returns a list of output dicts, or raises RuntimeError with the reference's stdout if it STOPped."""
+    if with_rad is None:
+        with_rad = use_skin
+    n = records[0]["sst"].size
+    case = dict(algo=algo, n=n, nt=len(records), zt=float(zt), zu=float(zu), niter=int(niter),
+                use_skin=bool(use_skin), with_rad=bool(with_rad),
+                records=[{k: np.ascontiguousarray(v, dtype=np.float64) for k, v in r.items() if v is not None}
+                         for r in records])
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.pkl"), os.path.join(td, "out.pkl")
+        with open(fin, "wb") as fh:
+            pickle.dump(case, fh)
+        pr = subprocess.run([sys.executable, "-c", _CHILD, REF_SO, fin, fout], capture_output=True, text=True,
+                            timeout=timeout)
+        if not os.path.exists(fout):
+            raise RuntimeError("reference aborted (STOP):\n" + pr.stdout[-2000:] + pr.stderr[-2000:])
+        with open(fout, "rb") as fh:
+            return pickle.load(fh)
+
+
+def ref_scalar(symbol, *args):
+    """Call a scalar REAL(8) module function of the reference (flang ABI: all by reference)."""
+    L = C.CDLL(REF_SO)
+    f = getattr(L, symbol)
+    f.restype = C.c_double
+    return f(*[C.byref(C.c_double(a)) for a in args])
