@@ -1,0 +1,7 @@
+"""aerobulk_amd — MI355X-native bulk air-sea flux engine (drop-in for AeroBulk's aerobulk_compute path).
+
+Host mirror of the reference interface lives in `aerobulk_amd.api`; the product is the HIP
+library `libaerobulk_amd.so` (C ABI: include/aerobulk_amd.h)."""
+from .api import (ALGOS, AerobulkError, Session, aerobulk_model, synth_fields_device)  # noqa: F401
+
+__all__ = ["ALGOS", "AerobulkError", "Session", "aerobulk_model", "synth_fields_device"]

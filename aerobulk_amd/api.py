@@ -1,0 +1,236 @@
+"""Python host mirror of the AeroBulk public interface, on top of the C ABI.
+
+Names and argument meaning follow the reference's Fortran API
+(`AEROBULK_MODEL`, src/mod_aerobulk.f90:176-230) so that parity tests read like the
+reference's own example drivers (src/tests/example_call_aerobulk.f90:48-51).
+
+Arrays may be numpy float64 arrays (host: the library stages them through HBM) or torch CUDA
+tensors (device-resident: zero-copy, asynchronous).  PyTorch is used only as a device-memory
+and stream provider.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+ALGOS = {"coare3p0": 1, "coare3p6": 2, "ncar": 3, "ecmwf": 4, "andreas": 5}
+HUM_TYPES = {0: "sh", 1: "dp", 2: "rh"}
+HUM_IDS = {v: k for k, v in HUM_TYPES.items()}
+AB_MEM_HOST, AB_MEM_DEVICE = 0, 1
+AB_F64, AB_F32 = 0, 1
+AB_ERR_TAU = 8
+IN_NAMES = ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp", "rad_sw", "rad_lw")
+OUT_NAMES = ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")
+
+
+class AerobulkError(RuntimeError):
+    """A condition on which the reference prints a message and STOPs (mod_const.f90:238-278)."""
+
+    def __init__(self, status, message):
+        super().__init__(f"[ab_status {status}] {message}")
+        self.status = status
+        self.message = message
+
+
+def _raise(status):
+    lib = _lib.load()
+    msg = lib.ab_last_error().decode(errors="replace") or lib.ab_strerror(status).decode()
+    raise AerobulkError(status, msg)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x, dtype, n):
+    """(address, keepalive) of a flat field; None -> NULL."""
+    if x is None:
+        return None, None
+    if _is_torch(x):
+        if not x.is_cuda:
+            raise ValueError("torch tensors must live on the GPU (use numpy arrays for host data)")
+        import torch
+        want = torch.float64 if dtype == np.float64 else torch.float32
+        if x.dtype != want or not x.is_contiguous():
+            raise ValueError(f"device field must be contiguous {want}")
+        if x.numel() != n:
+            raise ValueError(f"field has {x.numel()} cells, expected {n}")
+        return x.data_ptr(), x
+    a = np.ascontiguousarray(x, dtype=dtype)
+    if a.size != n:
+        raise ValueError(f"field has {a.size} cells, expected {n}")
+    return a.ctypes.data, a
+
+
+class Session:
+    """One aerobulk_model() time loop (jt = 1..Nt) on one MI355X.
+
+    Replaces the reference's module-global state by an explicit handle."""
+
+    def __init__(self, calgo, Ni, Nj=1, Nt=1, l_use_skin=False, precision="f64", device=-1):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        algo = self._lib.ab_algo_from_string(calgo.encode(), -1)
+        if algo == 0:
+            raise AerobulkError(1, f"ERROR: mod_aerobulk_compute.f90 => bulk algorithm {calgo} is unknown!!!")
+        self.calgo, self.Ni, self.Nj, self.Nt = calgo, int(Ni), int(Nj), int(Nt)
+        self.n = self.Ni * self.Nj
+        self.l_use_skin = bool(l_use_skin)
+        self.dtype = np.float64 if precision == "f64" else np.float32
+        rc = self._lib.ab_session_create(C.byref(self._h), algo, self.Ni, self.Nj, self.Nt, int(self.l_use_skin),
+                                         AB_F64 if precision == "f64" else AB_F32, device)
+        if rc:
+            _raise(rc)
+        self.hum_type = "sh"
+
+    # -- AEROBULK_INIT (mod_aerobulk.f90:24-160)
+    def init(self, sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw=None, rad_lw=None):
+        fields = [sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw, rad_lw]
+        dev = _is_torch(sst)
+        ptrs, keep = zip(*[_ptr(f, self.dtype, self.n) for f in fields])
+        rep = _lib.InitReport()
+        rc = self._lib.ab_session_init(self._h, *ptrs, AB_MEM_DEVICE if dev else AB_MEM_HOST, C.byref(rep))
+        report = dict(n_cells=rep.n_cells, n_masked=rep.n_masked, hum_type=HUM_TYPES.get(rep.hum_type),
+                      bad_field=rep.bad_field, bad_min=rep.bad_min, bad_max=rep.bad_max, bad_mean=rep.bad_mean)
+        if rc:
+            _raise(rc)
+        self.hum_type = report["hum_type"]
+        return report
+
+    def set_humidity(self, hum_type):
+        rc = self._lib.ab_session_set_humidity(self._h, HUM_IDS[hum_type])
+        if rc:
+            _raise(rc)
+        self.hum_type = hum_type
+
+    def set_solar_time(self, isecday_utc, lon=None):
+        p, keep = _ptr(lon, self.dtype, self.n)
+        rc = self._lib.ab_session_set_solar_time(self._h, int(isecday_utc), p,
+                                                 AB_MEM_DEVICE if (lon is not None and _is_torch(lon)) else AB_MEM_HOST)
+        if rc:
+            _raise(rc)
+
+    # -- aerobulk_compute (mod_aerobulk_compute.f90:22-213)
+    def compute(self, jt, zt, zu, sst, t_zt, hum_zt, U_zu, V_zu, slp, Niter=5, rad_sw=None, rad_lw=None,
+                out=None, want_T_s=None, stream=None, check=True):
+        dev = _is_torch(sst)
+        ins = [sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw, rad_lw]
+        iptr, ikeep = zip(*[_ptr(f, self.dtype, self.n) for f in ins])
+        if want_T_s is None:
+            want_T_s = rad_sw is not None and rad_lw is not None
+        names = OUT_NAMES if want_T_s else OUT_NAMES[:5]
+        if out is None:
+            if dev:
+                import torch
+                out = {k: torch.empty(self.n, dtype=sst.dtype, device=sst.device) for k in names}
+            else:
+                out = {k: np.empty(self.n, dtype=self.dtype) for k in names}
+        optr = []
+        for k in OUT_NAMES:
+            o = out.get(k)
+            optr.append(_ptr(o, self.dtype, self.n)[0] if o is not None else None)
+            if o is not None and not dev and not (isinstance(o, np.ndarray) and o.flags["C_CONTIGUOUS"] and o.dtype == self.dtype):
+                raise ValueError("host outputs must be contiguous arrays of the session precision")
+        if dev and stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        rc = self._lib.ab_session_compute(self._h, int(jt), float(zt), float(zu), int(Niter), *iptr, *optr,
+                                          AB_MEM_DEVICE if dev else AB_MEM_HOST, C.c_void_p(stream or 0))
+        if rc:
+            _raise(rc)
+        if dev and check:
+            self.check()
+        return out
+
+    def check(self):
+        rc = self._lib.ab_session_check(self._h)
+        if rc:
+            _raise(rc)
+
+    def wl_state(self):
+        st = np.empty(4 * self.n)
+        rc = self._lib.ab_session_get_wl_state(self._h, st.ctypes.data_as(_lib.dp))
+        if rc:
+            _raise(rc)
+        return dict(zip(("dT_wl", "Hz_wl", "Qnt_ac", "Tau_ac"), st.reshape(4, self.n)))
+
+    def last_kernel_ms(self):
+        return self._lib.ab_session_last_kernel_ms(self._h)
+
+    def close(self):
+        if self._h:
+            self._lib.ab_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def aerobulk_model(jt, Nt, calgo, zt, zu, sst, t_zt, hum_zt, U_zu, V_zu, slp, Niter=None, l_use_skin=False,
+                   rad_sw=None, rad_lw=None):
+    """AEROBULK_MODEL (src/mod_aerobulk.f90:176-269) through the library's process-global session:
+    INIT checks at jt==1, sticky Niter, non-reentrant — the reference's own protocol.
+    Host float64 arrays of any shape (flattened in Fortran order is the caller's business: cells
+    are independent).  Returns dict(QL, QH, Tau_x, Tau_y, Evap[, T_s]) shaped like `sst`."""
+    lib = _lib.load()
+    shape = np.shape(sst)
+    n = int(np.prod(shape))
+    ni = shape[0] if len(shape) > 0 else 1
+    nj = n // ni
+    ins = [np.ascontiguousarray(np.ravel(f, order="F"), dtype=np.float64) for f in (sst, t_zt, hum_zt, U_zu, V_zu, slp)]
+    for a in ins:
+        if a.size != n:  # mod_aerobulk.f90:87-91
+            raise AerobulkError(10, " AEROBULK_INIT => SST and input arrays do not agree in shape!")
+    rad = [None, None]
+    if rad_sw is not None and rad_lw is not None:
+        rad = [np.ascontiguousarray(np.ravel(f, order="F"), dtype=np.float64) for f in (rad_sw, rad_lw)]
+        for a in rad:
+            if a.size != n:  # :93-94
+                raise AerobulkError(10, " AEROBULK_INIT => SST and Rad arrays do not agree in shape!")
+    outs = [np.empty(n) for _ in range(5)]
+    t_s = np.empty(n) if rad[0] is not None else None
+    P = lambda a: a.ctypes.data_as(_lib.dp) if a is not None else C.cast(None, _lib.dp)
+    rep = _lib.InitReport()
+    rc = lib.ab_model(int(jt), int(Nt), calgo.encode(), len(calgo), float(zt), float(zu), *[P(a) for a in ins],
+                      *[P(a) for a in outs], int(Niter) if Niter else 0, int(bool(l_use_skin)), P(rad[0]), P(rad[1]),
+                      P(t_s), ni, nj, C.byref(rep))
+    if rc:
+        _raise(rc)
+    res = {k: v.reshape(shape, order="F") for k, v in zip(OUT_NAMES[:5], outs)}
+    if t_s is not None:
+        res["T_s"] = t_s.reshape(shape, order="F")
+    if jt == 1:
+        res["init_report"] = dict(n_masked=rep.n_masked, hum_type=HUM_TYPES.get(rep.hum_type))
+    return res
+
+
+def synth_fields_device(Ni, Nj, j0=0, nj_local=None, precision="f64", device="cuda", with_rad=True):
+    """SURVEY §8d synthetic fields generated straight into HBM (torch tensors)."""
+    import torch
+    lib = _lib.load()
+    if nj_local is None:
+        nj_local = Nj - j0
+    n = Ni * nj_local
+    dt = torch.float64 if precision == "f64" else torch.float32
+    names = IN_NAMES if with_rad else IN_NAMES[:6]
+    f = {k: torch.empty(n, dtype=dt, device=device) for k in names}
+    rc = lib.ab_synth_fields_device(*[f[k].data_ptr() for k in IN_NAMES[:6]],
+                                    f["rad_sw"].data_ptr() if with_rad else None,
+                                    f["rad_lw"].data_ptr() if with_rad else None, Ni, j0, nj_local,
+                                    AB_F64 if precision == "f64" else AB_F32,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc:
+        _raise(rc)
+    return f

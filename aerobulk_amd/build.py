@@ -1,0 +1,83 @@
+"""Build the in-tree native libraries (gfx950 only).
+
+    python -m aerobulk_amd.build          # libaerobulk_amd.so (+ C++ wrapper, Fortran host if amdflang exists)
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libaerobulk_amd.so")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+ARCH = "gfx950"
+HIPFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, **kw)
+
+
+def build_engine(force=False):
+    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_runtime.hip", "ab_cxx.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("ab_kernels.hpp", "ab_physics.hpp", "ab_math.hpp")] + [
+        os.path.join(ROOT, "include", "aerobulk_amd.h"), os.path.join(ROOT, "include", "aerobulk.hpp")]
+    if not force and not _newer(LIB, deps):
+        return LIB
+    objs = []
+    for s in srcs:
+        o = os.path.join(CSRC, os.path.basename(s).rsplit(".", 1)[0] + ".o")
+        if force or _newer(o, deps):
+            extra = ["-x", "hip"] if s.endswith(".cpp") else []
+            _run([HIPCC, *HIPFLAGS, "-I", os.path.join(ROOT, "include"), *extra, "-c", s, "-o", o])
+        objs.append(o)
+    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+def build_fortran_host(force=False):
+    """From-scratch Fortran host module (mod_aerobulk) + example driver; needs amdflang."""
+    fc = shutil.which("amdflang") or "/opt/rocm/bin/amdflang"
+    if not os.path.exists(fc):
+        print("amdflang absent: Fortran host not built")
+        return None
+    fdir = os.path.join(PKG, "fortran")
+    src = os.path.join(fdir, "mod_aerobulk.f90")
+    drv = os.path.join(fdir, "example_call_aerobulk.f90")
+    exe = os.path.join(fdir, "example_call_aerobulk.x")
+    if not os.path.exists(src):
+        return None
+    if force or _newer(exe, [src, drv, LIB]):
+        _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-c", src, "-o", os.path.join(fdir, "mod_aerobulk.o")])
+        _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, drv, os.path.join(fdir, "mod_aerobulk.o"),
+              "-L", PKG, "-laerobulk_amd", f"-Wl,-rpath,{PKG}", "-o", exe])
+    return exe
+
+
+def build_oracle():
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
+
+
+def build_all(force=False):
+    build_engine(force)
+    build_fortran_host(force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

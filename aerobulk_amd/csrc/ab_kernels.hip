@@ -1,0 +1,296 @@
+// ab_kernels.hip — HIP kernels of the bulk air-sea flux engine, written for gfx950 (MI355X).
+//
+// flux_kernel<R,ALGO,SKIN>: the whole of aerobulk_compute() (mod_aerobulk_compute.f90:22-213)
+// fused into ONE pointwise kernel: humidity conversion, scalar wind, q_sat(SST), theta(zt),
+// TURB_<algo> with its nb_iter Monin-Obukhov iterations and optional cool-skin/warm-layer,
+// BULK_FORMULA and the stress vector.  One lane = one cell; a wave reads 64 consecutive cells of
+// each field with one coalesced 8-byte-per-lane load (512 B per wave-instruction) and writes the
+// outputs the same way; none of the reference's 15 (Ni,Nj) temporaries exists.  The kernel is
+// bound by fp64 VALU throughput, not HBM, so there is no LDS staging: the
+// ≈100 B/cell stream is hidden under thousands of VALU cycles per cell by wave-level parallelism.
+#include "ab_kernels.hpp"
+#include "ab_physics.hpp"
+
+namespace ab {
+
+constexpr int kBlock = 256;  // 4 waves of 64 lanes, one per SIMD
+
+template <class R> struct FluxArgs {
+    const R *sst, *t_zt, *hum, *u, *v, *slp, *rad_sw, *rad_lw, *lon;
+    R *ql, *qh, *tau_x, *tau_y, *evap, *t_s;
+    R *wl0, *wl1, *wl2, *wl3;
+    int *flags;
+    long n;
+    Heights<R> h;
+    int nb_iter, hum_type, wl_load, wl_store, isecday, dawn_uniform;
+};
+
+template <class R, int ALGO, bool SKIN>
+__global__ void __launch_bounds__(kBlock) flux_kernel(const FluxArgs<R> a)
+{
+    using M = Mth<R>;
+    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= a.n) return;
+
+    // ---- coalesced loads of the input fields
+    const R sst = a.sst[k];
+    const R t_zt = a.t_zt[k];
+    const R hum = a.hum[k];
+    const R uu = a.u[k];
+    const R vv = a.v[k];
+    const R slp = a.slp[k];
+
+    CellIn<R> in;
+    in.sst = sst;
+    in.slp = slp;
+    // ---- pre-processing, mod_aerobulk_compute.f90:99-126
+    if (a.hum_type == 0) in.q_zt = hum;                                        // 'sh'
+    else if (a.hum_type == 1) in.q_zt = q_air_dp(hum, vmax(slp, R(50000.)));   // 'dp' :103
+    else in.q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));                  // 'rh' :105
+    in.wnd = M::sqrt(uu * uu + vv * vv);                                       // :111
+    in.ssq = K<R>::rdct_qsat_salt * q_sat(sst, slp);                           // :114
+    in.theta_zt = theta_from_z_p0_t_q(a.h.zt, slp, t_zt, in.q_zt);             // :118
+    in.qsw = R(0.);
+    in.rlw = R(0.);
+
+    R wl[4] = {R(0.), R(0.), R(0.), R(0.)};
+    bool dawn = false;
+    if (SKIN) {
+        in.qsw = (R(1.) - K<R>::roce_alb0) * a.rad_sw[k];                      // :135,146,161
+        in.rlw = a.rad_lw[k];
+        if (a.wl_load) {
+            wl[0] = a.wl0[k];
+            wl[1] = a.wl1[k];
+            if (ALGO != 4) { wl[2] = a.wl2[k]; wl[3] = a.wl3[k]; }
+        } else {  // COARE3Px_INIT mod_blk_coare3p6.f90:84-87 ; ECMWF_INIT mod_blk_ecmwf.f90:403-404
+            wl[1] = (ALGO == 4) ? R(3.) : R(20.);
+        }
+        if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>(a.lon[k], a.isecday) : (a.dawn_uniform != 0);
+    }
+
+    // ---- TURB_<algo>, mod_aerobulk_compute.f90:129-176
+    CellOut<R> o;
+    if (ALGO == 1) turb_coare<R, false, SKIN>(a.h, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 2) turb_coare<R, true, SKIN>(a.h, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 3) turb_ncar<R>(a.h, in, a.nb_iter, o);
+    else if (ALGO == 4) turb_ecmwf<R, SKIN>(a.h, in, a.nb_iter, wl, o);
+    else turb_andreas<R>(a.h, in, a.nb_iter, o);
+
+    if (SKIN && a.wl_store) {
+        a.wl0[k] = wl[0];
+        a.wl1[k] = wl[1];
+        if (ALGO != 4) { a.wl2[k] = wl[2]; a.wl3[k] = wl[3]; }
+    }
+
+    // ---- BULK_FORMULA + stress vector, :184-194
+    R zTaum, QH, QL, zEvap;
+    bulk_formula(a.h.zu, o.T_s, o.q_s, o.t_zu, o.q_zu, o.Cd, o.Ch, o.Ce, in.wnd, o.Ubzu, slp, zTaum, QH, QL, zEvap);
+    if (zTaum > R(10.)) atomicOr(a.flags, 1);                                  // mod_phymbl.f90:1250-1253
+    R tx = R(0.), ty = R(0.);
+    if (in.wnd > R(1.E-3)) {
+        const R s = zTaum / in.wnd;
+        tx = s * uu;
+        ty = s * vv;
+    }
+    a.ql[k] = QL;
+    a.qh[k] = QH;
+    a.tau_x[k] = tx;
+    a.tau_y[k] = ty;
+    if (a.evap) a.evap[k] = zEvap;                                             // :208
+    if (a.t_s) a.t_s[k] = o.T_s;                                               // :206
+}
+
+template <class R> static Heights<R> make_heights(double zt, double zu)
+{
+    Heights<R> h;
+    h.zt = (R)zt;
+    h.zu = (R)zu;
+    h.log_zt = (R)log(zt);
+    h.log_zu = (R)log(zu);
+    h.log_10 = (R)log(10.);
+    h.log_ztu = (R)log(zt / zu);
+    h.log_zu10 = (R)log(zu / 10.);
+    h.fg_ca = (R)(0.035 * log(10. / 0.0001) / log(zu / 0.0001));  // mod_common_coare.f90:107
+    h.zt_eq_zu = (fabs(zu - zt) < 0.01) ? 1 : 0;
+    return h;
+}
+
+// host copy of WL_COARE's solar-time test for uniform longitude 0 (mod_skin_coare.f90:146-163)
+static int dawn_at_lon0(int isd)
+{
+    int s = isd % 86400;
+    if (s < 0) s += 86400;
+    const double hr = (double)s / 3600.;
+    return (hr > 4.) && (hr <= 6.5);
+}
+
+template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
+{
+    FluxArgs<R> a;
+    a.sst = (const R *)c.sst; a.t_zt = (const R *)c.t_zt; a.hum = (const R *)c.hum;
+    a.u = (const R *)c.u; a.v = (const R *)c.v; a.slp = (const R *)c.slp;
+    a.rad_sw = (const R *)c.rad_sw; a.rad_lw = (const R *)c.rad_lw; a.lon = (const R *)c.lon;
+    a.ql = (R *)c.ql; a.qh = (R *)c.qh; a.tau_x = (R *)c.tau_x; a.tau_y = (R *)c.tau_y;
+    a.evap = (R *)c.evap; a.t_s = (R *)c.t_s;
+    a.wl0 = (R *)c.wl[0]; a.wl1 = (R *)c.wl[1]; a.wl2 = (R *)c.wl[2]; a.wl3 = (R *)c.wl[3];
+    a.flags = c.flags;
+    a.n = c.n;
+    a.h = make_heights<R>(c.zt, c.zu);
+    a.nb_iter = c.nb_iter; a.hum_type = c.hum_type; a.wl_load = c.wl_load; a.wl_store = c.wl_store;
+    a.isecday = c.isecday;
+    a.dawn_uniform = dawn_at_lon0(c.isecday);
+    const long nblk = (c.n + kBlock - 1) / kBlock;
+    if (nblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <class R> static hipError_t launch_r(const FluxCall &c, hipStream_t s)
+{
+    switch (c.algo) {
+    case 1: return c.skin ? launch_t<R, 1, true>(c, s) : launch_t<R, 1, false>(c, s);
+    case 2: return c.skin ? launch_t<R, 2, true>(c, s) : launch_t<R, 2, false>(c, s);
+    case 3: return launch_t<R, 3, false>(c, s);
+    case 4: return c.skin ? launch_t<R, 4, true>(c, s) : launch_t<R, 4, false>(c, s);
+    case 5: return launch_t<R, 5, false>(c, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_flux(const FluxCall &c, hipStream_t stream)
+{
+    return c.f32 ? launch_r<float>(c, stream) : launch_r<double>(c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// AEROBULK_INIT statistics: sanity mask (mod_aerobulk.f90:105-115, ranges mod_const.f90:138-146) and
+// masked sum/min/max of every field for type_of_humidity (mod_phymbl.f90:1957-2007) and
+// check_unit_consistency (:1851-1954).  HBM-bound streaming reduction: grid-stride, wave shuffles,
+// one partial row per block; the host folds the <=2048 rows.
+template <class R>
+__global__ void __launch_bounds__(kBlock) init_stats_kernel(const R *sst, const R *ta, const R *hum, const R *u,
+                                                            const R *v, const R *slp, const R *rsw, const R *rlw,
+                                                            long n, double *partials)
+{
+    double cnt = 0.;
+    double sum[kStatFields], mn[kStatFields], mx[kStatFields];
+#pragma unroll
+    for (int f = 0; f < kStatFields; ++f) { sum[f] = 0.; mn[f] = 1.e300; mx[f] = -1.e300; }
+    const bool rad = (rsw != nullptr) && (rlw != nullptr);
+    for (long k = (long)blockIdx.x * kBlock + threadIdx.x; k < n; k += (long)gridDim.x * kBlock) {
+        double x[kStatFields];
+        x[0] = (double)sst[k]; x[1] = (double)ta[k]; x[2] = (double)slp[k];
+        x[3] = (double)u[k]; x[4] = (double)v[k];
+        x[5] = sqrt(x[3] * x[3] + x[4] * x[4]);
+        x[6] = (double)hum[k];
+        x[7] = rad ? (double)rsw[k] : 0.;
+        x[8] = rad ? (double)rlw[k] : 0.;
+        bool ok = !((x[0] < 270.) || (x[0] > 320.));
+        ok = ok && !((x[1] < 180.) || (x[1] > 330.));
+        ok = ok && !((x[2] < 80000.) || (x[2] > 110000.));
+        ok = ok && !(x[5] > 50.);
+        if (rad) {
+            ok = ok && !((x[7] < 0.) || (x[7] > 1500.));
+            ok = ok && !((x[8] < 0.) || (x[8] > 750.));
+        }
+        if (ok) {
+            cnt += 1.;
+#pragma unroll
+            for (int f = 0; f < kStatFields; ++f) {
+                sum[f] += x[f];
+                mn[f] = x[f] < mn[f] ? x[f] : mn[f];
+                mx[f] = x[f] > mx[f] ? x[f] : mx[f];
+            }
+        }
+    }
+    __shared__ double red[kBlock / 64][kStatStride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto wsum = [](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
+    auto wmin = [](double v) { for (int o = 32; o > 0; o >>= 1) { double t = __shfl_down(v, o, 64); v = t < v ? t : v; } return v; };
+    auto wmax = [](double v) { for (int o = 32; o > 0; o >>= 1) { double t = __shfl_down(v, o, 64); v = t > v ? t : v; } return v; };
+    cnt = wsum(cnt);
+    if (lane == 0) red[wave][0] = cnt;
+#pragma unroll
+    for (int f = 0; f < kStatFields; ++f) {
+        const double s = wsum(sum[f]), a = wmin(mn[f]), b = wmax(mx[f]);
+        if (lane == 0) { red[wave][1 + 3 * f] = s; red[wave][2 + 3 * f] = a; red[wave][3 + 3 * f] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < kStatStride) {
+        const int j = threadIdx.x;
+        double r = red[0][j];
+        const int kind = (j == 0) ? 0 : ((j - 1) % 3);  // 0 sum, 1 min, 2 max
+        for (int w = 1; w < kBlock / 64; ++w) {
+            const double t = red[w][j];
+            r = (kind == 0) ? r + t : (kind == 1 ? (t < r ? t : r) : (t > r ? t : r));
+        }
+        partials[(long)blockIdx.x * kStatStride + j] = r;
+    }
+}
+
+hipError_t launch_init_stats(const void *sst, const void *t_air, const void *hum, const void *u, const void *v,
+                             const void *slp, const void *rad_sw, const void *rad_lw, long n, int f32,
+                             double *partials, hipStream_t stream)
+{
+    if (f32)
+        hipLaunchKernelGGL(init_stats_kernel<float>, dim3(kStatBlocks), dim3(kBlock), 0, stream, (const float *)sst,
+                           (const float *)t_air, (const float *)hum, (const float *)u, (const float *)v,
+                           (const float *)slp, (const float *)rad_sw, (const float *)rad_lw, n, partials);
+    else
+        hipLaunchKernelGGL(init_stats_kernel<double>, dim3(kStatBlocks), dim3(kBlock), 0, stream, (const double *)sst,
+                           (const double *)t_air, (const double *)hum, (const double *)u, (const double *)v,
+                           (const double *)slp, (const double *)rad_sw, (const double *)rad_lw, n, partials);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Synthetic inputs of SURVEY.md §8d.  Always evaluated in fp64, stored in R.
+template <class R>
+__global__ void __launch_bounds__(kBlock) synth_kernel(R *sst, R *t_zt, R *q_zt, R *u, R *v, R *slp, R *rsw, R *rlw,
+                                                       long ni, long j0, long n)
+{
+    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const double i = (double)(k % ni + 1), j = (double)(j0 + k / ni + 1);
+    const double A[7] = {0.6180339887498949, 0.5698402909980532, 0.8191725133961645, 0.4142135623730951,
+                         0.2360679774997897, 0.3166247903553998, 0.1231056256176606};
+    const double B[7] = {0.7548776662466927, 0.3247179572447460, 0.6710436067037893, 0.7320508075688772,
+                         0.6457513110645906, 0.6055512754639891, 0.3588989435406740};
+    const double C[7] = {0., 0.1, 0.2, 0.3, 0.4, 0.5, 0.6};
+    double r[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        const double x = i * A[m] + j * B[m] + C[m];
+        r[m] = x - floor(x);
+    }
+    const double s = 274.15 + 29. * r[0];
+    const double t = s - 6. + 9. * r[1];
+    const double p = 98000. + 5000. * r[2];
+    sst[k] = (R)s;
+    t_zt[k] = (R)t;
+    slp[k] = (R)p;
+    q_zt[k] = (R)((0.55 + 0.4 * r[3]) * q_sat<double>(t, p));
+    u[k] = (R)(-14. + 28. * r[4]);
+    v[k] = (R)(-14. + 28. * r[5]);
+    if (rsw) rsw[k] = (R)(900. * r[6]);
+    if (rlw) rlw[k] = (R)(250. + 200. * r[0]);
+}
+
+hipError_t launch_synth(void *sst, void *t_zt, void *q_zt, void *u, void *v, void *slp, void *rad_sw, void *rad_lw,
+                        long ni, long j0, long nj_local, int f32, hipStream_t stream)
+{
+    const long n = ni * nj_local;
+    const long nblk = (n + kBlock - 1) / kBlock;
+    if (nblk <= 0) return hipSuccess;
+    if (f32)
+        hipLaunchKernelGGL(synth_kernel<float>, dim3((unsigned)nblk), dim3(kBlock), 0, stream, (float *)sst,
+                           (float *)t_zt, (float *)q_zt, (float *)u, (float *)v, (float *)slp, (float *)rad_sw,
+                           (float *)rad_lw, ni, j0, n);
+    else
+        hipLaunchKernelGGL(synth_kernel<double>, dim3((unsigned)nblk), dim3(kBlock), 0, stream, (double *)sst,
+                           (double *)t_zt, (double *)q_zt, (double *)u, (double *)v, (double *)slp, (double *)rad_sw,
+                           (double *)rad_lw, ni, j0, n);
+    return hipGetLastError();
+}
+
+}  // namespace ab

@@ -1,0 +1,46 @@
+// ab_kernels.hpp — launch interface between the C-ABI runtime (ab_runtime.hip) and the
+// device kernels (ab_kernels.hip).  Internal; not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ab {
+
+// Wave-uniform description of one aerobulk_compute() call (mod_aerobulk_compute.f90:22-213).
+struct FluxCall {
+    // inputs (device pointers; element type follows `f32`)
+    const void *sst, *t_zt, *hum, *u, *v, *slp, *rad_sw, *rad_lw, *lon;
+    // outputs
+    void *ql, *qh, *tau_x, *tau_y, *evap, *t_s;
+    // warm-layer state planes dT_wl, Hz_wl, Qnt_ac, Tau_ac (mod_skin_coare.f90:31-36)
+    void *wl[4];
+    int *flags;     // bit0: wind stress > 10 N/m^2 somewhere (mod_phymbl.f90:1250)
+    long n;
+    double zt, zu;
+    int algo;       // enum ab_algo
+    int skin;       // cool-skin + warm-layer
+    int f32;        // element type
+    int nb_iter;
+    int hum_type;   // enum ab_hum
+    int wl_load;    // jt > 1: read state ; else initial values
+    int wl_store;   // jt < nt: write state back
+    int isecday;    // UTC seconds of day for WL_COARE (12 in aerobulk_compute)
+};
+
+hipError_t launch_flux(const FluxCall &c, hipStream_t stream);
+
+// AEROBULK_INIT statistics (mod_aerobulk.f90:104-153): per-block partial reductions.
+//  fields order: 0 sst,1 t_air,2 slp,3 u,4 v,5 wnd,6 hum,7 rad_sw,8 rad_lw
+//  partials layout per block: [count, then for each of 9 fields: sum, min, max] = 28 doubles
+constexpr int kStatFields = 9;
+constexpr int kStatStride = 1 + 3 * kStatFields;
+constexpr int kStatBlocks = 2048;
+hipError_t launch_init_stats(const void *sst, const void *t_air, const void *hum, const void *u, const void *v,
+                             const void *slp, const void *rad_sw, const void *rad_lw, long n, int f32,
+                             double *partials /* kStatBlocks*kStatStride */, hipStream_t stream);
+
+// Synthetic quasi-random fields of SURVEY.md §8d generated straight into HBM (bench utility):
+// rows j0 .. j0+nj_local-1 (0-based) of an ni-wide grid.
+hipError_t launch_synth(void *sst, void *t_zt, void *q_zt, void *u, void *v, void *slp, void *rad_sw,
+                        void *rad_lw, long ni, long j0, long nj_local, int f32, hipStream_t stream);
+
+}  // namespace ab

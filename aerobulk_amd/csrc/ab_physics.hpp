@@ -1,0 +1,847 @@
+// ab_physics.hpp — per-cell device physics of the bulk air-sea flux engine (HIP, gfx950).
+//
+// One wavefront lane owns one grid cell; everything below is scalar per lane and lives in
+// VGPRs.  Written from the physics (Fairall 1996/2003, Edson 2013, Large & Yeager 2004/2008,
+// IFS Cy40r1 ch.3, Zeng & Beljaars 2005, Andreas 2015, Grachev 2007) with the observable
+// behaviour of AeroBulk as the contract: each function cites the reference file:line
+// (brodeau/aerobulk `src/`) whose results it must reproduce to <=1e-10 relative.
+//
+// Differences w.r.t. the reference that are deliberate (not observable at 1e-10):
+//   * the reference evaluates BOTH the stable and unstable psi branches and blends them with
+//     a 0/1 weight; here the lane picks its branch (exact: the weight is exactly 0 or 1);
+//   * loop invariants (alpha_sw(SST), warm-layer constants, logs of heights) are hoisted;
+//   * `x**y` is strength-reduced (ab_math.hpp); a/exp(b) is a*exp(-b); sums of logs are fused.
+#pragma once
+#include "ab_math.hpp"
+
+namespace ab {
+
+template <class R> struct K {  // constants, mod_const.f90:38-114
+    static constexpr R grav = R(9.8);
+    static constexpr R rpi = R(3.141592653589793);
+    static constexpr R roce_alb0 = R(0.066);
+    static constexpr R emiss_w = R(0.98);
+    static constexpr R stefan = R(5.67E-8);
+    static constexpr R rt0 = R(273.15);
+    static constexpr R rCp0_w = R(4190.);
+    static constexpr R rho0_w = R(1025.);
+    static constexpr R rnu0_w = R(1.e-6);
+    static constexpr R rk0_w = R(0.6);
+    static constexpr R rCp_dry = R(1005.0);
+    static constexpr R rCp_vap = R(1860.0);
+    static constexpr R R_dry = R(287.05);
+    static constexpr R R_gas = R(8.314510);
+    static constexpr R rmm_dryair = R(28.9647e-3);
+    static constexpr R rmm_water = R(18.0153e-3);
+    static constexpr R rLevap = R(2.46e+6);
+    static constexpr R vkarmn = R(0.4);
+    static constexpr R vkarmn2 = R(0.4 * 0.4);
+    static constexpr R rdct_qsat_salt = R(0.98);
+    static constexpr R z0_sea_max = R(0.0025);
+    static constexpr R Cx_min = R(0.1E-3);
+    static constexpr R rdt = R(3600.);   // mod_const.f90:32
+    static constexpr R gdept1 = R(1.);   // mod_const.f90:31
+    static constexpr R rpoiss_dry = R(287.05 / 1005.0);
+    static constexpr R rgamma_dry = R(9.8 / 1005.0);
+    static constexpr R reps0 = R(287.05 / 461.495);
+    static constexpr R one_m_reps0 = R(1. - 287.05 / 461.495);
+    static constexpr R rctv0 = R(461.495 / 287.05 - 1.);
+    // -16*9.80665*rho0_w*rCp0_w*rnu0_w^3/rk0_w^2, mod_const.f90:109
+    static constexpr R rcst_cs = R(-16. * 9.80665 * 1025. * 4190. * 1.e-6 * 1.e-6 * 1.e-6 / (0.6 * 0.6));
+    static constexpr R sq_radrw = R(0.034215956910732065);  // sqrt(1.2/1025.), mod_const.f90:112
+    static constexpr R inv_vk = R(2.5);                    // 1/0.4 (exact in binary up to 1 ulp of 0.4)
+};
+
+// ---------------------------------------------------------------- thermodynamics (mod_phymbl.f90)
+// e_sat_sclr :777-800 — Goff (1957), T floored at 180 K
+template <class R> __device__ __forceinline__ R e_sat(R pTa)
+{
+    using M = Mth<R>;
+    const R zta = vmax(pTa, R(180.));
+    const R ztmp = K<R>::rt0 / zta;
+    const R zx = zta / K<R>::rt0;
+    const R e = R(10.79574) * (R(1.) - ztmp) - R(5.028) * M::log10(zx)
+                + R(1.50475E-4) * (R(1.) - M::exp10(R(-8.2969) * (zx - R(1.))))
+                + R(0.42873E-3) * (M::exp10(R(4.76955) * (R(1.) - ztmp)) - R(1.)) + R(0.78614);
+    return R(100.) * M::exp10(e);
+}
+// q_sat_sclr :881-904
+template <class R> __device__ __forceinline__ R q_sat(R pTa, R pslp)
+{
+    const R ze_s = e_sat(pTa);
+    return K<R>::reps0 * ze_s / (pslp - K<R>::one_m_reps0 * ze_s);
+}
+// q_air_rh :963-985
+template <class R> __device__ __forceinline__ R q_air_rh(R prha, R pTa, R pslp)
+{
+    const R ze = R(0.01) * prha * e_sat(pTa);
+    return ze * K<R>::reps0 / vmax(pslp - K<R>::one_m_reps0 * ze, R(1.));
+}
+// q_air_dp :990-1000
+template <class R> __device__ __forceinline__ R q_air_dp(R da, R pslp)
+{
+    const R q = vmax(e_sat(da), R(0.));
+    return q * K<R>::reps0 / vmax(pslp - K<R>::one_m_reps0 * q, R(1.));
+}
+// Theta_from_z_P0_T_q :343-375 = Pz_from_P0_tz_qz_sclr :283-318 (3 barometric iterations) + Poisson :189-200
+template <class R> __device__ __forceinline__ R theta_from_z_p0_t_q(R pz, R pslp, R pTa, R pqa)
+{
+    using M = Mth<R>;
+    // e_sat(pTa) does not depend on the pressure iterate: evaluate once (the reference recomputes it)
+    const R ze_s = e_sat(pTa);
+    const R c = -K<R>::grav * pz / (K<R>::R_gas * pTa);
+    R zpa = pslp;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const R zqsat = K<R>::reps0 * ze_s / (zpa - K<R>::one_m_reps0 * ze_s);
+        const R zf = pqa / zqsat;
+        const R zxm = (R(1.) - zf) * K<R>::rmm_dryair + zf * K<R>::rmm_water;
+        zpa = pslp * M::exp(c * zxm);
+    }
+    return pTa * M::exp(K<R>::rpoiss_dry * M::log(pslp / zpa));
+}
+// virt_temp_sclr :247-269
+template <class R> __device__ __forceinline__ R virt_temp(R t, R q) { return t * (R(1.) + K<R>::rctv0 * q); }
+// rho_air_sclr :522-537
+template <class R> __device__ __forceinline__ R rho_air(R pTa, R pqa, R pslp)
+{
+    return vmax(pslp / (K<R>::R_dry * pTa * (R(1.) + K<R>::rctv0 * pqa)), R(0.8));
+}
+// visc_air_sclr :549-563
+template <class R> __device__ __forceinline__ R visc_air(R pTa)
+{
+    const R ztc = pTa - K<R>::rt0;
+    const R ztc2 = ztc * ztc;
+    return R(1.326e-5) * (R(1.) + R(6.542E-3) * ztc + R(8.301e-6) * ztc2 - R(4.84e-9) * ztc2 * ztc);
+}
+// One_on_L_sclr :666-693
+template <class R> __device__ __forceinline__ R one_on_l(R pThta, R pqa, R pus, R pts, R pqs)
+{
+    const R zqa = R(1.) + K<R>::rctv0 * pqa;
+    const R r = K<R>::grav * K<R>::vkarmn * (pts * zqa + K<R>::rctv0 * pThta * pqs)
+                / vmax(pus * pus * pThta * zqa, R(1.E-9));
+    return sclamp(r, R(200.));
+}
+// Ri_bulk_sclr :712-747 (layer arguments are never passed on this path)
+template <class R> __device__ __forceinline__ R ri_bulk(R pz, R psst, R pThta, R pssq, R pqa, R pub)
+{
+    const R zsstv = virt_temp(psst, pssq);
+    const R zdthv = virt_temp(pThta, pqa) - zsstv;
+    const R ztv = R(0.5) * (zsstv + virt_temp(pThta - K<R>::rgamma_dry * pz, pqa));
+    return K<R>::grav * zdthv * pz / (ztv * pub * pub);
+}
+// BULK_FORMULA_SCLR :1149-1203 (open ocean: l_ice false)
+template <class R>
+__device__ __forceinline__ void bulk_formula(R pzu, R pts, R pqs, R pThta, R pqa, R pCd, R pCh, R pCe, R pwnd,
+                                             R pUb, R pslp, R &pTau, R &pQsen, R &pQlat, R &pEvap)
+{
+    const R zta = pThta - K<R>::rgamma_dry * pzu;
+    R zrho = rho_air(zta, pqa, pslp);
+    zrho = rho_air(zta, pqa, pslp - zrho * K<R>::grav * pzu);
+    const R zUrho = pUb * vmax(zrho, R(1.));
+    pTau = zUrho * pCd * pwnd;
+    pEvap = zUrho * pCe * (pqa - pqs);
+    pQsen = zUrho * pCh * (pThta - pts) * (K<R>::rCp_dry + K<R>::rCp_vap * pqa);
+    pQlat = (R(2.501) - R(0.00237) * (pts - K<R>::rt0)) * R(1.e6) * pEvap;  // L_vap :590
+}
+// UPDATE_QNSOL_TAU_SCLR :1059-1103 (+ qlw_net_sclr :1291-1314)
+template <class R>
+__device__ __forceinline__ void update_qnsol_tau(R pzu, R pts, R pqs, R pThta, R pqa, R pust, R ptst, R pqst,
+                                                 R pwnd, R pUb, R pslp, R prlw, R &pQns, R &pTau, R &pQlat)
+{
+    const R zdt = sfloor(pThta - pts, R(1.E-09));
+    const R zdq = sfloor(pqa - pqs, R(1.E-12));
+    const R zz0 = pust / pUb;
+    R zQsen, zEvap;
+    bulk_formula(pzu, pts, pqs, pThta, pqa, zz0 * zz0, zz0 * ptst / zdt, zz0 * pqst / zdq, pwnd, pUb, pslp, pTau,
+                 zQsen, pQlat, zEvap);
+    const R zt2 = pts * pts;
+    pQns = pQlat + zQsen + K<R>::emiss_w * (prlw - K<R>::stefan * zt2 * zt2);
+}
+// alpha_sw_sclr :1267-1280
+template <class R> __device__ __forceinline__ R alpha_sw(R psst)
+{
+    return R(2.1e-5) * pow_pos(vmax(psst - K<R>::rt0 + R(3.2), R(0.)), R(0.79));
+}
+
+// ---------------------------------------------------------------- cool skin
+// CS_COARE mod_skin_coare.f90:48-93 (c0 = 0.137, latent-heat term) and CS_ECMWF
+// mod_skin_ecmwf.f90:68-110 (c0 = 0.065) around delta_skin_layer_sclr mod_phymbl.f90:2010-2046.
+// palpha = alpha_sw(SST) is hoisted by the caller.
+template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R pQnsol, R pustar, R palpha, R pQlat)
+{
+    using M = Mth<R>;
+    const R c0 = COARE ? R(0.137) : R(0.065);
+    // invariants of the five delta evaluations
+    const R zusw = vmax(pustar, R(1.E-4)) * K<R>::sq_radrw;
+    const R zusw2 = zusw * zusw;
+    const R zA = palpha * K<R>::rcst_cs / (zusw2 * zusw2);
+    const R ztmp = K<R>::rnu0_w / zusw;
+    const R zql = COARE ? R(0.026) * vmin(pQlat, R(0.)) * K<R>::rCp0_w / K<R>::rLevap / palpha : R(0.);
+    const R zdwarm = vmin(R(6.) * ztmp, R(0.007));
+    auto delta = [&](R pQd) -> R {
+        const R zQd = pQd + zql;
+        if (nonneg(zQd)) return zdwarm;                       // warming of the viscous layer (rare)
+        const R x = vmax(zA * zQd, R(0.));
+        const R sx = M::sqrt(x);
+        return R(6.) * M::rcbrt(R(1.) + sx * M::sqrt(sx)) * ztmp;  // 6 (1 + x^0.75)^(-1/3) nu/u*w
+    };
+    R zQabs = pQnsol;
+    R zdelta = delta(zQabs);
+#pragma unroll 1
+    for (int jc = 0; jc < 4; ++jc) {
+        const R zfr = vmax(c0 + R(11.) * zdelta - R(6.6E-5) / zdelta * (R(1.) - M::exp(-zdelta / R(8.E-4))), R(0.01));
+        zQabs = pQnsol + zfr * pQsw;
+        zdelta = delta(zQabs);
+    }
+    return zQabs * zdelta / K<R>::rk0_w;
+}
+
+// ---------------------------------------------------------------- warm layer, COARE 3.6
+// WL_COARE mod_skin_coare.f90:97-250.  State st = {dT_wl, Hz_wl, Qnt_ac, Tau_ac}.
+// Hoisted per cell: zcd1, zcd2 (depend on alpha_sw(SST) only), `dawn` (solar time 4h-6.5h).
+template <class R> struct WlCoareCell {
+    R zcd1, zcd2;
+    bool dawn;
+};
+template <class R> __device__ __forceinline__ R wl_absorb(R zHwl)
+{
+    // 1 - (0.28*0.014*(1-e^{-H/0.014}) + 0.27*0.357*(1-e^{-H/0.357}) + 0.45*12.82*(1-e^{-H/12.82}))/H  :167-168
+    // exp(x) for x < -40 rounds 1-exp(x) to exactly 1 in fp64 (and fp32): skip those evaluations.
+    using M = Mth<R>;
+    const R a1 = zHwl / R(0.014), a2 = zHwl / R(0.357);
+    const R e1 = a1 > R(40.) ? R(1.) : R(1.) - M::exp(-a1);
+    const R e2 = a2 > R(40.) ? R(1.) : R(1.) - M::exp(-a2);
+    const R e3 = R(1.) - M::exp(-zHwl / R(12.82));
+    return R(1.) - (R(0.28) * R(0.014) * e1 + R(0.27) * R(0.357) * e2 + R(0.45) * R(12.82) * e3) / zHwl;
+}
+template <class R>
+__device__ __forceinline__ void wl_coare(R (&st)[4], const WlCoareCell<R> &c, R pQsw, R pQnsol, R pTau, bool commit)
+{
+    using M = Mth<R>;
+    const R Hwl_max = R(20.);
+    R zdTwl = st[0];
+    R zHwl = vmax(vmin(st[1], Hwl_max), R(0.1));
+    R zqac = st[2];
+    R ztac = st[3];
+    bool l_exit = c.dawn, l_destroy = c.dawn;  // dawn reset :159-163
+    R zQabs = R(0.);
+    if (!l_exit) {
+        zQabs = wl_absorb(zHwl) * pQsw + pQnsol;                                   // :167-169
+        if ((M::abs(zdTwl) < R(1.E-6)) && (zQabs <= R(0.))) l_exit = true;         // :171-176
+    }
+    if (!l_exit && (st[2] + zQabs * K<R>::rdt <= R(0.))) { l_exit = true; l_destroy = true; }  // :182-185
+    if (!l_exit) {
+        ztac = st[3] + vmax(R(.002), pTau) * K<R>::rdt;                            // :199
+#pragma unroll 1
+        for (int jl = 0; jl < 5; ++jl) {                                           // :204-211
+            zQabs = wl_absorb(zHwl) * pQsw + pQnsol;
+            zqac = st[2] + zQabs * K<R>::rdt;
+            if (zqac <= R(0.)) break;
+            zHwl = vmax(vmin(Hwl_max, c.zcd1 * ztac / M::sqrt(zqac)), R(0.1));
+        }
+        if (zqac <= R(0.)) {
+            l_destroy = true;
+        } else {
+            zdTwl = c.zcd2 * (zqac * M::sqrt(zqac)) / ztac;                        // :220 (zqac > 0 here)
+            if (!nonneg(K<R>::gdept1 - zHwl)) zdTwl = zdTwl * (K<R>::gdept1 / zHwl);  // :223-224
+        }
+    }
+    if (l_destroy) { zdTwl = R(0.); zHwl = Hwl_max; zqac = R(0.); ztac = R(0.); }   // :229-235
+    if (commit) { st[0] = zdTwl; st[1] = zHwl; st[2] = zqac; st[3] = ztac; }        // :239-248
+}
+// local solar time test of WL_COARE :146-163 -> true inside the dawn-reset window ]4h, 6.5h]
+template <class R> __device__ __forceinline__ bool wl_coare_dawn(R plon, int isd)
+{
+    using M = Mth<R>;
+    auto fmodulo = [](R a, R p) -> R { return a - M::floor(a / p) * p; };
+    R rlag = R(-1.) * fmodulo((R(360.) - fmodulo(plon, R(360.))) / R(15.), R(24.));
+    rlag = R(-1.) * M::copysign(vmin(M::abs(rlag), M::abs(fmodulo(rlag, R(24.)))), rlag + R(12.));
+    const int ilag = (int)(rlag * R(3600.));
+    int isd_sol = (isd + ilag) % 86400;
+    if (isd_sol < 0) isd_sol += 86400;
+    const R rhr = (R)isd_sol / R(3600.);
+    return (rhr > R(4.)) && (rhr <= R(6.5));
+}
+
+// ---------------------------------------------------------------- warm layer, ECMWF (Zeng & Beljaars 2005 / Takaya 2010)
+// PHI mod_skin_ecmwf.f90:233-253
+template <class R> __device__ __forceinline__ R phi_takaya(R z)
+{
+    using M = Mth<R>;
+    if (nonneg(z)) return R(1.) + (R(5.) * z + R(4.) * z * z) / (R(1.) + R(3.) * z + R(0.25) * z * z);
+    return R(1.) / M::sqrt(R(1.) - R(16.) * (-M::abs(z)));
+}
+// WL_ECMWF mod_skin_ecmwf.f90:113-230 (no Stokes drift).  Advances dT_wl on EVERY call (:228).
+template <class R> __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, R pQsw, R pQnsol, R pustar, R zalpha)
+{
+    using M = Mth<R>;
+    const R zRhoCp_w = K<R>::rho0_w * K<R>::rCp0_w;
+    const R rNuwl0 = R(0.5);
+    const R ztcorr = nonneg(K<R>::gdept1 - zHwl) ? R(1.) : K<R>::gdept1 / zHwl;
+    const R zdTwl_b = vmax(dT_wl / ztcorr, R(0.));
+    const R zfr = R(1.) - R(0.28) * M::exp(R(-71.5) * zHwl) - R(0.27) * M::exp(R(-2.8) * zHwl)
+                  - R(0.45) * M::exp(R(-0.07) * zHwl);
+    const R zQabs = zfr * pQsw + pQnsol;
+    const R zusw = vmax(pustar, R(1.E-4)) * K<R>::sq_radrw;
+    const R zusw2 = zusw * zusw;
+    const R zfLa = R(2.231443166940565);  // MAX(0.3**(-2/3), 1) :185
+    const bool zwf = nonneg(zQabs);
+    const R zcst1 = K<R>::vkarmn * K<R>::grav * zalpha;
+    const R zL2 = zcst1 * zQabs / (zRhoCp_w * zusw2 * zusw);
+    const R zcst2 = zcst1 / (R(5.) * zHwl * zusw2);
+    const R zcst0 = K<R>::rdt * (rNuwl0 + R(1.)) / zHwl;
+    const R zA = zcst0 * zQabs / (rNuwl0 * zRhoCp_w);
+    const R zcst3 = -zcst0 * K<R>::vkarmn * zusw * zfLa;
+    R zdTwl_n = zdTwl_b;
+    // when zQabs >= 0 the stability parameter does not depend on the iterate: PHI is loop-invariant
+    const R zB_warm = zcst3 / phi_takaya(zHwl * zL2);
+#pragma unroll 1
+    for (int jc = 0; jc < 10; ++jc) {
+        zdTwl_n = R(0.5) * (zdTwl_n + zdTwl_b);
+        R zB = zB_warm;
+        if (!zwf) zB = zcst3 / phi_takaya(zHwl * M::sqrt(zdTwl_n * zcst2));
+        zdTwl_n = vmax(zdTwl_b + zA + zB * zdTwl_n, R(0.));
+    }
+    dT_wl = zdTwl_n * ztcorr;
+}
+
+// ---------------------------------------------------------------- COARE stability functions (mod_common_coare.f90)
+// psi_m_coare_sclr :217-254 and psi_h_coare_sclr :305-344 at the same zeta
+template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
+{
+    using M = Mth<R>;
+    if (nonneg(z)) {  // stable: Beljaars & Holtslag (1991)
+        const R zc = vmin(R(50.), R(0.35) * z);
+        const R t = R(0.6667) * (z - R(14.28)) * M::exp(-zc);
+        if (pm) *pm = -(R(1.) + z + t + R(8.525));
+        if (ph) {
+            const R a = M::abs(R(1.) + R(2.) * z / R(3.));
+            *ph = -(a * M::sqrt(a) + t + R(8.525));
+        }
+    } else {  // unstable: Kansas / free-convection blend
+        R zf = z * z;
+        zf = zf / (R(1.) + zf);
+        if (pm) {
+            const R x2 = M::sqrt(M::abs(R(1.) - R(15.) * z));
+            const R x = M::sqrt(x2);
+            const R hx = R(0.5) * (R(1.) + x);
+            const R psik = M::log(hx * hx * (R(0.5) * (R(1.) + x2))) - R(2.) * M::atan(x) + R(0.5) * K<R>::rpi;
+            const R c = pow_pos(M::abs(R(1.) - R(10.15) * z), R(.3333));
+            const R psic = R(1.5) * M::log((R(1.) + c + c * c) / R(3.))
+                           - R(1.7320508) * M::atan((R(1.) + R(2.) * c) / R(1.7320508)) + R(1.813799447);
+            *pm = (R(1.) - zf) * psik + zf * psic;
+        }
+        if (ph) {
+            const R x2 = M::sqrt(M::abs(R(1.) - R(15.) * z));
+            const R psik = R(2.) * M::log(R(0.5) * (R(1.) + x2));
+            const R c = pow_pos(M::abs(R(1.) - R(34.15) * z), R(.3333));
+            const R psic = R(1.5) * M::log((R(1.) + c + c * c) / R(3.))
+                           - R(1.7320508) * M::atan((R(1.) + R(2.) * c) / R(1.7320508)) + R(1.813799447);
+            *ph = (R(1.) - zf) * psik + zf * psic;
+        }
+    }
+}
+template <class R> __device__ __forceinline__ R psi_h_coare(R z) { R h; psi_coare<R>(z, nullptr, &h); return h; }
+template <class R> __device__ __forceinline__ R psi_m_coare(R z) { R m; psi_coare<R>(z, &m, nullptr); return m; }
+
+// charn_coare3p6_sclr mod_blk_coare3p6.f90:417-432 (Edson 2013 Eq.13)
+template <class R> __device__ __forceinline__ R charn_coare3p6(R w)
+{
+    return vmax(vmin(R(0.0017) * w - R(0.005), R(0.028)), R(0.));
+}
+// charn_coare3p0 mod_blk_coare3p0.f90:420-447 (Hare 1999 ramp 10..18 m/s)
+template <class R> __device__ __forceinline__ R charn_coare3p0(R w)
+{
+    if (!nonneg(w - R(10.))) return R(0.011);
+    if (nonneg(w - R(18.))) return R(0.018);
+    return R(0.011) + R(0.018 - 0.011) * (w - R(10.)) / R(18. - 10.);
+}
+
+// FIRST_GUESS_COARE_SCLR mod_common_coare.f90:33-179 (shared by COARE 3.0/3.6 and ECMWF)
+template <class R> struct Heights {  // wave-uniform, prepared on the host
+    R zt, zu, log_zt, log_zu, log_10, log_ztu, log_zu10, fg_ca;
+    int zt_eq_zu;  // ABS(zu-zt) < 0.01
+};
+template <class R>
+__device__ __forceinline__ void first_guess_coare(const Heights<R> &h, R psst, R t_zt, R pssq, R q_zt, R U_zu,
+                                                  R pcharn, R &pus, R &pts, R &pqs, R &t_zu, R &q_zu, R &Ubzu,
+                                                  R &pz0)
+{
+    using M = Mth<R>;
+    const R vk = K<R>::vkarmn;
+    t_zu = vmax(t_zt, R(180.));
+    q_zu = vmax(q_zt, R(1.e-6));
+    const R zc_b = R(0.004 * 600. * 1.2 * 1.2 * 1.2);
+    R zdt = sfloor(t_zu - psst, R(1.E-09));
+    R zdq = sfloor(q_zu - pssq, R(1.E-12));
+    const R zNu_a = visc_air(t_zu);
+    const R zUb = M::sqrt(U_zu * U_zu + R(0.25));
+    R zus = h.fg_ca * zUb;  // zc_a = 0.035*LOG(10/z0)/LOG(zu/z0), z0 = 1e-4 :107
+    R zz0 = pcharn * zus * zus / K<R>::grav + R(0.11) * zNu_a / zus;
+    zz0 = vmin(vmax(M::abs(zz0), R(1.E-8)), R(1.));
+    const R zlog_z0 = M::log(zz0);
+    R zCd = vk / (h.log_zu - zlog_z0);
+    zCd = zCd * zCd;
+    const R z1_o_sqrt_Cd10 = (h.log_10 - zlog_z0) / vk;
+    R zz0t = R(10.) * M::exp(-vk / (R(0.00115) * z1_o_sqrt_Cd10));
+    zz0t = vmin(vmax(M::abs(zz0t), R(1.E-8)), R(1.));
+    const R zlog_z0t = M::log(zz0t);
+    const R zRib = ri_bulk(h.zu, psst, t_zu, pssq, q_zu, zUb);
+    const R zcc_ri = K<R>::vkarmn2 / (zCd * (h.log_zt - zlog_z0t)) * zRib;
+    R zzeta_u;
+    if (nonneg(zRib)) zzeta_u = zcc_ri + R(27.) / R(9.) * zRib * zRib;
+    else zzeta_u = zcc_ri / (R(1.) + zRib * (-zc_b / h.zu));
+    R psm, psh;
+    psi_coare<R>(zzeta_u, &psm, &psh);
+    zus = vmax(zUb * vk / (h.log_zu - zlog_z0 - psm), R(1.E-9));
+    const R ztmp = vk / (h.log_zu - zlog_z0t - psh);
+    R zts = zdt * ztmp;
+    R zqs = zdq * ztmp;
+    if (!h.zt_eq_zu) {
+        const R zzeta_t = h.zt * zzeta_u / h.zu;
+        const R zprf = h.log_ztu + psh - psi_h_coare<R>(zzeta_t);
+        t_zu = t_zt - zts / vk * zprf;
+        q_zu = q_zt - zqs / vk * zprf;
+        q_zu = nonneg(q_zu) ? q_zu : R(0.) * q_zu;
+        zdt = sfloor(t_zu - psst, R(1.E-09));
+        zdq = sfloor(q_zu - pssq, R(1.E-12));
+        zts = zdt * ztmp;
+        zqs = zdq * ztmp;
+    }
+    pus = zus; pts = zts; pqs = zqs; Ubzu = zUb;
+    zz0 = pcharn * zus * zus / K<R>::grav + R(0.11) * zNu_a / zus;
+    pz0 = vmin(vmax(M::abs(zz0), R(1.E-8)), R(1.));
+}
+
+// ---------------------------------------------------------------- per-cell inputs / outputs of a TURB_* routine
+template <class R> struct CellIn {
+    R sst, theta_zt, ssq, q_zt, wnd, slp;  // after the pre-processing of aerobulk_compute :99-126
+    R qsw, rlw;                            // (1-albedo)*rad_sw, rad_lw   (skin only)
+};
+template <class R> struct CellOut {
+    R Cd, Ch, Ce, t_zu, q_zu, Ubzu, T_s, q_s;
+};
+
+// ---------------------------------------------------------------- TURB_COARE3P6 / turb_coare3p0
+// mod_blk_coare3p6.f90:123-413, mod_blk_coare3p0.f90:54-358.  V36 selects the version; SKIN = cool-skin AND
+// warm-layer (aerobulk_compute always switches both on together, mod_aerobulk_compute.f90:133,144).
+template <class R, bool V36, bool SKIN>
+__device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
+                                           bool dawn, CellOut<R> &o)
+{
+    using M = Mth<R>;
+    const R vk = K<R>::vkarmn;
+    const R Beta0 = V36 ? R(1.2) : R(1.25);
+    const R zi0 = R(600.), zeta_max = R(50.);
+    const R zUzu = in.wnd;
+    const R xSST = in.sst;
+    R T_s = in.sst, q_s = in.ssq;
+    R zalpha = R(0.);
+    WlCoareCell<R> wc{R(0.), R(0.), dawn};
+    if (SKIN) {
+        T_s = T_s - R(0.25);                                           // :274
+        q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);  // :275
+        zalpha = alpha_sw(xSST);                                       // hoisted from CS_COARE :81 / WL_COARE :153
+        const R Rich0 = R(0.65);
+        wc.zcd1 = M::sqrt(R(2.) * Rich0 * K<R>::rCp0_w / (zalpha * K<R>::grav * K<R>::rho0_w));   // :155
+        wc.zcd2 = M::sqrt(R(2.) * zalpha * K<R>::grav / (Rich0 * K<R>::rho0_w))
+                  / R(271219.5770957547);                             // rCp0_w**1.5 :156
+    }
+    R zus, zts, zqs, t_zu, q_zu, Ubzu, zz0;
+    first_guess_coare(h, T_s, in.theta_zt, q_s, in.q_zt, zUzu, V36 ? charn_coare3p6(zUzu) : charn_coare3p0(zUzu),
+                      zus, zts, zqs, t_zu, q_zu, Ubzu, zz0);
+    R zlog_z0 = M::log(zz0);
+    const R znu_a = visc_air(V36 ? t_zu : in.theta_zt);  // 3p6 :294 (first-guess t_zu) vs 3p0 :237 (t_zt)
+    R zdt = sfloor(t_zu - T_s, R(1.E-09));
+    R zdq = sfloor(q_zu - q_s, R(1.E-12));
+    R zdT_cs = R(0.);
+
+#pragma unroll 1
+    for (int jit = 1; jit <= nb_iter; ++jit) {
+        const R zus2 = zus * zus;
+        const R z1oL = one_on_l(t_zu, q_zu, zus, zts, zqs);            // :307-308 (second clamp is idempotent)
+        // gustiness :311-313: Ug^2 = Beta0^2 u*^2 (max(-zi0/(kappa L),0))^(2/3)
+        const R zg = vmax(-zi0 * z1oL / vk, R(0.));
+        const R zcb = M::cbrt(zg);
+        const R zgust2 = Beta0 * Beta0 * zus2 * (zcb * zcb);
+        Ubzu = vmax(M::sqrt(zUzu * zUzu + zgust2), R(0.2));
+        const R zzta_u = sclamp(h.zu * z1oL, zeta_max);                // :317-318
+        // roughness lengths :328-336 (3p0 :270-278)
+        const R zUn10 = zus / vk * (h.log_10 - zlog_z0);
+        zz0 = (V36 ? charn_coare3p6(zUn10) : charn_coare3p0(zUn10)) * zus2 / K<R>::grav + R(0.11) * znu_a / zus;
+        zz0 = vmin(vmax(M::abs(zz0), R(1.E-9)), R(1.));
+        zlog_z0 = M::log(zz0);
+        // z0t = min(1.6e-4, 5.8e-5 Rr^-0.72) (3p6) | min(1.1e-4, 5.5e-5 Rr^-0.6) (3p0); log taken analytically
+        const R zlog_rr = M::log(znu_a / (zz0 * zus));
+        R zz0t = V36 ? vmin(R(1.6E-4), R(5.8E-5) * M::exp(R(0.72) * zlog_rr))
+                     : vmin(R(1.1E-4), R(5.5E-5) * M::exp(R(0.6) * zlog_rr));
+        zz0t = vmin(vmax(M::abs(zz0t), R(1.E-9)), R(1.));
+        const R zlog_z0t = M::log(zz0t);
+        // turbulent scales :339-344
+        R psm, psh;
+        psi_coare<R>(zzta_u, &psm, &psh);
+        R ztmp1 = vk / (h.log_zu - zlog_z0t - psh);
+        zts = zdt * ztmp1;
+        zqs = zdq * ztmp1;
+        zus = vmax(Ubzu * vk / (h.log_zu - zlog_z0 - psm), R(1.E-9));
+        if (!h.zt_eq_zu) {                                             // :346-351 (3p0 :289-291 with zm_ztzu = 1)
+            const R zzta_t = sclamp(h.zt * z1oL, zeta_max);
+            ztmp1 = h.log_zt - h.log_zu + psh - psi_h_coare<R>(zzta_t);
+            t_zu = in.theta_zt - zts / vk * ztmp1;
+            q_zu = in.q_zt - zqs / vk * ztmp1;
+        } else if (!V36) {                                             // 3p0: t_zu = t_zt - 0*...  (drops the 180 K floor)
+            t_zu = in.theta_zt;
+            q_zu = in.q_zt;
+        }
+        if (SKIN) {
+            R zQns, zTau, zQlat;
+            update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
+                             zQlat);                                   // :355-356
+            zdT_cs = cool_skin<R, true>(in.qsw, zQns, zus, zalpha, zQlat);  // :358
+            T_s = xSST + zdT_cs;
+            T_s = T_s + wl[0];                                         // :360-361
+            q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
+            update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
+                             zQlat);                                   // :367-368
+            wl_coare(wl, wc, in.qsw, zQns, zTau, (nb_iter % jit) == 0);  // :370  iwait = MOD(nb_iter,jit)
+            T_s = xSST + wl[0];
+            T_s = T_s + zdT_cs;                                        // :373-374
+            q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
+        }
+        if (!V36 || SKIN || !h.zt_eq_zu) {                             // :378-381 (3p0 :317-318 unconditional)
+            zdt = sfloor(t_zu - T_s, R(1.E-09));
+            zdq = sfloor(q_zu - q_s, R(1.E-12));
+        }
+    }
+    const R ztmp0 = zus / Ubzu;                                        // :386-389
+    o.Cd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);
+    o.Ch = vmax(ztmp0 * zts / zdt, K<R>::Cx_min);
+    o.Ce = vmax(ztmp0 * zqs / zdq, K<R>::Cx_min);
+    o.t_zu = t_zu; o.q_zu = q_zu; o.Ubzu = Ubzu; o.T_s = T_s; o.q_s = q_s;
+}
+
+// ---------------------------------------------------------------- ECMWF (mod_blk_ecmwf.f90)
+// psi_m_ecmwf_scl :441-477, psi_h_ecmwf_scl :498-533, cap_zeta :551-564
+template <class R> __device__ __forceinline__ void psi_ecmwf(R pz, R *pm, R *ph)
+{
+    using M = Mth<R>;
+    const R zc = R(5. / 0.35);
+    const R z = vmin(vmax(pz, R(-50.)), R(5.));
+    if (nonneg(z)) {
+        const R t = R(-2. / 3.) * (z - zc) * M::exp(R(-0.35) * z);
+        if (pm) *pm = t - z - R(2. / 3.) * zc;
+        if (ph) {
+            const R a = M::abs(R(1.) + R(2. / 3.) * z);
+            *ph = t - a * M::sqrt(a) - R(2. / 3.) * zc + R(1.);
+        }
+    } else {
+        const R x2 = M::sqrt(M::abs(R(1.) - R(16.) * z));
+        if (pm) {
+            const R x = M::sqrt(x2);
+            const R t = R(1.) + x;
+            *pm = M::log(R(0.125) * t * t * (R(1.) + x2)) - R(2.) * M::atan(x) + R(0.5) * K<R>::rpi;
+        }
+        if (ph) *ph = R(2.) * M::log(R(0.5) * (R(1.) + x2));
+    }
+}
+template <class R> __device__ __forceinline__ R psi_m_ecmwf(R z) { R m; psi_ecmwf<R>(z, &m, nullptr); return m; }
+template <class R> __device__ __forceinline__ R psi_h_ecmwf(R z) { R v; psi_ecmwf<R>(z, nullptr, &v); return v; }
+
+// turb_ecmwf :63-383
+template <class R, bool SKIN>
+__device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
+                                           CellOut<R> &o)
+{
+    using M = Mth<R>;
+    const R vk = K<R>::vkarmn;
+    const R charn0 = R(0.018), zi0 = R(1000.), alpha_M = R(0.11), alpha_H = R(0.40), alpha_Q = R(0.62);
+    const R zm_ztzu = h.zt_eq_zu ? R(0.) : R(1.);
+    const R zUzu = in.wnd, zSST = in.sst;
+    R zT_s = in.sst, zq_s = in.ssq;
+    R zalpha = R(0.);
+    if (SKIN) {
+        zT_s = zT_s - R(0.25);                                          // :214
+        zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
+        zalpha = alpha_sw(zSST);
+    }
+    R zus, zts, zqs, zt_zu, zq_zu, zUbzu, zz0;
+    first_guess_coare(h, zT_s, in.theta_zt, zq_s, in.q_zt, zUzu, charn0, zus, zts, zqs, zt_zu, zq_zu, zUbzu, zz0);
+    R zlog_z0 = M::log(zz0);
+    const R znu_a = visc_air(in.theta_zt);                              // :238
+    R zdt = sfloor(zt_zu - zT_s, R(1.E-09));
+    R zdq = sfloor(zq_zu - zq_s, R(1.E-12));
+    R z1oL = one_on_l(zt_zu, zq_zu, zus, zts, zqs);                     // :245
+    R zzeta_u = h.zu * z1oL;
+    // :249  z0t = 1/(0.1 exp(kappa/(0.00115/(kappa/(ln10 - ln z0)))))
+    R zz0t = R(1.) / (R(0.1) * M::exp(vk / (R(0.00115) / (vk / (h.log_10 - zlog_z0)))));
+    zz0t = vmin(vmax(M::abs(zz0t), R(1.E-9)), R(1.));
+    R zlog_z0t = M::log(zz0t);
+    R zpsi_m_u, zpsi_h_u;
+    psi_ecmwf<R>(zzeta_u, &zpsi_m_u, &zpsi_h_u);
+    R zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf<R>(zz0 * z1oL);   // :253
+    R zFh = h.log_zu - zlog_z0t - zpsi_h_u + psi_h_ecmwf<R>(zz0t * z1oL); // :255
+    R zlog_z0q = R(0.), zpsi_h_z0q = R(0.), zdT_cs = R(0.);
+
+#pragma unroll 1
+    for (int jit = 1; jit <= nb_iter; ++jit) {
+        const R zRib = ri_bulk(h.zu, zT_s, zt_zu, zq_s, zq_zu, zUbzu);  // :261 (previous Ub, T_s, q_s)
+        z1oL = sclamp(zRib * zFm * zFm / zFh / h.zu, R(200.));          // :264-266
+        zzeta_u = h.zu * z1oL;
+        psi_ecmwf<R>(zzeta_u, &zpsi_m_u, &zpsi_h_u);                    // :269-270
+        const R zpsi_h_t = psi_h_ecmwf<R>(h.zt * z1oL);                 // :272-273
+        zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf<R>(zz0 * z1oL);  // :276
+        zus = zUbzu * vk / zFm;                                         // :279
+        const R zus2 = zus * zus;
+        R ztmp0 = znu_a / zus;
+        zz0 = vmin(M::abs(alpha_M * ztmp0 + charn0 * zus2 / K<R>::grav), R(0.001));  // :282-284
+        zz0t = vmin(M::abs(alpha_H * ztmp0), R(0.001));
+        const R zz0q = vmin(M::abs(alpha_Q * ztmp0), R(0.001));
+        zlog_z0 = M::log(zz0);
+        zlog_z0t = M::log(zz0t);
+        zlog_z0q = M::log(zz0q);
+        const R zpsi_m_z0 = psi_m_ecmwf<R>(zz0 * z1oL);                 // :290-292
+        const R zpsi_h_z0t = psi_h_ecmwf<R>(zz0t * z1oL);
+        zpsi_h_z0q = psi_h_ecmwf<R>(zz0q * z1oL);
+        // gustiness :296-298 (Beta0 = 1)
+        const R zcb = M::cbrt(vmax(-zi0 * z1oL / vk, R(0.)));
+        zUbzu = vmax(M::sqrt(zUzu * zUzu + zus2 * (zcb * zcb)), R(0.2));
+        // t*, q* and height adjustment :303-313
+        ztmp0 = zpsi_h_u - zpsi_h_z0t;
+        R ztmp1 = vk / (h.log_zu - zlog_z0t - ztmp0);
+        zts = zdt * ztmp1;
+        ztmp1 = h.log_ztu + ztmp0 - zpsi_h_t + zpsi_h_z0t;
+        zt_zu = in.theta_zt - zm_ztzu * zts / vk * ztmp1;
+        ztmp0 = zpsi_h_u - zpsi_h_z0q;
+        ztmp1 = vk / (h.log_zu - zlog_z0q - ztmp0);
+        zqs = zdq * ztmp1;
+        ztmp1 = h.log_ztu + ztmp0 - zpsi_h_t + zpsi_h_z0q;
+        zq_zu = vmax(in.q_zt - zm_ztzu * zqs / vk * ztmp1, R(0.));
+        zFm = h.log_zu - zlog_z0 - zpsi_m_u + zpsi_m_z0;                // :316-317
+        zFh = h.log_zu - zlog_z0t - zpsi_h_u + zpsi_h_z0t;
+        if (SKIN) {
+            R zQns, zTau, zQlat;
+            update_qnsol_tau(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
+                             zQlat);                                    // :321-322
+            zdT_cs = cool_skin<R, false>(in.qsw, zQns, zus, zalpha, R(0.));  // :324
+            zT_s = zSST + zdT_cs;
+            zT_s = zT_s + wl[0];
+            zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
+            update_qnsol_tau(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
+                             zQlat);                                    // :333-334
+            wl_ecmwf(wl[0], wl[1], in.qsw, zQns, zus, zalpha);          // :335
+            zT_s = zSST + wl[0];
+            zT_s = zT_s + zdT_cs;
+            zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
+        }
+        zdt = sfloor(zt_zu - zT_s, R(1.E-09));                          // :342-343
+        zdq = sfloor(zq_zu - zq_s, R(1.E-12));
+    }
+    const R zFq = h.log_zu - zlog_z0q - zpsi_h_u + zpsi_h_z0q;          // :356-359
+    o.Cd = vmax(K<R>::vkarmn2 / (zFm * zFm), K<R>::Cx_min);
+    o.Ch = vmax(K<R>::vkarmn2 / (zFm * zFh), K<R>::Cx_min);
+    o.Ce = vmax(K<R>::vkarmn2 / (zFm * zFq), K<R>::Cx_min);
+    o.t_zu = zt_zu; o.q_zu = zq_zu; o.Ubzu = zUbzu; o.T_s = zT_s; o.q_s = zq_s;
+}
+
+// ---------------------------------------------------------------- NCAR (mod_blk_ncar.f90, Large & Yeager 2004/2008)
+// cd_n10_ncar_sclr :244-271
+template <class R> __device__ __forceinline__ R cd_n10_ncar(R zw)
+{
+    R r;
+    if (nonneg(zw - R(33.))) {
+        r = R(1.e-3) * R(2.34);
+    } else {
+        R zw6 = zw * zw * zw;
+        zw6 = zw6 * zw6;
+        r = R(1.e-3) * (R(2.7) / zw + R(0.142) + zw / R(13.09) - R(3.14807E-10) * zw6);
+    }
+    return vmax(r, K<R>::Cx_min);
+}
+// psi_m_ncar_sclr :333-363 / psi_h_ncar_sclr :379-407
+template <class R> __device__ __forceinline__ void psi_ncar(R z, R *pm, R *ph)
+{
+    using M = Mth<R>;
+    if (nonneg(z)) {
+        if (pm) *pm = R(-5.) * z;
+        if (ph) *ph = R(-5.) * z;
+    } else {
+        const R x2 = vmax(M::sqrt(M::abs(R(1.) - R(16.) * z)), R(1.));
+        if (pm) {
+            const R x = M::sqrt(x2);
+            const R hx = (R(1.) + x) * R(0.5);
+            *pm = M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan(x) + K<R>::rpi * R(0.5);
+        }
+        if (ph) *ph = R(2.) * M::log(R(0.5) * (R(1.) + x2));
+    }
+}
+// turb_ncar :57-240
+template <class R>
+__device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &in, int nb_iter, CellOut<R> &o)
+{
+    using M = Mth<R>;
+    const R vk = K<R>::vkarmn;
+    const R sst = in.sst, ssq = in.ssq;
+    const R Ubzu = vmax(R(0.5), in.wnd);                                // :148
+    bool stab = nonneg(virt_temp(in.theta_zt, in.q_zt) - virt_temp(sst, ssq));  // :158
+    R zCdN = cd_n10_ncar(Ubzu);
+    R zsqrt_CdN = M::sqrt(zCdN);
+    R Cd = zCdN;
+    R Ce = vmax(R(1.e-3) * (R(34.6) * zsqrt_CdN), K<R>::Cx_min);         // ce_n10 :321
+    R Ch = vmax(R(1.e-3) * zsqrt_CdN * (stab ? R(18.) : R(32.7)), K<R>::Cx_min);  // ch_n10 :301
+    R zsqrt_Cd = zsqrt_CdN;
+    R t_zu = vmax(in.theta_zt, R(180.));
+    R q_zu = vmax(in.q_zt, R(1.e-6));
+#pragma unroll 1
+    for (int jit = 1; jit <= nb_iter; ++jit) {
+        const R zdt = t_zu - sst;                                       // :177-178 (not floored)
+        const R zdq = q_zu - ssq;
+        const R zus = zsqrt_Cd * Ubzu;
+        const R zts = Ch / zsqrt_Cd * zdt;
+        const R zqs = Ce / zsqrt_Cd * zdq;
+        const R z1oL = one_on_l(t_zu, q_zu, zus, zts, zqs);
+        const R zeta_u = sclamp(h.zu * z1oL, R(10.));                   // :189-190
+        R psm, psh;
+        psi_ncar<R>(zeta_u, &psm, &psh);
+        if (!h.zt_eq_zu) {                                              // :193-200
+            const R zeta_t = sclamp(h.zt * z1oL, R(10.));
+            R psht;
+            psi_ncar<R>(zeta_t, nullptr, &psht);
+            const R ztmp = h.log_ztu + psh - psht;
+            t_zu = in.theta_zt - zts / vk * ztmp;
+            q_zu = in.q_zt - zqs / vk * ztmp;
+            q_zu = vmax(R(0.), q_zu);
+        }
+        // UN10_from_CD mod_phymbl.f90:1545 with z0_from_Cd :1346:
+        //   sqrt(Cd) Ub/kappa * ln(10/(zu exp(-(kappa/sqrt(Cd)+psi)))) = sqrt(Cd) Ub/kappa * (ln(10/zu) + kappa/sqrt(Cd) + psi)
+        const R zsq = M::sqrt(Cd);
+        const R zUn10 = vmax(R(0.25), zsq * Ubzu / vk * (-h.log_zu10 + (vk / zsq + psm)));  // :207
+        zCdN = cd_n10_ncar(zUn10);
+        zsqrt_CdN = M::sqrt(zCdN);
+        R ztmp = R(1.) + zsqrt_CdN / vk * (h.log_zu10 - psm);           // :213
+        Cd = vmax(zCdN / (ztmp * ztmp), K<R>::Cx_min);
+        zsqrt_Cd = M::sqrt(Cd);
+        ztmp = (h.log_zu10 - psh) / vk / zsqrt_CdN;                     // :217
+        const R ztmp2 = zsqrt_Cd / zsqrt_CdN;
+        stab = nonneg(zeta_u);                                          // :220
+        const R zChN = R(1.e-3) * zsqrt_CdN * (stab ? R(18.) : R(32.7));
+        const R zCeN = R(1.e-3) * (R(34.6) * zsqrt_CdN);
+        Ch = vmax(zChN * ztmp2 / (R(1.) + zChN * ztmp), K<R>::Cx_min);
+        Ce = vmax(zCeN * ztmp2 / (R(1.) + zCeN * ztmp), K<R>::Cx_min);
+    }
+    o.Cd = Cd; o.Ch = Ch; o.Ce = Ce; o.t_zu = t_zu; o.q_zu = q_zu; o.Ubzu = Ubzu; o.T_s = sst; o.q_s = ssq;
+}
+
+// ---------------------------------------------------------------- ANDREAS (mod_blk_andreas.f90, Andreas et al. 2015)
+// psi_m_andreas :307-360 — Paulson unstable, Grachev et al. (2007) stable
+template <class R> __device__ __forceinline__ R psi_m_andreas(R pz)
+{
+    using M = Mth<R>;
+    const R z = vmin(pz, R(15.));
+    if (nonneg(z)) {
+        const R zam = R(5.), zbm = R(5. / 6.5), zsr3 = R(1.7320508075688772);
+        const R zbbm = R(0.6694329500821695);  // ((1-b_m)/b_m)^(1/3) = 0.3^(1/3)
+        const R x = M::cbrt(M::abs(R(1.) + z));
+        const R l1 = (x + zbbm) / (R(1.) + zbbm);
+        const R l2 = (x * x - x * zbbm + zbbm * zbbm) / (R(1.) - zbbm + zbbm * zbbm);
+        return R(-3.) * zam / zbm * (x - R(1.))
+               + zam * zbbm / (R(2.) * zbm)
+                     * (M::log(l1 * l1 / l2)
+                        + R(2.) * zsr3 * (M::atan((R(2.) * x - zbbm) / (zsr3 * zbbm)) - M::atan((R(2.) - zbbm) / (zsr3 * zbbm))));
+    }
+    const R x2 = vmax(M::sqrt(M::abs(R(1.) - R(16.) * z)), R(1.));
+    const R x = M::sqrt(x2);
+    const R hx = (R(1.) + x) * R(0.5);
+    return M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan(x) + K<R>::rpi * R(0.5);
+}
+// psi_h_andreas :363-410
+template <class R> __device__ __forceinline__ R psi_h_andreas(R pz)
+{
+    using M = Mth<R>;
+    const R z = vmin(pz, R(15.));
+    if (nonneg(z)) {
+        const R zah = R(5.), zbh = R(5.), zch = R(3.), zbbh = R(2.23606797749979);
+        const R zz = R(2.) * z + zch;
+        // LOG|(zz-B)/(zz+B)| - LOG|(c-B)/(c+B)|
+        const R r = ((zz - zbbh) / (zz + zbbh)) / ((zch - zbbh) / (zch + zbbh));
+        return R(-0.5) * zbh * M::log(M::abs(R(1.) + zch * z + z * z))
+               + (-zah / zbbh + R(0.5) * zbh * zch / zbbh) * M::log(M::abs(r));
+    }
+    const R x2 = vmax(M::sqrt(M::abs(R(1.) - R(16.) * z)), R(1.));
+    return R(2.) * M::log(R(0.5) * (R(1.) + x2));
+}
+// z0tq_LKB mod_phymbl.f90:1635-1701 (Liu, Katsaros & Businger 1979): both z0t (iflag 1) and z0q (iflag 2)
+template <class R> __device__ __forceinline__ void z0tq_lkb(R zrr, R pz0, R &z0t, R &z0q)
+{
+    using M = Mth<R>;
+    R rt = R(-999.), rq = R(-999.);
+    if ((zrr > R(0.)) && (zrr < R(1000.))) {
+        R at, bt, aq, bq;
+        if (zrr <= R(0.11))       { at = R(0.177);   bt = R(0.);     aq = R(0.292);   bq = R(0.); }
+        else if (zrr <= R(0.825)) { at = R(1.376);   bt = R(0.929);  aq = R(1.808);   bq = R(0.826); }
+        else if (zrr <= R(3.0))   { at = R(1.026);   bt = R(-0.599); aq = R(1.393);   bq = R(-0.528); }
+        else if (zrr <= R(10.0))  { at = R(1.625);   bt = R(-1.018); aq = R(1.956);   bq = R(-0.870); }
+        else if (zrr <= R(30.0))  { at = R(4.661);   bt = R(-1.475); aq = R(4.994);   bq = R(-1.297); }
+        else if (zrr <= R(100.))  { at = R(34.904);  bt = R(-2.067); aq = R(30.709);  bq = R(-1.845); }
+        else if (zrr <= R(300.))  { at = R(1667.19); bt = R(-2.907); aq = R(1448.68); bq = R(-2.682); }
+        else                      { at = R(5.88e5);  bt = R(-3.935); aq = R(2.98e5);  bq = R(-3.616); }
+        const R lr = M::log(zrr);
+        rt = at * M::exp(bt * lr) * pz0 / zrr;
+        rq = aq * M::exp(bq * lr) * pz0 / zrr;
+    }
+    z0t = vmin(vmax(M::abs(rt), R(1.E-9)), R(0.05));
+    z0q = vmin(vmax(M::abs(rq), R(1.E-9)), R(0.05));
+}
+// turb_andreas :66-272
+template <class R>
+__device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R> &in, int nb_iter, CellOut<R> &o)
+{
+    using M = Mth<R>;
+    const R vk = K<R>::vkarmn;
+    const R psst = in.sst, pssq = in.ssq;
+    const R pUbzu = vmax(R(0.25), in.wnd);                              // :157
+    R UN10 = pUbzu;
+    R pt_zu = in.theta_zt, pq_zu = in.q_zt;
+    const R sq0 = M::sqrt(R(1.1E-3));
+    R t_star = R(1.1E-3) / sq0 * (pt_zu - psst);                        // :168-170
+    R q_star = R(1.1E-3) / sq0 * (pq_zu - pssq);
+    R RiB = ri_bulk(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);             // :173
+    R u_star = R(0.);
+#pragma unroll 1
+    for (int jit = 1; jit <= nb_iter; ++jit) {
+        if (RiB < R(0.15)) {                                            // :183-191
+            const R za = UN10 - R(8.271);                               // u_star_andreas_sclr :289-291
+            u_star = R(0.239) + R(0.0433) * (za + M::sqrt(R(0.12) * za * za + R(0.181)));
+        } else {
+            u_star = R(0.01) * pUbzu;                                   // SQRT(Cx_min) = 1e-2
+        }
+        const R zeta_u = h.zu * one_on_l(pt_zu, pq_zu, u_star, t_star, q_star);  // :200
+        R ztmp0 = u_star / pUbzu;
+        const R pCd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);                // :209
+        const R psm = psi_m_andreas<R>(zeta_u);
+        const R z0 = vmin(h.zu * M::exp(-(vk / M::sqrt(pCd) + psm)), K<R>::z0_sea_max);  // :214
+        ztmp0 = z0 * u_star / visc_air(pt_zu);                          // :219 Re_r
+        R z0t, z0q;
+        z0tq_lkb(ztmp0, z0, z0t, z0q);                                  // :220-221
+        const R psh = psi_h_andreas<R>(zeta_u);
+        t_star = (pt_zu - psst) * vk / (h.log_zu - M::log(z0t) - psh);  // :226-227
+        q_star = (pq_zu - pssq) * vk / (h.log_zu - M::log(z0q) - psh);
+        if ((!h.zt_eq_zu) && (jit > 1)) {                               // :229-236
+            const R zeta_t = zeta_u / h.zu * h.zt;
+            const R zp = h.log_ztu + psh - psi_h_andreas<R>(zeta_t);
+            pt_zu = in.theta_zt - t_star / vk * zp;
+            pq_zu = in.q_zt - q_star / vk * zp;
+            RiB = ri_bulk(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);
+        }
+        UN10 = vmax(R(0.1), pUbzu - u_star / vk * (h.log_zu10 - psm));  // :239 (UN10_from_ustar mod_phymbl.f90:1508)
+    }
+    const R ztmp0 = u_star / pUbzu;                                     // :247-254
+    o.Cd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);
+    const R d1 = sfloor(pt_zu - psst, R(1.E-6));
+    const R d2 = sfloor(pq_zu - pssq, R(1.E-9));
+    o.Ch = vmax(ztmp0 * t_star / d1, R(0.35E-3));
+    o.Ce = vmax(ztmp0 * q_star / d2, R(0.35E-3));
+    o.t_zu = pt_zu; o.q_zu = pq_zu; o.Ubzu = pUbzu; o.T_s = psst; o.q_s = pssq;
+}
+
+}  // namespace ab

@@ -1,0 +1,527 @@
+// ab_runtime.hip — C-ABI runtime of the MI355X bulk-flux engine (include/aerobulk_amd.h).
+//
+// Owns what the reference keeps in Fortran module globals (mod_const.f90:22-33, warm-layer SAVE
+// arrays mod_skin_coare.f90:31-36 / mod_skin_ecmwf.f90:52-55): here it is per-session state living
+// in HBM.  There is NO CPU fallback: every entry point needs a gfx950 device and returns
+// AB_ERR_HIP (with a message) when none is usable.
+#include "../../include/aerobulk_amd.h"
+#include "ab_kernels.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define AB_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(AB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+const char *kAlgoNames[6] = {"other", "coare3p0", "coare3p6", "ncar", "ecmwf", "andreas"};
+
+bool algo_has_skin(int algo) { return algo == AB_ALGO_COARE3P0 || algo == AB_ALGO_COARE3P6 || algo == AB_ALGO_ECMWF; }
+
+}  // namespace
+
+struct ab_session {
+    int algo = 0, nt = 1, use_skin = 0, f32 = 0, device = 0;
+    long ni = 0, nj = 0, n = 0;
+    size_t esz = 8;
+    int hum_type = AB_HUM_SH;
+    int last_jt = 0;
+    int isecday = 12;                 // mod_aerobulk_compute.f90:136,146
+    void *d_lon = nullptr;            // optional longitude field (device, session-owned copy)
+    void *wl[4] = {nullptr, nullptr, nullptr, nullptr};
+    int *d_flags = nullptr;
+    double *d_partials = nullptr;
+    void *stage_in[8] = {nullptr};    // device staging for AB_MEM_HOST callers
+    void *stage_out[6] = {nullptr};
+    hipStream_t stream = nullptr;     // session stream for host-mem calls
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+extern "C" {
+
+int ab_algo_from_string(const char *calgo, int len)
+{
+    if (!calgo) return 0;
+    size_t l = len < 0 ? strlen(calgo) : (size_t)len;
+    while (l > 0 && (calgo[l - 1] == ' ' || calgo[l - 1] == '\0')) --l;  // TRIM(calgo)
+    for (int a = 1; a <= 5; ++a)
+        if (strlen(kAlgoNames[a]) == l && strncmp(kAlgoNames[a], calgo, l) == 0) return a;
+    return 0;
+}
+
+const char *ab_algo_name(int algo) { return (algo >= 0 && algo <= 5) ? kAlgoNames[algo] : "unknown"; }
+
+const char *ab_strerror(int st)
+{
+    switch (st) {
+    case AB_OK: return "ok";
+    case AB_ERR_ALGO: return "unknown bulk algorithm";
+    case AB_ERR_SKIN_ALGO: return "Only `COARE*` and `ECMWF` algorithms support cool-skin & warm/layer schemes";
+    case AB_ERR_SKIN_NORAD: return "provide SW and LW rad. input if you want to use skin schemes";
+    case AB_ERR_JT: return "jt < 1 !??";
+    case AB_ERR_ALL_MASKED: return "the whole domain is masked! check unit consistency of input fields";
+    case AB_ERR_HUM_TYPE: return "un-identified humidity type";
+    case AB_ERR_UNITS: return "input field does not seem to be in the expected unit";
+    case AB_ERR_TAU: return "wind stress too strong (> 10 N/m^2)";
+    case AB_ERR_HIP: return "HIP runtime error / no usable gfx950 device";
+    case AB_ERR_ARG: return "bad argument";
+    case AB_ERR_STATE: return "call protocol violated";
+    default: return "unknown status";
+    }
+}
+
+const char *ab_last_error(void) { return g_err.c_str(); }
+
+int ab_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int use_skin, int precision, int device)
+{
+    if (!out) return fail(AB_ERR_ARG, "ab_session_create: out == NULL");
+    *out = nullptr;
+    if (algo < AB_ALGO_COARE3P0 || algo > AB_ALGO_ANDREAS)
+        return fail(AB_ERR_ALGO, "bulk algorithm id %d is unknown!!!", algo);
+    if (ni <= 0 || nj <= 0 || nt < 1) return fail(AB_ERR_ARG, "ab_session_create: bad shape %ld x %ld, nt=%d", ni, nj, nt);
+    if (use_skin && !algo_has_skin(algo))
+        return fail(AB_ERR_SKIN_ALGO, " AEROBULK_INIT => Only `COARE*` and `ECMWF` algorithms support cool-skin & warm/layer schemes");
+    if (precision != AB_F64 && precision != AB_F32) return fail(AB_ERR_ARG, "bad precision %d", precision);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(AB_ERR_HIP, "no HIP device visible: this engine has no CPU fallback");
+    if (device < 0) AB_HIP(hipGetDevice(&device));
+    if (device >= ndev) return fail(AB_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    AB_HIP(hipSetDevice(device));
+    ab_session *s = new ab_session;
+    s->algo = algo; s->ni = ni; s->nj = nj; s->n = ni * nj; s->nt = nt; s->use_skin = use_skin ? 1 : 0;
+    s->f32 = (precision == AB_F32); s->esz = s->f32 ? 4 : 8; s->device = device;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
+    chk(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    chk(hipEventCreate(&s->ev0));
+    chk(hipEventCreate(&s->ev1));
+    chk(hipMalloc((void **)&s->d_flags, sizeof(int)));
+    chk(hipMalloc((void **)&s->d_partials, sizeof(double) * ab::kStatBlocks * ab::kStatStride));
+    if (e == hipSuccess) chk(hipMemset(s->d_flags, 0, sizeof(int)));
+    if (s->use_skin && nt > 1) {  // persistent warm-layer planes; a single record keeps them in registers
+        const int np = (algo == AB_ALGO_ECMWF) ? 2 : 4;
+        for (int p = 0; p < np; ++p) chk(hipMalloc(&s->wl[p], s->esz * (size_t)s->n));
+    }
+    if (e != hipSuccess) {
+        ab_session_destroy(s);
+        return fail(AB_ERR_HIP, "ab_session_create: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return AB_OK;
+}
+
+int ab_session_destroy(ab_session *s)
+{
+    if (!s) return AB_OK;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto &p : s->wl) if (p) (void)hipFree(p);
+    for (auto &p : s->stage_in) if (p) (void)hipFree(p);
+    for (auto &p : s->stage_out) if (p) (void)hipFree(p);
+    if (s->d_lon) (void)hipFree(s->d_lon);
+    if (s->d_flags) (void)hipFree(s->d_flags);
+    if (s->d_partials) (void)hipFree(s->d_partials);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return AB_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// copy caller host arrays into the session's device staging (allocated on first use)
+int stage_inputs(ab_session *s, const void *const host[8], const void *dev[8])
+{
+    const size_t bytes = s->esz * (size_t)s->n;
+    for (int i = 0; i < 8; ++i) {
+        dev[i] = nullptr;
+        if (!host[i]) continue;
+        if (!s->stage_in[i]) AB_HIP(hipMalloc(&s->stage_in[i], bytes));
+        AB_HIP(hipMemcpyAsync(s->stage_in[i], host[i], bytes, hipMemcpyHostToDevice, s->stream));
+        dev[i] = s->stage_in[i];
+    }
+    return AB_OK;
+}
+
+struct FieldStat { double sum, mn, mx; };
+
+}  // namespace
+
+extern "C" {
+
+int ab_session_set_humidity(ab_session *s, int hum_type)
+{
+    if (!s) return fail(AB_ERR_ARG, "NULL session");
+    if (hum_type < AB_HUM_SH || hum_type > AB_HUM_RH) return fail(AB_ERR_HUM_TYPE, "humidty type %d is unknown!!!", hum_type);
+    s->hum_type = hum_type;
+    return AB_OK;
+}
+
+int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int mem)
+{
+    if (!s) return fail(AB_ERR_ARG, "NULL session");
+    AB_HIP(hipSetDevice(s->device));
+    s->isecday = isecday_utc;
+    if (!lon) {
+        if (s->d_lon) { (void)hipFree(s->d_lon); s->d_lon = nullptr; }
+        return AB_OK;
+    }
+    const size_t bytes = s->esz * (size_t)s->n;
+    if (!s->d_lon) AB_HIP(hipMalloc(&s->d_lon, bytes));
+    AB_HIP(hipMemcpy(s->d_lon, lon, bytes, mem == AB_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return AB_OK;
+}
+
+int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt, const void *u_zu,
+                    const void *v_zu, const void *slp, const void *rad_sw, const void *rad_lw, int mem,
+                    ab_init_report *report)
+{
+    if (!s) return fail(AB_ERR_ARG, "NULL session");
+    if (!sst || !t_zt || !hum_zt || !u_zu || !v_zu || !slp) return fail(AB_ERR_ARG, "ab_session_init: NULL input field");
+    AB_HIP(hipSetDevice(s->device));
+    const void *host[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw};
+    const void *dev[8];
+    if (mem == AB_MEM_HOST) {
+        // rad_sw == rad_lw is the reference's own call pattern (mod_aerobulk.f90:248): stage once
+        if (rad_sw && rad_sw == rad_lw) host[6] = nullptr;
+        int rc = stage_inputs(s, host, dev);
+        if (rc) return rc;
+        if (rad_sw && rad_sw == rad_lw) dev[6] = dev[7];
+    } else {
+        for (int i = 0; i < 8; ++i) dev[i] = host[i];
+    }
+    const bool rad = dev[6] && dev[7];
+    AB_HIP(ab::launch_init_stats(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], rad ? dev[6] : nullptr,
+                                 rad ? dev[7] : nullptr, s->n, s->f32, s->d_partials, s->stream));
+    std::vector<double> part((size_t)ab::kStatBlocks * ab::kStatStride);
+    AB_HIP(hipMemcpyAsync(part.data(), s->d_partials, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    AB_HIP(hipStreamSynchronize(s->stream));
+
+    double cnt = 0.;
+    FieldStat st[ab::kStatFields];
+    for (auto &f : st) { f.sum = 0.; f.mn = 1.e300; f.mx = -1.e300; }
+    for (int b = 0; b < ab::kStatBlocks; ++b) {
+        const double *p = &part[(size_t)b * ab::kStatStride];
+        cnt += p[0];
+        for (int f = 0; f < ab::kStatFields; ++f) {
+            st[f].sum += p[1 + 3 * f];
+            if (p[2 + 3 * f] < st[f].mn) st[f].mn = p[2 + 3 * f];
+            if (p[3 + 3 * f] > st[f].mx) st[f].mx = p[3 + 3 * f];
+        }
+    }
+    ab_init_report rep;
+    memset(&rep, 0, sizeof rep);
+    rep.n_cells = s->n;
+    rep.n_masked = s->n - (long)cnt;
+    rep.hum_type = -1;
+    rep.bad_field = -1;
+    if (report) *report = rep;
+    if (cnt <= 0.)  // mod_aerobulk.f90:121-123
+        return fail(AB_ERR_ALL_MASKED, "the whole domain is masked!\n check unit consistency of input fields");
+
+    // type_of_humidity, mod_phymbl.f90:1984-2003
+    const double hmean = st[6].sum / cnt, hmin = st[6].mn, hmax = st[6].mx;
+    double hlo, hhi;
+    if ((hmean >= 0.) && (hmean < 0.08) && (hmin >= 0.) && (hmax < 0.08)) { rep.hum_type = AB_HUM_SH; hlo = 0.; hhi = 0.08; }
+    else if ((hmean >= 150.) && (hmean < 330.) && (hmin >= 150.) && (hmax < 330.)) { rep.hum_type = AB_HUM_DP; hlo = 150.; hhi = 330.; }
+    else if ((hmean >= 0.) && (hmean <= 100.) && (hmin >= 0.) && (hmax <= 100.)) { rep.hum_type = AB_HUM_RH; hlo = 0.; hhi = 100.; }
+    else {
+        if (report) *report = rep;
+        return fail(AB_ERR_HUM_TYPE,
+                    "ERROR: type_of_humidity()@mod_aerobulk_compute => un-identified humidity type!\n"
+                    "   ==> we could not identify the humidity type based on the mean, min & max of the field:\n"
+                    "     * mean = %g\n     * min  = %g\n     * max  = %g", hmean, hmin, hmax);
+    }
+    s->hum_type = rep.hum_type;
+
+    // check_unit_consistency x7(+2), mod_aerobulk.f90:143-153 ; ranges mod_phymbl.f90:1885-1940
+    static const char *names[9] = {"sst", "t_air", "slp", "u10", "v10", "wnd", "hum", "rad_sw", "rad_lw"};
+    static const char *units[9] = {"K", "K", "Pa", "m/s", "m/s", "m/s", "kg/kg", "W/m^2", "W/m^2"};
+    const double lo[9] = {270., 180., 80000., -50., -50., 0., hlo, 0., 0.};
+    const double hi[9] = {320., 330., 110000., 50., 50., 50., hhi, 1500., 750.};
+    const int nf = rad ? 9 : 7;
+    for (int f = 0; f < nf; ++f) {
+        const double mean = st[f].sum / cnt;
+        if ((st[f].mx > hi[f]) || (st[f].mn < lo[f]) || (mean < lo[f]) || (mean > hi[f])) {
+            rep.bad_field = f; rep.bad_min = st[f].mn; rep.bad_max = st[f].mx; rep.bad_mean = mean;
+            if (report) *report = rep;
+            return fail(AB_ERR_UNITS,
+                        " *** ERROR (check_unit_consistency@mod_phymbl): field `%s` does not seem to be in %s !\n"
+                        " min value = %10.3e max value = %10.3e mean value = %10.3e",
+                        names[f], units[f], st[f].mn, st[f].mx, mean);
+        }
+    }
+    if (report) *report = rep;
+    return AB_OK;
+}
+
+int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, const void *sst, const void *t_zt,
+                       const void *hum_zt, const void *u_zu, const void *v_zu, const void *slp, const void *rad_sw,
+                       const void *rad_lw, void *ql, void *qh, void *tau_x, void *tau_y, void *evap, void *t_s,
+                       int mem, void *stream)
+{
+    if (!s) return fail(AB_ERR_ARG, "NULL session");
+    if (jt < 1) return fail(AB_ERR_JT, "AEROBULK_MODEL => jt < 1 !??\n we are in a Fortran world here...");
+    if (jt > s->nt) return fail(AB_ERR_STATE, "jt=%d > nt=%d", jt, s->nt);
+    if (!sst || !t_zt || !hum_zt || !u_zu || !v_zu || !slp) return fail(AB_ERR_ARG, "ab_session_compute: NULL input field");
+    if (!ql || !qh || !tau_x || !tau_y) return fail(AB_ERR_ARG, "ab_session_compute: NULL output field");
+    if (s->use_skin && (!rad_sw || !rad_lw))
+        return fail(AB_ERR_SKIN_NORAD, " AEROBULK_INIT => provide SW and LW rad. input if you want to use skin schemes");
+    if (niter < 0) return fail(AB_ERR_ARG, "niter < 0");
+    if (s->use_skin && s->nt > 1 && jt > 1 && s->last_jt != jt - 1 && s->last_jt != jt)
+        return fail(AB_ERR_STATE, "warm-layer state: record jt=%d requested after jt=%d", jt, s->last_jt);
+    AB_HIP(hipSetDevice(s->device));
+
+    hipStream_t st = (mem == AB_MEM_HOST) ? s->stream : (hipStream_t)stream;
+    const void *host_in[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, s->use_skin ? rad_sw : nullptr,
+                              s->use_skin ? rad_lw : nullptr};
+    const void *din[8];
+    void *hout[6] = {ql, qh, tau_x, tau_y, evap, t_s};
+    void *dout[6];
+    const size_t bytes = s->esz * (size_t)s->n;
+    if (mem == AB_MEM_HOST) {
+        int rc = stage_inputs(s, host_in, din);
+        if (rc) return rc;
+        for (int i = 0; i < 6; ++i) {
+            dout[i] = nullptr;
+            if (!hout[i]) continue;
+            if (!s->stage_out[i]) AB_HIP(hipMalloc(&s->stage_out[i], bytes));
+            dout[i] = s->stage_out[i];
+        }
+    } else {
+        for (int i = 0; i < 8; ++i) din[i] = host_in[i];
+        for (int i = 0; i < 6; ++i) dout[i] = hout[i];
+    }
+
+    ab::FluxCall c;
+    memset(&c, 0, sizeof c);
+    c.sst = din[0]; c.t_zt = din[1]; c.hum = din[2]; c.u = din[3]; c.v = din[4]; c.slp = din[5];
+    c.rad_sw = din[6]; c.rad_lw = din[7]; c.lon = s->d_lon;
+    c.ql = dout[0]; c.qh = dout[1]; c.tau_x = dout[2]; c.tau_y = dout[3]; c.evap = dout[4]; c.t_s = dout[5];
+    for (int p = 0; p < 4; ++p) c.wl[p] = s->wl[p];
+    c.flags = s->d_flags;
+    c.n = s->n; c.zt = zt; c.zu = zu;
+    c.algo = s->algo; c.skin = s->use_skin; c.f32 = s->f32;
+    c.nb_iter = niter; c.hum_type = s->hum_type;
+    c.wl_load = (s->use_skin && jt > 1 && s->wl[0]) ? 1 : 0;      // kt == nit000 initialises, mod_blk_coare3p6.f90:250
+    c.wl_store = (s->use_skin && jt < s->nt && s->wl[0]) ? 1 : 0;  // freed at kt == nitend, :411
+    c.isecday = s->isecday;
+
+    AB_HIP(hipEventRecord(s->ev0, st));
+    AB_HIP(ab::launch_flux(c, st));
+    AB_HIP(hipEventRecord(s->ev1, st));
+    s->timed = true;
+    s->last_stream = st;
+    s->last_jt = jt;
+
+    if (mem == AB_MEM_HOST) {
+        for (int i = 0; i < 6; ++i)
+            if (hout[i]) AB_HIP(hipMemcpyAsync(hout[i], dout[i], bytes, hipMemcpyDeviceToHost, st));
+        return ab_session_check(s);
+    }
+    return AB_OK;
+}
+
+int ab_session_check(ab_session *s)
+{
+    if (!s) return fail(AB_ERR_ARG, "NULL session");
+    AB_HIP(hipSetDevice(s->device));
+    hipStream_t st = s->last_stream;
+    int flags = 0;
+    AB_HIP(hipMemcpyAsync(&flags, s->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    AB_HIP(hipStreamSynchronize(st));
+    if (flags) {
+        AB_HIP(hipMemsetAsync(s->d_flags, 0, sizeof(int), st));
+        AB_HIP(hipStreamSynchronize(st));
+        if (flags & 1) return fail(AB_ERR_TAU, "BULK_FORMULA_VCTR()@mod_phymbl: wind stress too strong!\n => > 10 N/m^2 !");
+    }
+    return AB_OK;
+}
+
+int ab_session_get_wl_state(ab_session *s, double *state4n)
+{
+    if (!s || !state4n) return fail(AB_ERR_ARG, "NULL argument");
+    if (!s->wl[0]) return fail(AB_ERR_STATE, "session keeps no persistent warm-layer state (no skin scheme or nt == 1)");
+    AB_HIP(hipSetDevice(s->device));
+    AB_HIP(hipDeviceSynchronize());
+    const size_t n = (size_t)s->n;
+    for (int p = 0; p < 4; ++p) {
+        double *dst = state4n + (size_t)p * n;
+        if (!s->wl[p]) { for (size_t k = 0; k < n; ++k) dst[k] = 0.; continue; }
+        if (!s->f32) {
+            AB_HIP(hipMemcpy(dst, s->wl[p], n * sizeof(double), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> tmp(n);
+            AB_HIP(hipMemcpy(tmp.data(), s->wl[p], n * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < n; ++k) dst[k] = tmp[k];
+        }
+    }
+    return AB_OK;
+}
+
+double ab_session_last_kernel_ms(ab_session *s)
+{
+    if (!s || !s->timed) return -1.;
+    if (hipSetDevice(s->device) != hipSuccess) return -1.;
+    if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, s->ev0, s->ev1) != hipSuccess) return -1.;
+    return (double)ms;
+}
+
+/* bench / test utility: synthetic fields of SURVEY.md §8d written straight into device arrays */
+int ab_synth_fields_device(void *sst, void *t_zt, void *q_zt, void *u, void *v, void *slp, void *rad_sw,
+                           void *rad_lw, long ni, long j0, long nj_local, int precision, void *stream)
+{
+    AB_HIP(ab::launch_synth(sst, t_zt, q_zt, u, v, slp, rad_sw, rad_lw, ni, j0, nj_local, precision == AB_F32,
+                            (hipStream_t)stream));
+    return AB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AEROBULK_MODEL on a process-global session (mod_aerobulk.f90:176-269) — non-reentrant by contract.
+static ab_session *g_sess = nullptr;
+static int g_nb_iter = 5;  // mod_const.f90:33 ; sticky once set through Niter (mod_aerobulk.f90:236)
+
+int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double zu, const double *sst,
+             const double *t_zt, const double *hum_zt, const double *u_zu, const double *v_zu, const double *slp,
+             double *ql, double *qh, double *tau_x, double *tau_y, double *evap, int niter, int use_skin,
+             const double *rad_sw, const double *rad_lw, double *t_s, long ni, long nj, ab_init_report *report)
+{
+    if (niter > 0) g_nb_iter = niter;                                        // :236
+    const bool lsrad = rad_sw && rad_lw;                                     // :242
+    if (jt < 1) return fail(AB_ERR_JT, "AEROBULK_MODEL => jt < 1 !??\n we are in a Fortran world here...");  // :244
+    const int algo = ab_algo_from_string(calgo, calgo_len);
+    if (jt == 1) {                                                           // AEROBULK_INIT :248 / :257
+        if (use_skin) {                                                      // :67-79
+            if (!(algo_has_skin(algo) || (calgo && (calgo_len < 0 ? strlen(calgo) : (size_t)calgo_len) >= 4 && strncmp(calgo, "coar", 4) == 0)))
+                return fail(AB_ERR_SKIN_ALGO, " AEROBULK_INIT => Only `COARE*` and `ECMWF` algorithms support cool-skin & warm/layer schemes");
+            if (!lsrad) return fail(AB_ERR_SKIN_NORAD, " AEROBULK_INIT => provide SW and LW rad. input if you want to use skin schemes");
+        }
+        if (algo == 0)                                                       // mod_aerobulk_compute.f90:173-175
+            return fail(AB_ERR_ALGO, "ERROR: mod_aerobulk_compute.f90 => bulk algorithm %.*s is unknown!!!",
+                        calgo_len < 0 ? (int)strlen(calgo ? calgo : "") : calgo_len, calgo ? calgo : "");
+        const bool reuse = g_sess && g_sess->algo == algo && g_sess->ni == ni && g_sess->nj == nj && g_sess->nt == nt &&
+                           g_sess->use_skin == (use_skin ? 1 : 0) && !g_sess->f32;
+        if (!reuse) {
+            if (g_sess) { ab_session_destroy(g_sess); g_sess = nullptr; }
+            int rc = ab_session_create(&g_sess, algo, ni, nj, nt, use_skin, AB_F64, -1);
+            if (rc) return rc;
+        }
+        g_sess->last_jt = 0;
+        // the reference hands rad_lw to BOTH prsw and prlw (mod_aerobulk.f90:248)
+        int rc = ab_session_init(g_sess, sst, t_zt, hum_zt, u_zu, v_zu, slp, lsrad ? rad_lw : nullptr,
+                                 lsrad ? rad_lw : nullptr, AB_MEM_HOST, report);
+        if (rc) return rc;
+    } else {
+        if (!g_sess) return fail(AB_ERR_STATE, "AEROBULK_MODEL called with jt=%d before jt=1", jt);
+        if (g_sess->algo != algo || g_sess->n != ni * nj)
+            return fail(AB_ERR_STATE, "AEROBULK_MODEL: algorithm or shape changed between time records");
+    }
+    // rad present but l_use_skin false => no skin, T_s = sst (mod_aerobulk_compute.f90:132,206)
+    return ab_session_compute(g_sess, jt, zt, zu, g_nb_iter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, ql, qh,
+                              tau_x, tau_y, evap, lsrad ? t_s : nullptr, AB_MEM_HOST, nullptr);
+}
+
+static void stop_like_fortran(int rc)
+{
+    // ctl_stop, mod_const.f90:255-276: banner + message on stdout, then STOP
+    printf(" *** E R R O R :  \n %s\n\n", ab_last_error());
+    fflush(stdout);
+    exit(rc > 0 ? rc : 1);
+}
+
+static void print_init_banner(const char *calgo, int l, long m, int nt, int niter_now, int skin, const ab_init_report &r)
+{
+    // AEROBULK_INIT banner, mod_aerobulk.f90:59-64,75-78,97-102,118-120,140,157
+    printf("\n ===================================================================\n");
+    printf("                    ----- AeroBulk_init -----\n\n");
+    printf("     *** Bulk parameterization to be used => \"%.*s\"\n", l, calgo);
+    if (skin) printf("        ==> will use the Cool-skin & Warm-layer scheme of `%.*s` !\n", l, calgo);
+    else printf("     *** Cool-skin & Warm-layer schemes will NOT be used!\n");
+    printf("     *** Computational domain shape: Ni x Nj = %05ld x %05d\n", m, 1);
+    printf("     *** Number of time records that will be treated: %d\n", nt);
+    printf("     *** Number of iterations in bulk algos: nb_iter  = %d\n", niter_now);
+    printf("     *** Filling the `mask` array...\n");
+    if (r.n_masked == 0) printf("         ==> no points need to be masked! :)\n");
+    else printf("         ==> number of points to mask: %ld (out of %ld)\n", r.n_masked, r.n_cells);
+    static const char *hn[3] = {"specific humidity [kg/kg]", "dew-point temperature [K]", "relative humidity [%]"};
+    if (r.hum_type >= 0 && r.hum_type <= 2) printf("     *** Type of prescribed air humidity  `%s`\n", hn[r.hum_type]);
+    printf(" ===================================================================\n");
+}
+
+static void print_bye_banner(void)
+{
+    // AEROBULK_BYE, mod_aerobulk.f90:164-170
+    printf(" ===================================================================\n");
+    printf("                    ----- AeroBulk_bye -----\n");
+    printf(" ===================================================================\n\n");
+}
+
+void aerobulk_cxx_skin(const int *jt, const int *nt, const char *calgo, const double *zt, const double *zu,
+                       const double *sst, const double *t_zt, const double *hum_zt, const double *u_zu,
+                       const double *v_zu, const double *slp, double *ql, double *qh, double *tau_x, double *tau_y,
+                       double *evap, const int *niter, const bool *l_skin, const double *rad_sw, const double *rad_lw,
+                       double *t_s, const int *l, const int *m)
+{
+    ab_init_report rep;
+    memset(&rep, 0, sizeof rep);
+    const int skin = *l_skin ? 1 : 0;  // one byte, as the C++ caller passes it (aerobulk.cpp:10,107)
+    int rc = ab_model(*jt, *nt, calgo, *l, *zt, *zu, sst, t_zt, hum_zt, u_zu, v_zu, slp, ql, qh, tau_x, tau_y, evap,
+                      *niter, skin, rad_sw, rad_lw, t_s, (long)*m, 1, &rep);
+    if (*jt == 1 && (rc == AB_OK || rc == AB_ERR_TAU)) print_init_banner(calgo, *l, *m, *nt, g_nb_iter, skin, rep);
+    if (rc != AB_OK) stop_like_fortran(rc);
+    if (*jt == *nt) print_bye_banner();  // mod_aerobulk.f90:267
+}
+
+void aerobulk_cxx_no_skin(const int *jt, const int *nt, const char *calgo, const double *zt, const double *zu,
+                          const double *sst, const double *t_zt, const double *hum_zt, const double *u_zu,
+                          const double *v_zu, const double *slp, double *ql, double *qh, double *tau_x,
+                          double *tau_y, double *evap, const int *niter, const int *l, const int *m)
+{
+    ab_init_report rep;
+    memset(&rep, 0, sizeof rep);
+    int rc = ab_model(*jt, *nt, calgo, *l, *zt, *zu, sst, t_zt, hum_zt, u_zu, v_zu, slp, ql, qh, tau_x, tau_y, evap,
+                      *niter, 0, nullptr, nullptr, nullptr, (long)*m, 1, &rep);
+    if (*jt == 1 && (rc == AB_OK || rc == AB_ERR_TAU)) print_init_banner(calgo, *l, *m, *nt, g_nb_iter, 0, rep);
+    if (rc != AB_OK) stop_like_fortran(rc);
+    if (*jt == *nt) print_bye_banner();
+}
+
+}  // extern "C"

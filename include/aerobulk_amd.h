@@ -1,0 +1,164 @@
+/* include/aerobulk_amd.h — C ABI of the MI355X-native bulk air-sea flux engine.
+ *
+ * Drop-in boundary for the AeroBulk hot path `aerobulk_compute()` and its callers
+ * `AEROBULK_INIT / AEROBULK_MODEL / AEROBULK_BYE`.  Plain pointers and sizes only; no
+ * torch / C++ types.  Implemented by aerobulk_amd/csrc (libaerobulk_amd.so, HIP, gfx950).
+ *
+ * Citations are file:line in the reference tree (brodeau/aerobulk, `src/` unless noted).
+ *
+ * Data layout: every field is a flat, contiguous array of `ni*nj` cells (Fortran column-major
+ * (Ni,Nj), i fastest — exactly what the reference's C shim sees as an (m,1) array,
+ * mod_aerobulk_cxx.f90:40-44).  Element type is `double` for an AB_F64 session and `float`
+ * for an AB_F32 session.  `mem` says where the caller's arrays live: AB_MEM_HOST (the
+ * reference's calling convention; the library stages H2D/D2H) or AB_MEM_DEVICE (arrays are
+ * already resident in HBM; nothing is copied and the call is asynchronous on `stream`).
+ */
+#ifndef AEROBULK_AMD_H
+#define AEROBULK_AMD_H
+
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums --------------------------------------------------------------------------- */
+/* numbering of include/aerobulk.hpp:13-21 */
+enum ab_algo { AB_ALGO_OTHER = 0, AB_ALGO_COARE3P0 = 1, AB_ALGO_COARE3P6 = 2, AB_ALGO_NCAR = 3,
+               AB_ALGO_ECMWF = 4, AB_ALGO_ANDREAS = 5 };
+/* ctype_humidity 'sh' | 'dp' | 'rh', mod_const.f90:27 */
+enum ab_hum { AB_HUM_SH = 0, AB_HUM_DP = 1, AB_HUM_RH = 2 };
+enum ab_mem { AB_MEM_HOST = 0, AB_MEM_DEVICE = 1 };
+enum ab_precision { AB_F64 = 0, AB_F32 = 1 };
+
+/* Error codes.  The reference has none: it prints and STOPs (mod_const.f90:238-278).  Each code
+ * below names the reference condition it replaces; the Fortran host turns a non-zero code
+ * back into the reference's message + STOP. */
+enum ab_status {
+    AB_OK = 0,
+    AB_ERR_ALGO = 1,        /* unknown algorithm string, mod_aerobulk_compute.f90:173-175 */
+    AB_ERR_SKIN_ALGO = 2,   /* skin scheme asked for ncar/andreas, mod_aerobulk.f90:69-70 */
+    AB_ERR_SKIN_NORAD = 3,  /* skin scheme without rad_sw/rad_lw, mod_aerobulk.f90:72 */
+    AB_ERR_JT = 4,          /* jt < 1, mod_aerobulk.f90:244 */
+    AB_ERR_ALL_MASKED = 5,  /* whole domain masked, mod_aerobulk.f90:122 */
+    AB_ERR_HUM_TYPE = 6,    /* humidity type not identified, mod_phymbl.f90:1996-2003 */
+    AB_ERR_UNITS = 7,       /* check_unit_consistency failed, mod_phymbl.f90:1946-1950 */
+    AB_ERR_TAU = 8,         /* wind stress > 10 N/m^2, mod_phymbl.f90:1250-1253 */
+    AB_ERR_HIP = 9,         /* HIP runtime failure / no gfx950 device */
+    AB_ERR_ARG = 10,        /* NULL pointer, size mismatch (mod_aerobulk.f90:87-95), bad enum */
+    AB_ERR_STATE = 11       /* call protocol violated (e.g. jt>1 before jt==1, mod_aerobulk.f90:246-267) */
+};
+
+typedef struct ab_session ab_session; /* opaque; owns WL state + staging buffers on one GPU */
+
+/* Summary of the AEROBULK_INIT checks (mod_aerobulk.f90:104-153), for the caller's banner. */
+typedef struct ab_init_report {
+    long n_cells;
+    long n_masked;      /* cells failing the sanity ranges mod_const.f90:138-146 */
+    int hum_type;       /* enum ab_hum detected by type_of_humidity, mod_phymbl.f90:1957-2007 */
+    int bad_field;      /* on AB_ERR_UNITS: 0 sst,1 t_air,2 slp,3 u10,4 v10,5 wnd,6 hum,7 rad_sw,8 rad_lw */
+    double bad_min, bad_max, bad_mean;
+} ab_init_report;
+
+/* ---- helpers -------------------------------------------------------------------------- */
+/* 'coare3p0'|'coare3p6'|'ncar'|'ecmwf'|'andreas' -> enum ab_algo, 0 if unknown.
+ * `len` < 0 means NUL-terminated.  Replaces SELECT CASE(TRIM(calgo)) mod_aerobulk_compute.f90:129-176
+ * and algorithm_to_string, aerobulk.cpp:22-49 (inverse direction). */
+int ab_algo_from_string(const char *calgo, int len);
+const char *ab_algo_name(int algo);
+const char *ab_strerror(int status);
+/* Human-readable detail of the last failure on this thread (mirrors the text ctl_stop prints). */
+const char *ab_last_error(void);
+/* Number of usable gfx950 devices (0 if none / HIP unavailable). */
+int ab_device_count(void);
+
+/* ---- session: one aerobulk_model() time loop jt = 1..nt on one GPU ----------------------- */
+/* Replaces the module-global state of the reference (nitend, l_use_skin_schemes, ctype_humidity,
+ * nb_iter: mod_const.f90:22-33; warm-layer arrays mod_skin_coare.f90:31-36, mod_skin_ecmwf.f90:52-55)
+ * with per-handle state.  `device` is the HIP device ordinal (-1: current device). */
+int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int use_skin,
+                      int precision, int device);
+int ab_session_destroy(ab_session *s);
+
+/* AEROBULK_INIT (mod_aerobulk.f90:24-160) minus its banner: builds the sanity mask, detects the
+ * humidity type, runs check_unit_consistency on every input.  rad_sw/rad_lw may be NULL.
+ * NB the reference passes prsw=rad_lw (mod_aerobulk.f90:248) so rad_sw is never range-checked:
+ * callers that want identical behaviour pass rad_lw for both (the Fortran/C++ hosts do).
+ * Global reductions run on the GPU (one pass over the inputs). */
+int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt,
+                    const void *u_zu, const void *v_zu, const void *slp,
+                    const void *rad_sw, const void *rad_lw, int mem, ab_init_report *report);
+/* Skip the detection and force the humidity type (device-resident callers that already know). */
+int ab_session_set_humidity(ab_session *s, int hum_type);
+
+/* aerobulk_compute (mod_aerobulk_compute.f90:22-213) for time record jt.
+ *   inputs : sst,t_zt,hum_zt,u_zu,v_zu,slp (+rad_sw,rad_lw when the session uses skin schemes)
+ *   outputs: ql,qh,tau_x,tau_y (required); evap, t_s optional (NULL = not wanted)
+ * WL state initialises at jt==1 and persists until jt==nt (mod_blk_coare3p6.f90:250,411).
+ * AB_MEM_HOST: synchronous; returns AB_ERR_TAU if any cell exceeded 10 N/m^2.
+ * AB_MEM_DEVICE: enqueued on `stream` (hipStream_t, NULL = default stream); call
+ * ab_session_check() to synchronise and fetch the AB_ERR_TAU flag. */
+int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter,
+                       const void *sst, const void *t_zt, const void *hum_zt,
+                       const void *u_zu, const void *v_zu, const void *slp,
+                       const void *rad_sw, const void *rad_lw,
+                       void *ql, void *qh, void *tau_x, void *tau_y, void *evap, void *t_s,
+                       int mem, void *stream);
+int ab_session_check(ab_session *s);
+
+/* Warm-layer solar-time inputs for the next ab_session_compute calls.  aerobulk_compute
+ * hard-wires isecday_utc=12 and longitude 0 (mod_aerobulk_compute.f90:126,136,146), which is
+ * the default; TURB_COARE3Px callers with real time/longitude (tests/test_aerobulk_buoy_series_oce.f90
+ * :345-377) set them here.  `lon` (degrees East, same layout/mem/precision as the fields) may be NULL. */
+int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int mem);
+
+/* Copy the persistent warm-layer state (planes dT_wl, Hz_wl, Qnt_ac, Tau_ac; ECMWF uses the
+ * first two) to host doubles — diagnostics pdT_wl/pHz_wl of TURB_COARE3P6, mod_blk_coare3p6.f90:406-407. */
+int ab_session_get_wl_state(ab_session *s, double *state4n);
+
+/* Duration in ms of the most recent flux kernel launched by this session (HIP events on the
+ * session's stream); < 0 if unavailable.  Synchronises. */
+double ab_session_last_kernel_ms(ab_session *s);
+
+/* Test/bench utility: fill device arrays with the deterministic quasi-random fields of SURVEY.md §8d
+ * (rows j0..j0+nj_local-1, 0-based, of an ni-wide grid; rad_sw/rad_lw may be NULL).  `precision` is an
+ * enum ab_precision; evaluation is always fp64. */
+int ab_synth_fields_device(void *sst, void *t_zt, void *q_zt, void *u_zu, void *v_zu, void *slp,
+                           void *rad_sw, void *rad_lw, long ni, long j0, long nj_local, int precision,
+                           void *stream);
+
+/* ---- the reference's own entry points --------------------------------------------------- */
+/* AEROBULK_MODEL (mod_aerobulk.f90:176-269) on a process-global session, with the reference's
+ * call protocol: INIT at jt==1, BYE at jt==nt.  Non-reentrant exactly like the reference.
+ * rad_sw/rad_lw/t_s may be NULL (the Fortran OPTIONALs); niter <= 0 keeps the current nb_iter
+ * (sticky, default 5: mod_const.f90:33, mod_aerobulk.f90:236).  Host arrays, fp64.
+ * Returns an ab_status; `report` (may be NULL) is filled when jt==1. */
+int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double zu,
+             const double *sst, const double *t_zt, const double *hum_zt,
+             const double *u_zu, const double *v_zu, const double *slp,
+             double *ql, double *qh, double *tau_x, double *tau_y, double *evap,
+             int niter, int use_skin, const double *rad_sw, const double *rad_lw, double *t_s,
+             long ni, long nj, ab_init_report *report);
+
+/* Exactly the two C symbols the reference exports from its Fortran shim
+ * (mod_aerobulk_cxx.f90:29-33,66-69; prototypes aerobulk.cpp:5-19): everything by reference,
+ * `calgo` is char[l+1], data are flat length-m vectors.  `l_skin` is read as ONE byte (C `bool`,
+ * aerobulk.cpp:10); the reference's Fortran side reads a 4-byte LOGICAL there (ABI slip).
+ * On error they print the reference's message and terminate the process, like `STOP`. */
+void aerobulk_cxx_skin(const int *jt, const int *nt, const char *calgo, const double *zt, const double *zu,
+                       const double *sst, const double *t_zt, const double *hum_zt, const double *u_zu,
+                       const double *v_zu, const double *slp,
+                       double *ql, double *qh, double *tau_x, double *tau_y, double *evap,
+                       const int *niter, const bool *l_skin, const double *rad_sw, const double *rad_lw,
+                       double *t_s, const int *l, const int *m);
+void aerobulk_cxx_no_skin(const int *jt, const int *nt, const char *calgo, const double *zt, const double *zu,
+                          const double *sst, const double *t_zt, const double *hum_zt, const double *u_zu,
+                          const double *v_zu, const double *slp,
+                          double *ql, double *qh, double *tau_x, double *tau_y, double *evap,
+                          const int *niter, const int *l, const int *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEROBULK_AMD_H */
