@@ -65,7 +65,17 @@ def build_fortran_host(force=False):
     if force or _newer(exe, [src, drv, LIB]):
         _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-c", src, "-o", os.path.join(fdir, "mod_aerobulk.o")])
         _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, drv, os.path.join(fdir, "mod_aerobulk.o"),
-              "-L", PKG, "-laerobulk_amd", f"-Wl,-rpath,{PKG}", "-o", exe])
+              "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", exe])
+    return exe
+
+
+def build_cxx_example(force=False):
+    """C++ API example driver (aerobulk::model), linked against libaerobulk_amd.so only."""
+    src = os.path.join(CSRC, "example_call_aerobulk.cpp")
+    exe = os.path.join(CSRC, "example_call_aerobulk_cxx.x")
+    if force or _newer(exe, [src, LIB, os.path.join(ROOT, "include", "aerobulk.hpp")]):
+        _run(["g++", "-std=c++11", "-O2", "-I", os.path.join(ROOT, "include"), src, "-L", PKG, "-laerobulk_amd",
+              "-Wl,-rpath,$ORIGIN/..", "-o", exe])
     return exe
 
 
@@ -76,6 +86,7 @@ def build_oracle():
 def build_all(force=False):
     build_engine(force)
     build_fortran_host(force)
+    build_cxx_example(force)
     build_oracle()
 
 

@@ -121,7 +121,7 @@ def have_reference():
 
 
 _CHILD = r"""
-import ctypes as C, pickle, sys, numpy as np
+import ctypes as C, pickle, sys, time, numpy as np
 so, fin, fout = sys.argv[1:4]
 case = pickle.load(open(fin, "rb"))
 L = C.CDLL(so)
@@ -135,6 +135,7 @@ res = []
 for jt in range(1, nt + 1):
     f = case["records"][jt - 1]
     o = {k: np.full(n, np.nan) for k in ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")}
+    _t0 = time.perf_counter()
     if case["with_rad"]:
         # reference declares l_skin as default LOGICAL (4 bytes): pass a 4-byte int
         L.aerobulk_cxx_skin(ci(jt), ci(nt), C.c_char_p(algo), cd(case["zt"]), cd(case["zu"]),
@@ -147,6 +148,7 @@ for jt in range(1, nt + 1):
             p(f["sst"]), p(f["t_zt"]), p(f["hum_zt"]), p(f["u_zu"]), p(f["v_zu"]), p(f["slp"]),
             p(o["ql"]), p(o["qh"]), p(o["tau_x"]), p(o["tau_y"]), p(o["evap"]),
             ci(case["niter"]), ci(len(algo)), ci(n))
+    o["secs"] = time.perf_counter() - _t0
     res.append(o)
 pickle.dump(res, open(fout, "wb"))
 """

@@ -22,6 +22,7 @@ def _run_both(oracle, algo, skin, niter, zt, ni=360, nj=180, nt=1, hum="sh", fie
     n = f["sst"].size
     osess = oracle.OracleSession(algo, n, nt, skin, hum)
     results = []
+    _run_both.last_fields = f
     with ab.Session(algo, n, 1, nt, skin) as s:
         s.set_humidity(hum)
         for jt in range(1, nt + 1):
@@ -31,6 +32,17 @@ def _run_both(oracle, algo, skin, niter, zt, ni=360, nj=180, nt=1, hum="sh", fie
             got = {k: got[CAP[k]] for k in OUT + (("t_s",) if skin else ())}
             results.append((got, ref))
     return results
+
+
+def _dump_outliers(got, ref, keys, nmax=3):
+    from conftest import rel_err
+    f = _run_both.last_fields
+    for k in keys:
+        e = rel_err(got[k], ref[k])
+        for c in np.argsort(e)[::-1][:nmax]:
+            if e[c] > TOL:
+                print(f"OUTLIER {k} cell {c} rel {e[c]:.3e}: " + " ".join(f"{n}={f[n][c]!r}" for n in f)
+                      + " | " + " ".join(f"{q}: got {got[q][c]!r} ref {ref[q][c]!r}" for q in keys))
 
 
 CASES = [(a, sk) for a in ("coare3p0", "coare3p6", "ncar", "ecmwf", "andreas")
@@ -44,6 +56,7 @@ def test_parity_single_record(oracle, algo, skin, niter, zt):
     keys = OUT + (("t_s",) if skin else ())
     rep = parity_report(got, ref, keys, TOL)
     print(algo, skin, niter, zt, rep)
+    _dump_outliers(got, ref, keys)
     for k in keys:
         assert rep[k]["n_bad"] == 0, (k, rep[k])
 

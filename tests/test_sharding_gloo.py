@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: the j-block sharding + packed-gather assembly that bench.py uses for N>1.
+The per-rank compute is stood in by the CPU oracle (the HIP kernel needs a GPU; the path is pointwise, so the
+sharding logic is independent of who computes a cell).  Checks that the gathered global field is bit-identical
+to the single-process result — the property the multi-GPU run relies on (no halo)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ni, nj, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from bench import shard_rows
+    from oracle import pyoracle as po
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    j0, njl, per = shard_rows(nj, world, rank)
+    n_local, n_pad = ni * njl, ni * per
+    f = po.synth_fields(ni, nj, j0, njl)
+    o = po.OracleSession("coare3p6", n_local, 1, True).compute(
+        1, 2.0, 10.0, 5, f["sst"], f["t_zt"], f["hum_zt"], f["u_zu"], f["v_zu"], f["slp"], rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+    names = ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")
+    buf = torch.zeros((6, n_pad), dtype=torch.float64)
+    for i, k in enumerate(names):
+        buf[i, :n_local] = torch.from_numpy(o[k])
+    gl = [torch.empty((6, n_pad), dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gl, dst=0)
+    if rank == 0:
+        glob = {}
+        for i, k in enumerate(names):
+            parts = []
+            for r in range(world):
+                _, njr, _ = shard_rows(nj, world, r)
+                parts.append(gl[r][i, :ni * njr].numpy())
+            glob[k] = np.concatenate(parts)
+        q.put(glob)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nj", [40, 41])  # divisible and ragged row counts
+def test_jblock_sharding_and_gather_reproduce_single_process(oracle, nj):
+    import torch.multiprocessing as mp
+    ni, world = 32, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + nj
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ni, nj, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    glob = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f = oracle.synth_fields(ni, nj)
+    ref = oracle.OracleSession("coare3p6", ni * nj, 1, True).compute(
+        1, 2.0, 10.0, 5, f["sst"], f["t_zt"], f["hum_zt"], f["u_zu"], f["v_zu"], f["slp"], rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+    for k in ("ql", "qh", "tau_x", "tau_y", "evap", "t_s"):
+        np.testing.assert_array_equal(glob[k], ref[k], err_msg=k)
+
+
+def test_shard_rows_partition():
+    from bench import shard_rows
+    for nj in (1, 7, 450, 3600, 10800):
+        for world in (1, 2, 3, 4, 8):
+            rows = [shard_rows(nj, world, r) for r in range(world)]
+            assert sum(r[1] for r in rows) == nj
+            pos = 0
+            for j0, njl, per in rows:
+                assert njl <= per
+                if njl:
+                    assert j0 == pos
+                pos += njl
