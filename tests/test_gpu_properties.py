@@ -60,7 +60,8 @@ def test_pointwise_sharding_invariance_full_grid(torch_mod):
 
 
 def test_wind_rotation_symmetry(torch_mod):
-    """(U,V) -> (-V,U) rotates the stress vector and leaves every scalar flux bit-identical."""
+    """(U,V) -> (-V,U) rotates the stress vector and leaves every scalar flux unchanged (to rounding: the wind
+    module sqrt(u*u+v*v) is FMA-contracted on the GPU, so it is symmetric only to 1 ulp)."""
     import aerobulk_amd as ab
     ni, nj = 1440, 1080
     f = ab.synth_fields_device(ni, nj, with_rad=False)
@@ -68,9 +69,12 @@ def test_wind_rotation_symmetry(torch_mod):
         with ab.Session(algo, ni, nj) as s:
             a = s.compute(1, 2.0, 10.0, *[f[k] for k in IN6], Niter=5)
             b = s.compute(1, 2.0, 10.0, f["sst"], f["t_zt"], f["hum_zt"], -f["V_zu"], f["U_zu"], f["slp"], Niter=5)
+        def close(x, y):
+            scale = float(y.abs().max())
+            return float((x - y).abs().max()) <= 1e-12 * scale
         for k in ("QL", "QH", "Evap"):
-            assert torch_mod.equal(a[k], b[k]), (algo, k)
-        assert torch_mod.equal(b["Tau_x"], -a["Tau_y"]) and torch_mod.equal(b["Tau_y"], a["Tau_x"]), algo
+            assert close(a[k], b[k]), (algo, k)
+        assert close(b["Tau_x"], -a["Tau_y"]) and close(b["Tau_y"], a["Tau_x"]), algo
 
 
 def test_device_pointer_path_equals_host_path(oracle, torch_mod):
