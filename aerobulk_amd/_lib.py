@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libaerobulk_amd.so")
+LIB_PATH = os.environ.get("AEROBULK_AMD_LIB") or os.path.join(PKG, "libaerobulk_amd.so")  # env override: A/B experiments only
 
 vp = C.c_void_p
 dp = C.POINTER(C.c_double)
@@ -38,6 +38,7 @@ SYMBOLS = {
     "ab_session_get_wl_state": (C.c_int, [vp, dp]),
     "ab_session_last_kernel_ms": (C.c_double, [vp]),
     "ab_synth_fields_device": (C.c_int, [vp] * 8 + [C.c_long, C.c_long, C.c_long, C.c_int, vp]),
+    "ab_test_math": (C.c_int, [C.c_int, dp, dp, dp, C.c_long]),
     "ab_model": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_double] + [dp] * 6 + [dp] * 5
                  + [C.c_int, C.c_int, dp, dp, dp, C.c_long, C.c_long, C.POINTER(InitReport)]),
     "aerobulk_cxx_skin": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, dp, dp] + [dp] * 6 + [dp] * 5

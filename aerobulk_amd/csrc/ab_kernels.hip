@@ -14,6 +14,9 @@
 namespace ab {
 
 constexpr int kBlock = 256;  // 4 waves of 64 lanes, one per SIMD
+#ifndef AB_WAVES_PER_EU
+#define AB_WAVES_PER_EU 2    // fp64 skin kernels want ~240 VGPRs: 2 waves/SIMD (measured best)
+#endif
 
 template <class R> struct FluxArgs {
     const R *sst, *t_zt, *hum, *u, *v, *slp, *rad_sw, *rad_lw, *lon;
@@ -26,7 +29,7 @@ template <class R> struct FluxArgs {
 };
 
 template <class R, int ALGO, bool SKIN>
-__global__ void __launch_bounds__(kBlock) flux_kernel(const FluxArgs<R> a)
+__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a)
 {
     using M = Mth<R>;
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -111,6 +114,8 @@ template <class R> static Heights<R> make_heights(double zt, double zu)
     h.log_ztu = (R)log(zt / zu);
     h.log_zu10 = (R)log(zu / 10.);
     h.fg_ca = (R)(0.035 * log(10. / 0.0001) / log(zu / 0.0001));  // mod_common_coare.f90:107
+    h.inv_zu = (R)(1. / zu);
+    h.zt_o_zu = (R)(zt / zu);
     h.zt_eq_zu = (fabs(zu - zt) < 0.01) ? 1 : 0;
     return h;
 }
@@ -290,6 +295,40 @@ hipError_t launch_synth(void *sst, void *t_zt, void *q_zt, void *u, void *v, voi
         hipLaunchKernelGGL(synth_kernel<double>, dim3((unsigned)nblk), dim3(kBlock), 0, stream, (double *)sst,
                            (double *)t_zt, (double *)q_zt, (double *)u, (double *)v, (double *)slp, (double *)rad_sw,
                            (double *)rad_lw, ni, j0, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Unit-test hook for the fp64 device math of ab_fastmath.hpp (tests/test_gpu_math.py).
+__global__ void __launch_bounds__(kBlock) math_test_kernel(int op, const double *x, const double *y, double *o, long n)
+{
+    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const double a = x[k], b = y ? y[k] : 1.0;
+    double r;
+    switch (op) {
+    case 0: r = fm::qdiv(a, b); break;
+    case 1: r = fm::qrcp(a); break;
+    case 2: r = fm::qsqrt(a); break;
+    case 3: r = fm::qlog(a); break;
+    case 4: r = fm::qlog10(a); break;
+    case 5: r = fm::qexp(a); break;
+    case 6: r = fm::qexp10(a); break;
+    case 7: r = fm::qatan(a); break;
+    case 8: r = fm::qcbrt(a); break;
+    case 9: r = fm::qrcbrt_mid(a); break;
+    case 10: r = e_sat<double>(a); break;
+    case 11: r = pow_pos<double>(a, b); break;
+    default: r = 0.; break;
+    }
+    o[k] = r;
+}
+
+hipError_t launch_math_test(int op, const double *x, const double *y, double *o, long n, hipStream_t stream)
+{
+    const long nblk = (n + kBlock - 1) / kBlock;
+    if (nblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL(math_test_kernel, dim3((unsigned)nblk), dim3(kBlock), 0, stream, op, x, y, o, n);
     return hipGetLastError();
 }
 

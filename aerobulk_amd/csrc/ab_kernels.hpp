@@ -43,4 +43,7 @@ hipError_t launch_init_stats(const void *sst, const void *t_air, const void *hum
 hipError_t launch_synth(void *sst, void *t_zt, void *q_zt, void *u, void *v, void *slp, void *rad_sw,
                         void *rad_lw, long ni, long j0, long nj_local, int f32, hipStream_t stream);
 
+// unit-test hook: apply fp64 device math function `op` elementwise (tests/test_gpu_math.py)
+hipError_t launch_math_test(int op, const double *x, const double *y, double *o, long n, hipStream_t stream);
+
 }  // namespace ab

@@ -1,11 +1,17 @@
 // ab_math.hpp — per-precision device math for the flux kernels (gfx950 only).
 //
-// The flux kernels are bound by fp64 VALU throughput (hundreds of transcendentals per cell
-// against ~100 B of HBM traffic), so every `x**y` of the reference is strength-reduced here:
-// constant exponents become sqrt/cbrt compositions or exp(y*log x).  None of these rewrites
-// is bit-exact w.r.t. libm pow(); all stay within a few ulp, far inside the 1e-10 parity bar.
+// The flux kernels are bound by fp64 VALU issue (hundreds of transcendentals per cell against
+// ~100 B of HBM traffic), so
+//   * every `x**y` of the reference is strength-reduced: constant exponents become sqrt/cbrt
+//     compositions or exp(y*log x);
+//   * fp64 log/exp/atan/sqrt/cbrt and division come from ab_fastmath.hpp (2-4x fewer VALU
+//     instructions than the ROCm device library, <= 3 ulp on the ranges used here).
+// None of this is bit-exact w.r.t. libm; all of it stays far inside the 1e-10 parity bar
+// (measured: tests/test_gpu_math.py, tests/test_gpu_golden.py).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "ab_fastmath.hpp"
 
 namespace ab {
 
@@ -13,17 +19,20 @@ template <class R> struct Mth;
 
 template <> struct Mth<double> {
     using R = double;
-    static __device__ __forceinline__ R log(R x) { return ::log(x); }
-    static __device__ __forceinline__ R log10(R x) { return ::log10(x); }
-    static __device__ __forceinline__ R exp(R x) { return ::exp(x); }
-    static __device__ __forceinline__ R exp10(R x) { return ::exp10(x); }
-    static __device__ __forceinline__ R atan(R x) { return ::atan(x); }
-    static __device__ __forceinline__ R sqrt(R x) { return ::sqrt(x); }
-    static __device__ __forceinline__ R cbrt(R x) { return ::cbrt(x); }
-    static __device__ __forceinline__ R rcbrt(R x) { return ::rcbrt(x); }
-    static __device__ __forceinline__ R abs(R x) { return ::fabs(x); }
-    static __device__ __forceinline__ R floor(R x) { return ::floor(x); }
-    static __device__ __forceinline__ R copysign(R a, R b) { return ::copysign(a, b); }
+    static __device__ __forceinline__ R log(R x) { return fm::qlog(x); }      // x > 0, normal
+    static __device__ __forceinline__ R log10(R x) { return fm::qlog10(x); }
+    static __device__ __forceinline__ R exp(R x) { return fm::qexp(x); }
+    static __device__ __forceinline__ R exp10(R x) { return fm::qexp10(x); }
+    static __device__ __forceinline__ R atan(R x) { return fm::qatan(x); }
+    static __device__ __forceinline__ R sqrt(R x) { return fm::qsqrt(x); }        // x >= 0
+    static __device__ __forceinline__ R sqrt_pos(R x) { return fm::qsqrt_pos(x); }  // x > 0 strictly
+    static __device__ __forceinline__ R cbrt(R x) { return fm::qcbrt(x); }        // x >= 0
+    static __device__ __forceinline__ R rcbrt(R x) { return fm::qrcbrt_mid(x); }  // 2^-100 < x < 2^100
+    static __device__ __forceinline__ R div(R a, R b) { return fm::qdiv(a, b); }
+    static __device__ __forceinline__ R rcp(R b) { return fm::qrcp(b); }
+    static __device__ __forceinline__ R abs(R x) { return __builtin_fabs(x); }
+    static __device__ __forceinline__ R floor(R x) { return __builtin_floor(x); }
+    static __device__ __forceinline__ R copysign(R a, R b) { return __builtin_copysign(a, b); }
 };
 
 template <> struct Mth<float> {
@@ -34,8 +43,11 @@ template <> struct Mth<float> {
     static __device__ __forceinline__ R exp10(R x) { return ::__exp10f(x); }
     static __device__ __forceinline__ R atan(R x) { return ::atanf(x); }
     static __device__ __forceinline__ R sqrt(R x) { return ::__fsqrt_rn(x); }
+    static __device__ __forceinline__ R sqrt_pos(R x) { return ::__fsqrt_rn(x); }
     static __device__ __forceinline__ R cbrt(R x) { return ::cbrtf(x); }
     static __device__ __forceinline__ R rcbrt(R x) { return ::rcbrtf(x); }
+    static __device__ __forceinline__ R div(R a, R b) { return a / b; }
+    static __device__ __forceinline__ R rcp(R b) { return R(1.) / b; }
     static __device__ __forceinline__ R abs(R x) { return ::fabsf(x); }
     static __device__ __forceinline__ R floor(R x) { return ::floorf(x); }
     static __device__ __forceinline__ R copysign(R a, R b) { return ::copysignf(a, b); }
@@ -61,4 +73,4 @@ template <class R> __device__ __forceinline__ R sclamp(R x, R cap)
 // `0.5 + SIGN(0.5,x)` == 1  <=>  sign bit of x clear (SIGN(0.5,-0.) = -0.5 on IEEE processors)
 template <class R> __device__ __forceinline__ bool nonneg(R x) { return !__builtin_signbit(x); }
 
-} // namespace ab
+}  // namespace ab

@@ -10,7 +10,10 @@
 //   * the reference evaluates BOTH the stable and unstable psi branches and blends them with
 //     a 0/1 weight; here the lane picks its branch (exact: the weight is exactly 0 or 1);
 //   * loop invariants (alpha_sw(SST), warm-layer constants, logs of heights) are hoisted;
-//   * `x**y` is strength-reduced (ab_math.hpp); a/exp(b) is a*exp(-b); sums of logs are fused.
+//   * `x**y` is strength-reduced (ab_math.hpp); a/exp(b) is a*exp(-b); sums of logs are fused;
+//   * divisions go through Mth<R>::div (rcp + Newton, ab_fastmath.hpp), divisions by literals become
+//     multiplications by the literal's reciprocal; where only LOG(z0t) is needed it is formed in the
+//     log domain (no exp/log round trip).
 #pragma once
 #include "ab_math.hpp"
 
@@ -58,8 +61,8 @@ template <class R> __device__ __forceinline__ R e_sat(R pTa)
 {
     using M = Mth<R>;
     const R zta = vmax(pTa, R(180.));
-    const R ztmp = K<R>::rt0 / zta;
-    const R zx = zta / K<R>::rt0;
+    const R ztmp = M::div(K<R>::rt0, zta);
+    const R zx = zta * R(1. / 273.15);
     const R e = R(10.79574) * (R(1.) - ztmp) - R(5.028) * M::log10(zx)
                 + R(1.50475E-4) * (R(1.) - M::exp10(R(-8.2969) * (zx - R(1.))))
                 + R(0.42873E-3) * (M::exp10(R(4.76955) * (R(1.) - ztmp)) - R(1.)) + R(0.78614);
@@ -69,19 +72,19 @@ template <class R> __device__ __forceinline__ R e_sat(R pTa)
 template <class R> __device__ __forceinline__ R q_sat(R pTa, R pslp)
 {
     const R ze_s = e_sat(pTa);
-    return K<R>::reps0 * ze_s / (pslp - K<R>::one_m_reps0 * ze_s);
+    return Mth<R>::div(K<R>::reps0 * ze_s, pslp - K<R>::one_m_reps0 * ze_s);
 }
 // q_air_rh :963-985
 template <class R> __device__ __forceinline__ R q_air_rh(R prha, R pTa, R pslp)
 {
     const R ze = R(0.01) * prha * e_sat(pTa);
-    return ze * K<R>::reps0 / vmax(pslp - K<R>::one_m_reps0 * ze, R(1.));
+    return Mth<R>::div(ze * K<R>::reps0, vmax(pslp - K<R>::one_m_reps0 * ze, R(1.)));
 }
 // q_air_dp :990-1000
 template <class R> __device__ __forceinline__ R q_air_dp(R da, R pslp)
 {
     const R q = vmax(e_sat(da), R(0.));
-    return q * K<R>::reps0 / vmax(pslp - K<R>::one_m_reps0 * q, R(1.));
+    return Mth<R>::div(q * K<R>::reps0, vmax(pslp - K<R>::one_m_reps0 * q, R(1.)));
 }
 // Theta_from_z_P0_T_q :343-375 = Pz_from_P0_tz_qz_sclr :283-318 (3 barometric iterations) + Poisson :189-200
 template <class R> __device__ __forceinline__ R theta_from_z_p0_t_q(R pz, R pslp, R pTa, R pqa)
@@ -89,23 +92,26 @@ template <class R> __device__ __forceinline__ R theta_from_z_p0_t_q(R pz, R pslp
     using M = Mth<R>;
     // e_sat(pTa) does not depend on the pressure iterate: evaluate once (the reference recomputes it)
     const R ze_s = e_sat(pTa);
-    const R c = -K<R>::grav * pz / (K<R>::R_gas * pTa);
+    const R c = M::div(-K<R>::grav * pz, K<R>::R_gas * pTa);
+    const R zi = M::rcp(K<R>::reps0 * ze_s);
     R zpa = pslp;
+    R zarg = R(0.);
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
-        const R zqsat = K<R>::reps0 * ze_s / (zpa - K<R>::one_m_reps0 * ze_s);
-        const R zf = pqa / zqsat;
+        const R zf = pqa * ((zpa - K<R>::one_m_reps0 * ze_s) * zi);   // q / q_sat(T, p)
         const R zxm = (R(1.) - zf) * K<R>::rmm_dryair + zf * K<R>::rmm_water;
-        zpa = pslp * M::exp(c * zxm);
+        zarg = c * zxm;
+        zpa = pslp * M::exp(zarg);
     }
-    return pTa * M::exp(K<R>::rpoiss_dry * M::log(pslp / zpa));
+    // T (P0/Pz)^kappa with P0/Pz = exp(-zarg): no log needed
+    return pTa * M::exp(-K<R>::rpoiss_dry * zarg);
 }
 // virt_temp_sclr :247-269
 template <class R> __device__ __forceinline__ R virt_temp(R t, R q) { return t * (R(1.) + K<R>::rctv0 * q); }
 // rho_air_sclr :522-537
 template <class R> __device__ __forceinline__ R rho_air(R pTa, R pqa, R pslp)
 {
-    return vmax(pslp / (K<R>::R_dry * pTa * (R(1.) + K<R>::rctv0 * pqa)), R(0.8));
+    return vmax(Mth<R>::div(pslp, K<R>::R_dry * pTa * (R(1.) + K<R>::rctv0 * pqa)), R(0.8));
 }
 // visc_air_sclr :549-563
 template <class R> __device__ __forceinline__ R visc_air(R pTa)
@@ -118,8 +124,8 @@ template <class R> __device__ __forceinline__ R visc_air(R pTa)
 template <class R> __device__ __forceinline__ R one_on_l(R pThta, R pqa, R pus, R pts, R pqs)
 {
     const R zqa = R(1.) + K<R>::rctv0 * pqa;
-    const R r = K<R>::grav * K<R>::vkarmn * (pts * zqa + K<R>::rctv0 * pThta * pqs)
-                / vmax(pus * pus * pThta * zqa, R(1.E-9));
+    const R r = Mth<R>::div(K<R>::grav * K<R>::vkarmn * (pts * zqa + K<R>::rctv0 * pThta * pqs),
+                            vmax(pus * pus * pThta * zqa, R(1.E-9)));
     return sclamp(r, R(200.));
 }
 // Ri_bulk_sclr :712-747 (layer arguments are never passed on this path)
@@ -128,7 +134,7 @@ template <class R> __device__ __forceinline__ R ri_bulk(R pz, R psst, R pThta, R
     const R zsstv = virt_temp(psst, pssq);
     const R zdthv = virt_temp(pThta, pqa) - zsstv;
     const R ztv = R(0.5) * (zsstv + virt_temp(pThta - K<R>::rgamma_dry * pz, pqa));
-    return K<R>::grav * zdthv * pz / (ztv * pub * pub);
+    return Mth<R>::div(K<R>::grav * zdthv * pz, ztv * pub * pub);
 }
 // BULK_FORMULA_SCLR :1149-1203 (open ocean: l_ice false)
 template <class R>
@@ -136,8 +142,10 @@ __device__ __forceinline__ void bulk_formula(R pzu, R pts, R pqs, R pThta, R pqa
                                              R pUb, R pslp, R &pTau, R &pQsen, R &pQlat, R &pEvap)
 {
     const R zta = pThta - K<R>::rgamma_dry * pzu;
-    R zrho = rho_air(zta, pqa, pslp);
-    zrho = rho_air(zta, pqa, pslp - zrho * K<R>::grav * pzu);
+    // rho_air twice (:1183-1184) with the same denominator: one reciprocal
+    const R zir = Mth<R>::rcp(K<R>::R_dry * zta * (R(1.) + K<R>::rctv0 * pqa));
+    R zrho = vmax(pslp * zir, R(0.8));
+    zrho = vmax((pslp - zrho * K<R>::grav * pzu) * zir, R(0.8));
     const R zUrho = pUb * vmax(zrho, R(1.));
     pTau = zUrho * pCd * pwnd;
     pEvap = zUrho * pCe * (pqa - pqs);
@@ -151,10 +159,10 @@ __device__ __forceinline__ void update_qnsol_tau(R pzu, R pts, R pqs, R pThta, R
 {
     const R zdt = sfloor(pThta - pts, R(1.E-09));
     const R zdq = sfloor(pqa - pqs, R(1.E-12));
-    const R zz0 = pust / pUb;
+    const R zz0 = Mth<R>::div(pust, pUb);
     R zQsen, zEvap;
-    bulk_formula(pzu, pts, pqs, pThta, pqa, zz0 * zz0, zz0 * ptst / zdt, zz0 * pqst / zdq, pwnd, pUb, pslp, pTau,
-                 zQsen, pQlat, zEvap);
+    bulk_formula(pzu, pts, pqs, pThta, pqa, zz0 * zz0, Mth<R>::div(zz0 * ptst, zdt), Mth<R>::div(zz0 * pqst, zdq), pwnd,
+                 pUb, pslp, pTau, zQsen, pQlat, zEvap);
     const R zt2 = pts * pts;
     pQns = pQlat + zQsen + K<R>::emiss_w * (prlw - K<R>::stefan * zt2 * zt2);
 }
@@ -175,9 +183,11 @@ template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R 
     // invariants of the five delta evaluations
     const R zusw = vmax(pustar, R(1.E-4)) * K<R>::sq_radrw;
     const R zusw2 = zusw * zusw;
-    const R zA = palpha * K<R>::rcst_cs / (zusw2 * zusw2);
-    const R ztmp = K<R>::rnu0_w / zusw;
-    const R zql = COARE ? R(0.026) * vmin(pQlat, R(0.)) * K<R>::rCp0_w / K<R>::rLevap / palpha : R(0.);
+    const R ziu = M::rcp(zusw);
+    const R ziu2 = ziu * ziu;
+    const R zA = palpha * K<R>::rcst_cs * (ziu2 * ziu2);
+    const R ztmp = K<R>::rnu0_w * ziu;
+    const R zql = COARE ? M::div(R(0.026) * vmin(pQlat, R(0.)) * R(4190. / 2.46e+6), palpha) : R(0.);
     const R zdwarm = vmin(R(6.) * ztmp, R(0.007));
     auto delta = [&](R pQd) -> R {
         const R zQd = pQd + zql;
@@ -190,11 +200,11 @@ template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R 
     R zdelta = delta(zQabs);
 #pragma unroll 1
     for (int jc = 0; jc < 4; ++jc) {
-        const R zfr = vmax(c0 + R(11.) * zdelta - R(6.6E-5) / zdelta * (R(1.) - M::exp(-zdelta / R(8.E-4))), R(0.01));
+        const R zfr = vmax(c0 + R(11.) * zdelta - M::div(R(6.6E-5), zdelta) * (R(1.) - M::exp(zdelta * R(-1. / 8.E-4))), R(0.01));
         zQabs = pQnsol + zfr * pQsw;
         zdelta = delta(zQabs);
     }
-    return zQabs * zdelta / K<R>::rk0_w;
+    return zQabs * zdelta * R(1. / 0.6);
 }
 
 // ---------------------------------------------------------------- warm layer, COARE 3.6
@@ -209,11 +219,11 @@ template <class R> __device__ __forceinline__ R wl_absorb(R zHwl)
     // 1 - (0.28*0.014*(1-e^{-H/0.014}) + 0.27*0.357*(1-e^{-H/0.357}) + 0.45*12.82*(1-e^{-H/12.82}))/H  :167-168
     // exp(x) for x < -40 rounds 1-exp(x) to exactly 1 in fp64 (and fp32): skip those evaluations.
     using M = Mth<R>;
-    const R a1 = zHwl / R(0.014), a2 = zHwl / R(0.357);
+    const R a1 = zHwl * R(1. / 0.014), a2 = zHwl * R(1. / 0.357);
     const R e1 = a1 > R(40.) ? R(1.) : R(1.) - M::exp(-a1);
     const R e2 = a2 > R(40.) ? R(1.) : R(1.) - M::exp(-a2);
-    const R e3 = R(1.) - M::exp(-zHwl / R(12.82));
-    return R(1.) - (R(0.28) * R(0.014) * e1 + R(0.27) * R(0.357) * e2 + R(0.45) * R(12.82) * e3) / zHwl;
+    const R e3 = R(1.) - M::exp(zHwl * R(-1. / 12.82));
+    return R(1.) - M::div(R(0.28 * 0.014) * e1 + R(0.27 * 0.357) * e2 + R(0.45 * 12.82) * e3, zHwl);
 }
 template <class R>
 __device__ __forceinline__ void wl_coare(R (&st)[4], const WlCoareCell<R> &c, R pQsw, R pQnsol, R pTau, bool commit)
@@ -238,13 +248,13 @@ __device__ __forceinline__ void wl_coare(R (&st)[4], const WlCoareCell<R> &c, R 
             zQabs = wl_absorb(zHwl) * pQsw + pQnsol;
             zqac = st[2] + zQabs * K<R>::rdt;
             if (zqac <= R(0.)) break;
-            zHwl = vmax(vmin(Hwl_max, c.zcd1 * ztac / M::sqrt(zqac)), R(0.1));
+            zHwl = vmax(vmin(Hwl_max, M::div(c.zcd1 * ztac, M::sqrt_pos(zqac))), R(0.1));
         }
         if (zqac <= R(0.)) {
             l_destroy = true;
         } else {
-            zdTwl = c.zcd2 * (zqac * M::sqrt(zqac)) / ztac;                        // :220 (zqac > 0 here)
-            if (!nonneg(K<R>::gdept1 - zHwl)) zdTwl = zdTwl * (K<R>::gdept1 / zHwl);  // :223-224
+            zdTwl = M::div(c.zcd2 * (zqac * M::sqrt_pos(zqac)), ztac);             // :220 (zqac > 0 here)
+            if (!nonneg(K<R>::gdept1 - zHwl)) zdTwl = M::div(zdTwl * K<R>::gdept1, zHwl);  // :223-224
         }
     }
     if (l_destroy) { zdTwl = R(0.); zHwl = Hwl_max; zqac = R(0.); ztac = R(0.); }   // :229-235
@@ -254,13 +264,13 @@ __device__ __forceinline__ void wl_coare(R (&st)[4], const WlCoareCell<R> &c, R 
 template <class R> __device__ __forceinline__ bool wl_coare_dawn(R plon, int isd)
 {
     using M = Mth<R>;
-    auto fmodulo = [](R a, R p) -> R { return a - M::floor(a / p) * p; };
-    R rlag = R(-1.) * fmodulo((R(360.) - fmodulo(plon, R(360.))) / R(15.), R(24.));
+    auto fmodulo = [](R a, R p) -> R { return a - M::floor(M::div(a, p)) * p; };
+    R rlag = R(-1.) * fmodulo((R(360.) - fmodulo(plon, R(360.))) * R(1. / 15.), R(24.));
     rlag = R(-1.) * M::copysign(vmin(M::abs(rlag), M::abs(fmodulo(rlag, R(24.)))), rlag + R(12.));
     const int ilag = (int)(rlag * R(3600.));
     int isd_sol = (isd + ilag) % 86400;
     if (isd_sol < 0) isd_sol += 86400;
-    const R rhr = (R)isd_sol / R(3600.);
+    const R rhr = (R)isd_sol * R(1. / 3600.);
     return (rhr > R(4.)) && (rhr <= R(6.5));
 }
 
@@ -269,8 +279,8 @@ template <class R> __device__ __forceinline__ bool wl_coare_dawn(R plon, int isd
 template <class R> __device__ __forceinline__ R phi_takaya(R z)
 {
     using M = Mth<R>;
-    if (nonneg(z)) return R(1.) + (R(5.) * z + R(4.) * z * z) / (R(1.) + R(3.) * z + R(0.25) * z * z);
-    return R(1.) / M::sqrt(R(1.) - R(16.) * (-M::abs(z)));
+    if (nonneg(z)) return R(1.) + M::div(R(5.) * z + R(4.) * z * z, R(1.) + R(3.) * z + R(0.25) * z * z);
+    return M::rcp(M::sqrt_pos(R(1.) - R(16.) * (-M::abs(z))));
 }
 // WL_ECMWF mod_skin_ecmwf.f90:113-230 (no Stokes drift).  Advances dT_wl on EVERY call (:228).
 template <class R> __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, R pQsw, R pQnsol, R pustar, R zalpha)
@@ -278,8 +288,10 @@ template <class R> __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, R 
     using M = Mth<R>;
     const R zRhoCp_w = K<R>::rho0_w * K<R>::rCp0_w;
     const R rNuwl0 = R(0.5);
-    const R ztcorr = nonneg(K<R>::gdept1 - zHwl) ? R(1.) : K<R>::gdept1 / zHwl;
-    const R zdTwl_b = vmax(dT_wl / ztcorr, R(0.));
+    const R zih = M::rcp(zHwl);
+    const bool deep = !nonneg(K<R>::gdept1 - zHwl);       // warm layer deeper than the bulk-SST depth (always: 3 m vs 1 m)
+    const R ztcorr = deep ? K<R>::gdept1 * zih : R(1.);
+    const R zdTwl_b = vmax(deep ? dT_wl * zHwl : dT_wl, R(0.));   // dT_wl / ztcorr, gdept1 == 1
     const R zfr = R(1.) - R(0.28) * M::exp(R(-71.5) * zHwl) - R(0.27) * M::exp(R(-2.8) * zHwl)
                   - R(0.45) * M::exp(R(-0.07) * zHwl);
     const R zQabs = zfr * pQsw + pQnsol;
@@ -288,19 +300,20 @@ template <class R> __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, R 
     const R zfLa = R(2.231443166940565);  // MAX(0.3**(-2/3), 1) :185
     const bool zwf = nonneg(zQabs);
     const R zcst1 = K<R>::vkarmn * K<R>::grav * zalpha;
-    const R zL2 = zcst1 * zQabs / (zRhoCp_w * zusw2 * zusw);
-    const R zcst2 = zcst1 / (R(5.) * zHwl * zusw2);
-    const R zcst0 = K<R>::rdt * (rNuwl0 + R(1.)) / zHwl;
-    const R zA = zcst0 * zQabs / (rNuwl0 * zRhoCp_w);
+    const R ziu2 = M::rcp(zusw2);
+    const R zL2 = zcst1 * zQabs * ziu2 * M::rcp(zRhoCp_w * zusw);
+    const R zcst2 = zcst1 * R(0.2) * zih * ziu2;
+    const R zcst0 = K<R>::rdt * (rNuwl0 + R(1.)) * zih;
+    const R zA = zcst0 * zQabs * R(1. / (0.5 * 1025. * 4190.));
     const R zcst3 = -zcst0 * K<R>::vkarmn * zusw * zfLa;
     R zdTwl_n = zdTwl_b;
     // when zQabs >= 0 the stability parameter does not depend on the iterate: PHI is loop-invariant
-    const R zB_warm = zcst3 / phi_takaya(zHwl * zL2);
+    const R zB_warm = M::div(zcst3, phi_takaya(zHwl * zL2));
 #pragma unroll 1
     for (int jc = 0; jc < 10; ++jc) {
         zdTwl_n = R(0.5) * (zdTwl_n + zdTwl_b);
         R zB = zB_warm;
-        if (!zwf) zB = zcst3 / phi_takaya(zHwl * M::sqrt(zdTwl_n * zcst2));
+        if (!zwf) zB = M::div(zcst3, phi_takaya(zHwl * M::sqrt(zdTwl_n * zcst2)));
         zdTwl_n = vmax(zdTwl_b + zA + zB * zdTwl_n, R(0.));
     }
     dT_wl = zdTwl_n * ztcorr;
@@ -316,28 +329,28 @@ template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
         const R t = R(0.6667) * (z - R(14.28)) * M::exp(-zc);
         if (pm) *pm = -(R(1.) + z + t + R(8.525));
         if (ph) {
-            const R a = M::abs(R(1.) + R(2.) * z / R(3.));
-            *ph = -(a * M::sqrt(a) + t + R(8.525));
+            const R a = M::abs(R(1.) + R(2.) * z * R(1. / 3.));
+            *ph = -(a * M::sqrt_pos(a) + t + R(8.525));
         }
     } else {  // unstable: Kansas / free-convection blend
         R zf = z * z;
-        zf = zf / (R(1.) + zf);
+        zf = M::div(zf, R(1.) + zf);
         if (pm) {
-            const R x2 = M::sqrt(M::abs(R(1.) - R(15.) * z));
-            const R x = M::sqrt(x2);
+            const R x2 = M::sqrt_pos(M::abs(R(1.) - R(15.) * z));
+            const R x = M::sqrt_pos(x2);
             const R hx = R(0.5) * (R(1.) + x);
             const R psik = M::log(hx * hx * (R(0.5) * (R(1.) + x2))) - R(2.) * M::atan(x) + R(0.5) * K<R>::rpi;
             const R c = pow_pos(M::abs(R(1.) - R(10.15) * z), R(.3333));
-            const R psic = R(1.5) * M::log((R(1.) + c + c * c) / R(3.))
-                           - R(1.7320508) * M::atan((R(1.) + R(2.) * c) / R(1.7320508)) + R(1.813799447);
+            const R psic = R(1.5) * M::log((R(1.) + c + c * c) * R(1. / 3.))
+                           - R(1.7320508) * M::atan((R(1.) + R(2.) * c) * R(1. / 1.7320508)) + R(1.813799447);
             *pm = (R(1.) - zf) * psik + zf * psic;
         }
         if (ph) {
-            const R x2 = M::sqrt(M::abs(R(1.) - R(15.) * z));
+            const R x2 = M::sqrt_pos(M::abs(R(1.) - R(15.) * z));
             const R psik = R(2.) * M::log(R(0.5) * (R(1.) + x2));
             const R c = pow_pos(M::abs(R(1.) - R(34.15) * z), R(.3333));
-            const R psic = R(1.5) * M::log((R(1.) + c + c * c) / R(3.))
-                           - R(1.7320508) * M::atan((R(1.) + R(2.) * c) / R(1.7320508)) + R(1.813799447);
+            const R psic = R(1.5) * M::log((R(1.) + c + c * c) * R(1. / 3.))
+                           - R(1.7320508) * M::atan((R(1.) + R(2.) * c) * R(1. / 1.7320508)) + R(1.813799447);
             *ph = (R(1.) - zf) * psik + zf * psic;
         }
     }
@@ -355,12 +368,12 @@ template <class R> __device__ __forceinline__ R charn_coare3p0(R w)
 {
     if (!nonneg(w - R(10.))) return R(0.011);
     if (nonneg(w - R(18.))) return R(0.018);
-    return R(0.011) + R(0.018 - 0.011) * (w - R(10.)) / R(18. - 10.);
+    return R(0.011) + R(0.018 - 0.011) * (w - R(10.)) * R(1. / (18. - 10.));
 }
 
 // FIRST_GUESS_COARE_SCLR mod_common_coare.f90:33-179 (shared by COARE 3.0/3.6 and ECMWF)
 template <class R> struct Heights {  // wave-uniform, prepared on the host
-    R zt, zu, log_zt, log_zu, log_10, log_ztu, log_zu10, fg_ca;
+    R zt, zu, log_zt, log_zu, log_10, log_ztu, log_zu10, fg_ca, inv_zu, zt_o_zu;
     int zt_eq_zu;  // ABS(zu-zt) < 0.01
 };
 template <class R>
@@ -376,33 +389,31 @@ __device__ __forceinline__ void first_guess_coare(const Heights<R> &h, R psst, R
     R zdt = sfloor(t_zu - psst, R(1.E-09));
     R zdq = sfloor(q_zu - pssq, R(1.E-12));
     const R zNu_a = visc_air(t_zu);
-    const R zUb = M::sqrt(U_zu * U_zu + R(0.25));
+    const R zUb = M::sqrt_pos(U_zu * U_zu + R(0.25));
     R zus = h.fg_ca * zUb;  // zc_a = 0.035*LOG(10/z0)/LOG(zu/z0), z0 = 1e-4 :107
-    R zz0 = pcharn * zus * zus / K<R>::grav + R(0.11) * zNu_a / zus;
+    R zz0 = pcharn * zus * zus * R(1. / 9.8) + M::div(R(0.11) * zNu_a, zus);
     zz0 = vmin(vmax(M::abs(zz0), R(1.E-8)), R(1.));
     const R zlog_z0 = M::log(zz0);
-    R zCd = vk / (h.log_zu - zlog_z0);
-    zCd = zCd * zCd;
-    const R z1_o_sqrt_Cd10 = (h.log_10 - zlog_z0) / vk;
-    R zz0t = R(10.) * M::exp(-vk / (R(0.00115) * z1_o_sqrt_Cd10));
-    zz0t = vmin(vmax(M::abs(zz0t), R(1.E-8)), R(1.));
-    const R zlog_z0t = M::log(zz0t);
+    const R zdl = h.log_zu - zlog_z0;
+    // z0t = 10/exp(kappa/(0.00115 (ln10-ln z0)/kappa)) :130, clamped to [1e-8,1]; only its log is used
+    const R zlog_z0t = vmin(vmax(h.log_10 - M::div(vk, R(0.00115) * ((h.log_10 - zlog_z0) * K<R>::inv_vk)), R(-18.420680743952367)), R(0.));
     const R zRib = ri_bulk(h.zu, psst, t_zu, pssq, q_zu, zUb);
-    const R zcc_ri = K<R>::vkarmn2 / (zCd * (h.log_zt - zlog_z0t)) * zRib;
+    // kappa^2/(Cd (ln zt - ln z0t)) Ri, Cd = (kappa/(ln zu - ln z0))^2  :126,138-139
+    const R zcc_ri = M::div(zdl * zdl, h.log_zt - zlog_z0t) * zRib;
     R zzeta_u;
-    if (nonneg(zRib)) zzeta_u = zcc_ri + R(27.) / R(9.) * zRib * zRib;
-    else zzeta_u = zcc_ri / (R(1.) + zRib * (-zc_b / h.zu));
+    if (nonneg(zRib)) zzeta_u = zcc_ri + R(27. / 9.) * zRib * zRib;
+    else zzeta_u = M::div(zcc_ri, R(1.) + zRib * (-zc_b * h.inv_zu));
     R psm, psh;
     psi_coare<R>(zzeta_u, &psm, &psh);
-    zus = vmax(zUb * vk / (h.log_zu - zlog_z0 - psm), R(1.E-9));
-    const R ztmp = vk / (h.log_zu - zlog_z0t - psh);
+    zus = vmax(M::div(zUb * vk, zdl - psm), R(1.E-9));
+    const R ztmp = M::div(vk, h.log_zu - zlog_z0t - psh);
     R zts = zdt * ztmp;
     R zqs = zdq * ztmp;
     if (!h.zt_eq_zu) {
-        const R zzeta_t = h.zt * zzeta_u / h.zu;
+        const R zzeta_t = zzeta_u * h.zt_o_zu;
         const R zprf = h.log_ztu + psh - psi_h_coare<R>(zzeta_t);
-        t_zu = t_zt - zts / vk * zprf;
-        q_zu = q_zt - zqs / vk * zprf;
+        t_zu = t_zt - zts * K<R>::inv_vk * zprf;
+        q_zu = q_zt - zqs * K<R>::inv_vk * zprf;
         q_zu = nonneg(q_zu) ? q_zu : R(0.) * q_zu;
         zdt = sfloor(t_zu - psst, R(1.E-09));
         zdq = sfloor(q_zu - pssq, R(1.E-12));
@@ -410,7 +421,7 @@ __device__ __forceinline__ void first_guess_coare(const Heights<R> &h, R psst, R
         zqs = zdq * ztmp;
     }
     pus = zus; pts = zts; pqs = zqs; Ubzu = zUb;
-    zz0 = pcharn * zus * zus / K<R>::grav + R(0.11) * zNu_a / zus;
+    zz0 = pcharn * zus * zus * R(1. / 9.8) + M::div(R(0.11) * zNu_a, zus);
     pz0 = vmin(vmax(M::abs(zz0), R(1.E-8)), R(1.));
 }
 
@@ -444,15 +455,16 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
         q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);  // :275
         zalpha = alpha_sw(xSST);                                       // hoisted from CS_COARE :81 / WL_COARE :153
         const R Rich0 = R(0.65);
-        wc.zcd1 = M::sqrt(R(2.) * Rich0 * K<R>::rCp0_w / (zalpha * K<R>::grav * K<R>::rho0_w));   // :155
-        wc.zcd2 = M::sqrt(R(2.) * zalpha * K<R>::grav / (Rich0 * K<R>::rho0_w))
-                  / R(271219.5770957547);                             // rCp0_w**1.5 :156
+        wc.zcd1 = M::sqrt(M::div(R(2.) * Rich0 * K<R>::rCp0_w, zalpha * K<R>::grav * K<R>::rho0_w));   // :155
+        wc.zcd2 = M::sqrt(R(2.) * zalpha * K<R>::grav * R(1. / (0.65 * 1025.)))
+                  * R(1. / 271219.5770957547);                        // / rCp0_w**1.5 :156
     }
     R zus, zts, zqs, t_zu, q_zu, Ubzu, zz0;
     first_guess_coare(h, T_s, in.theta_zt, q_s, in.q_zt, zUzu, V36 ? charn_coare3p6(zUzu) : charn_coare3p0(zUzu),
                       zus, zts, zqs, t_zu, q_zu, Ubzu, zz0);
     R zlog_z0 = M::log(zz0);
     const R znu_a = visc_air(V36 ? t_zu : in.theta_zt);  // 3p6 :294 (first-guess t_zu) vs 3p0 :237 (t_zt)
+    const R zlog_nu = M::log(znu_a);
     R zdt = sfloor(t_zu - T_s, R(1.E-09));
     R zdq = sfloor(q_zu - q_s, R(1.E-12));
     R zdT_cs = R(0.);
@@ -462,34 +474,35 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
         const R zus2 = zus * zus;
         const R z1oL = one_on_l(t_zu, q_zu, zus, zts, zqs);            // :307-308 (second clamp is idempotent)
         // gustiness :311-313: Ug^2 = Beta0^2 u*^2 (max(-zi0/(kappa L),0))^(2/3)
-        const R zg = vmax(-zi0 * z1oL / vk, R(0.));
+        const R zg = vmax(-zi0 * z1oL * K<R>::inv_vk, R(0.));
         const R zcb = M::cbrt(zg);
         const R zgust2 = Beta0 * Beta0 * zus2 * (zcb * zcb);
         Ubzu = vmax(M::sqrt(zUzu * zUzu + zgust2), R(0.2));
         const R zzta_u = sclamp(h.zu * z1oL, zeta_max);                // :317-318
         // roughness lengths :328-336 (3p0 :270-278)
-        const R zUn10 = zus / vk * (h.log_10 - zlog_z0);
-        zz0 = (V36 ? charn_coare3p6(zUn10) : charn_coare3p0(zUn10)) * zus2 / K<R>::grav + R(0.11) * znu_a / zus;
+        const R zUn10 = zus * K<R>::inv_vk * (h.log_10 - zlog_z0);
+        const R zlog_us = M::log(zus);
+        zz0 = (V36 ? charn_coare3p6(zUn10) : charn_coare3p0(zUn10)) * zus2 * R(1. / 9.8) + M::div(R(0.11) * znu_a, zus);
         zz0 = vmin(vmax(M::abs(zz0), R(1.E-9)), R(1.));
         zlog_z0 = M::log(zz0);
-        // z0t = min(1.6e-4, 5.8e-5 Rr^-0.72) (3p6) | min(1.1e-4, 5.5e-5 Rr^-0.6) (3p0); log taken analytically
-        const R zlog_rr = M::log(znu_a / (zz0 * zus));
-        R zz0t = V36 ? vmin(R(1.6E-4), R(5.8E-5) * M::exp(R(0.72) * zlog_rr))
-                     : vmin(R(1.1E-4), R(5.5E-5) * M::exp(R(0.6) * zlog_rr));
-        zz0t = vmin(vmax(M::abs(zz0t), R(1.E-9)), R(1.));
-        const R zlog_z0t = M::log(zz0t);
+        // z0t = min(1.6e-4, 5.8e-5 Rr^-0.72) (3p6 :333-334) | min(1.1e-4, 5.5e-5 Rr^-0.6) (3p0 :275-276), Rr = z0 u*/nu,
+        // clamped to [1e-9,1] (:335): only LOG(z0t) is used (:336,340), so it is formed in the log domain
+        const R zlog_rr = zlog_nu - zlog_z0 - zlog_us;                 // ln(nu/(z0 u*))
+        const R zlog_z0t = vmax(V36 ? vmin(R(-8.740336742730447), R(-9.755067547417855) + R(0.72) * zlog_rr)
+                                    : vmin(R(-9.115030192171858), R(-9.808177372731803) + R(0.6) * zlog_rr),
+                                R(-20.72326583694641));
         // turbulent scales :339-344
         R psm, psh;
         psi_coare<R>(zzta_u, &psm, &psh);
-        R ztmp1 = vk / (h.log_zu - zlog_z0t - psh);
+        R ztmp1 = M::div(vk, h.log_zu - zlog_z0t - psh);
         zts = zdt * ztmp1;
         zqs = zdq * ztmp1;
-        zus = vmax(Ubzu * vk / (h.log_zu - zlog_z0 - psm), R(1.E-9));
+        zus = vmax(M::div(Ubzu * vk, h.log_zu - zlog_z0 - psm), R(1.E-9));
         if (!h.zt_eq_zu) {                                             // :346-351 (3p0 :289-291 with zm_ztzu = 1)
             const R zzta_t = sclamp(h.zt * z1oL, zeta_max);
             ztmp1 = h.log_zt - h.log_zu + psh - psi_h_coare<R>(zzta_t);
-            t_zu = in.theta_zt - zts / vk * ztmp1;
-            q_zu = in.q_zt - zqs / vk * ztmp1;
+            t_zu = in.theta_zt - zts * K<R>::inv_vk * ztmp1;
+            q_zu = in.q_zt - zqs * K<R>::inv_vk * ztmp1;
         } else if (!V36) {                                             // 3p0: t_zu = t_zt - 0*...  (drops the 180 K floor)
             t_zu = in.theta_zt;
             q_zu = in.q_zt;
@@ -514,10 +527,10 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             zdq = sfloor(q_zu - q_s, R(1.E-12));
         }
     }
-    const R ztmp0 = zus / Ubzu;                                        // :386-389
+    const R ztmp0 = M::div(zus, Ubzu);                                 // :386-389
     o.Cd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);
-    o.Ch = vmax(ztmp0 * zts / zdt, K<R>::Cx_min);
-    o.Ce = vmax(ztmp0 * zqs / zdq, K<R>::Cx_min);
+    o.Ch = vmax(M::div(ztmp0 * zts, zdt), K<R>::Cx_min);
+    o.Ce = vmax(M::div(ztmp0 * zqs, zdq), K<R>::Cx_min);
     o.t_zu = t_zu; o.q_zu = q_zu; o.Ubzu = Ubzu; o.T_s = T_s; o.q_s = q_s;
 }
 
@@ -533,12 +546,12 @@ template <class R> __device__ __forceinline__ void psi_ecmwf(R pz, R *pm, R *ph)
         if (pm) *pm = t - z - R(2. / 3.) * zc;
         if (ph) {
             const R a = M::abs(R(1.) + R(2. / 3.) * z);
-            *ph = t - a * M::sqrt(a) - R(2. / 3.) * zc + R(1.);
+            *ph = t - a * M::sqrt_pos(a) - R(2. / 3.) * zc + R(1.);
         }
     } else {
-        const R x2 = M::sqrt(M::abs(R(1.) - R(16.) * z));
+        const R x2 = M::sqrt_pos(M::abs(R(1.) - R(16.) * z));
         if (pm) {
-            const R x = M::sqrt(x2);
+            const R x = M::sqrt_pos(x2);
             const R t = R(1.) + x;
             *pm = M::log(R(0.125) * t * t * (R(1.) + x2)) - R(2.) * M::atan(x) + R(0.5) * K<R>::rpi;
         }
@@ -574,9 +587,9 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
     R z1oL = one_on_l(zt_zu, zq_zu, zus, zts, zqs);                     // :245
     R zzeta_u = h.zu * z1oL;
     // :249  z0t = 1/(0.1 exp(kappa/(0.00115/(kappa/(ln10 - ln z0)))))
-    R zz0t = R(1.) / (R(0.1) * M::exp(vk / (R(0.00115) / (vk / (h.log_10 - zlog_z0)))));
-    zz0t = vmin(vmax(M::abs(zz0t), R(1.E-9)), R(1.));
-    R zlog_z0t = M::log(zz0t);
+    // :249  z0t = 1/(0.1 exp(kappa/(0.00115/(kappa/(ln10 - ln z0))))) clamped to [1e-9,1]; log and value both needed
+    R zlog_z0t = vmin(vmax(h.log_10 - M::div(vk, M::div(R(0.00115), M::div(vk, h.log_10 - zlog_z0))), R(-20.72326583694641)), R(0.));
+    R zz0t = M::exp(zlog_z0t);
     R zpsi_m_u, zpsi_h_u;
     psi_ecmwf<R>(zzeta_u, &zpsi_m_u, &zpsi_h_u);
     R zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf<R>(zz0 * z1oL);   // :253
@@ -586,37 +599,38 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
         const R zRib = ri_bulk(h.zu, zT_s, zt_zu, zq_s, zq_zu, zUbzu);  // :261 (previous Ub, T_s, q_s)
-        z1oL = sclamp(zRib * zFm * zFm / zFh / h.zu, R(200.));          // :264-266
+        z1oL = sclamp(M::div(zRib * zFm * zFm, zFh) * h.inv_zu, R(200.));  // :264-266
         zzeta_u = h.zu * z1oL;
         psi_ecmwf<R>(zzeta_u, &zpsi_m_u, &zpsi_h_u);                    // :269-270
         const R zpsi_h_t = psi_h_ecmwf<R>(h.zt * z1oL);                 // :272-273
         zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf<R>(zz0 * z1oL);  // :276
-        zus = zUbzu * vk / zFm;                                         // :279
+        zus = M::div(zUbzu * vk, zFm);                                  // :279
         const R zus2 = zus * zus;
-        R ztmp0 = znu_a / zus;
-        zz0 = vmin(M::abs(alpha_M * ztmp0 + charn0 * zus2 / K<R>::grav), R(0.001));  // :282-284
+        R ztmp0 = M::div(znu_a, zus);
+        zz0 = vmin(M::abs(alpha_M * ztmp0 + charn0 * zus2 * R(1. / 9.8)), R(0.001));  // :282-284
         zz0t = vmin(M::abs(alpha_H * ztmp0), R(0.001));
         const R zz0q = vmin(M::abs(alpha_Q * ztmp0), R(0.001));
         zlog_z0 = M::log(zz0);
-        zlog_z0t = M::log(zz0t);
-        zlog_z0q = M::log(zz0q);
+        const R zlog_nuus = M::log(M::abs(ztmp0));                      // z0t, z0q share ln(nu/u*) :287-288
+        zlog_z0t = vmin(R(-0.916290731874155) + zlog_nuus, R(-6.907755278982137));
+        zlog_z0q = vmin(R(-0.4780358009429998) + zlog_nuus, R(-6.907755278982137));
         const R zpsi_m_z0 = psi_m_ecmwf<R>(zz0 * z1oL);                 // :290-292
         const R zpsi_h_z0t = psi_h_ecmwf<R>(zz0t * z1oL);
         zpsi_h_z0q = psi_h_ecmwf<R>(zz0q * z1oL);
         // gustiness :296-298 (Beta0 = 1)
-        const R zcb = M::cbrt(vmax(-zi0 * z1oL / vk, R(0.)));
+        const R zcb = M::cbrt(vmax(-zi0 * z1oL * K<R>::inv_vk, R(0.)));
         zUbzu = vmax(M::sqrt(zUzu * zUzu + zus2 * (zcb * zcb)), R(0.2));
         // t*, q* and height adjustment :303-313
         ztmp0 = zpsi_h_u - zpsi_h_z0t;
-        R ztmp1 = vk / (h.log_zu - zlog_z0t - ztmp0);
+        R ztmp1 = M::div(vk, h.log_zu - zlog_z0t - ztmp0);
         zts = zdt * ztmp1;
         ztmp1 = h.log_ztu + ztmp0 - zpsi_h_t + zpsi_h_z0t;
-        zt_zu = in.theta_zt - zm_ztzu * zts / vk * ztmp1;
+        zt_zu = in.theta_zt - zm_ztzu * zts * K<R>::inv_vk * ztmp1;
         ztmp0 = zpsi_h_u - zpsi_h_z0q;
-        ztmp1 = vk / (h.log_zu - zlog_z0q - ztmp0);
+        ztmp1 = M::div(vk, h.log_zu - zlog_z0q - ztmp0);
         zqs = zdq * ztmp1;
         ztmp1 = h.log_ztu + ztmp0 - zpsi_h_t + zpsi_h_z0q;
-        zq_zu = vmax(in.q_zt - zm_ztzu * zqs / vk * ztmp1, R(0.));
+        zq_zu = vmax(in.q_zt - zm_ztzu * zqs * K<R>::inv_vk * ztmp1, R(0.));
         zFm = h.log_zu - zlog_z0 - zpsi_m_u + zpsi_m_z0;                // :316-317
         zFh = h.log_zu - zlog_z0t - zpsi_h_u + zpsi_h_z0t;
         if (SKIN) {
@@ -638,9 +652,10 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
         zdq = sfloor(zq_zu - zq_s, R(1.E-12));
     }
     const R zFq = h.log_zu - zlog_z0q - zpsi_h_u + zpsi_h_z0q;          // :356-359
-    o.Cd = vmax(K<R>::vkarmn2 / (zFm * zFm), K<R>::Cx_min);
-    o.Ch = vmax(K<R>::vkarmn2 / (zFm * zFh), K<R>::Cx_min);
-    o.Ce = vmax(K<R>::vkarmn2 / (zFm * zFq), K<R>::Cx_min);
+    const R ziFm = M::div(K<R>::vkarmn2, zFm);
+    o.Cd = vmax(M::div(ziFm, zFm), K<R>::Cx_min);
+    o.Ch = vmax(M::div(ziFm, zFh), K<R>::Cx_min);
+    o.Ce = vmax(M::div(ziFm, zFq), K<R>::Cx_min);
     o.t_zu = zt_zu; o.q_zu = zq_zu; o.Ubzu = zUbzu; o.T_s = zT_s; o.q_s = zq_s;
 }
 
@@ -654,7 +669,7 @@ template <class R> __device__ __forceinline__ R cd_n10_ncar(R zw)
     } else {
         R zw6 = zw * zw * zw;
         zw6 = zw6 * zw6;
-        r = R(1.e-3) * (R(2.7) / zw + R(0.142) + zw / R(13.09) - R(3.14807E-10) * zw6);
+        r = R(1.e-3) * (Mth<R>::div(R(2.7), zw) + R(0.142) + zw * R(1. / 13.09) - R(3.14807E-10) * zw6);
     }
     return vmax(r, K<R>::Cx_min);
 }
@@ -666,9 +681,9 @@ template <class R> __device__ __forceinline__ void psi_ncar(R z, R *pm, R *ph)
         if (pm) *pm = R(-5.) * z;
         if (ph) *ph = R(-5.) * z;
     } else {
-        const R x2 = vmax(M::sqrt(M::abs(R(1.) - R(16.) * z)), R(1.));
+        const R x2 = vmax(M::sqrt_pos(M::abs(R(1.) - R(16.) * z)), R(1.));
         if (pm) {
-            const R x = M::sqrt(x2);
+            const R x = M::sqrt_pos(x2);
             const R hx = (R(1.) + x) * R(0.5);
             *pm = M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan(x) + K<R>::rpi * R(0.5);
         }
@@ -685,7 +700,7 @@ __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &
     const R Ubzu = vmax(R(0.5), in.wnd);                                // :148
     bool stab = nonneg(virt_temp(in.theta_zt, in.q_zt) - virt_temp(sst, ssq));  // :158
     R zCdN = cd_n10_ncar(Ubzu);
-    R zsqrt_CdN = M::sqrt(zCdN);
+    R zsqrt_CdN = M::sqrt_pos(zCdN);
     R Cd = zCdN;
     R Ce = vmax(R(1.e-3) * (R(34.6) * zsqrt_CdN), K<R>::Cx_min);         // ce_n10 :321
     R Ch = vmax(R(1.e-3) * zsqrt_CdN * (stab ? R(18.) : R(32.7)), K<R>::Cx_min);  // ch_n10 :301
@@ -697,8 +712,9 @@ __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &
         const R zdt = t_zu - sst;                                       // :177-178 (not floored)
         const R zdq = q_zu - ssq;
         const R zus = zsqrt_Cd * Ubzu;
-        const R zts = Ch / zsqrt_Cd * zdt;
-        const R zqs = Ce / zsqrt_Cd * zdq;
+        const R zisq = M::rcp(zsqrt_Cd);
+        const R zts = Ch * zisq * zdt;
+        const R zqs = Ce * zisq * zdq;
         const R z1oL = one_on_l(t_zu, q_zu, zus, zts, zqs);
         const R zeta_u = sclamp(h.zu * z1oL, R(10.));                   // :189-190
         R psm, psh;
@@ -708,26 +724,27 @@ __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &
             R psht;
             psi_ncar<R>(zeta_t, nullptr, &psht);
             const R ztmp = h.log_ztu + psh - psht;
-            t_zu = in.theta_zt - zts / vk * ztmp;
-            q_zu = in.q_zt - zqs / vk * ztmp;
+            t_zu = in.theta_zt - zts * K<R>::inv_vk * ztmp;
+            q_zu = in.q_zt - zqs * K<R>::inv_vk * ztmp;
             q_zu = vmax(R(0.), q_zu);
         }
         // UN10_from_CD mod_phymbl.f90:1545 with z0_from_Cd :1346:
         //   sqrt(Cd) Ub/kappa * ln(10/(zu exp(-(kappa/sqrt(Cd)+psi)))) = sqrt(Cd) Ub/kappa * (ln(10/zu) + kappa/sqrt(Cd) + psi)
-        const R zsq = M::sqrt(Cd);
-        const R zUn10 = vmax(R(0.25), zsq * Ubzu / vk * (-h.log_zu10 + (vk / zsq + psm)));  // :207
+        // (zsqrt_Cd == SQRT(Cd) at this point: first guess :168, then :216)
+        const R zUn10 = vmax(R(0.25), zsqrt_Cd * Ubzu * K<R>::inv_vk * (-h.log_zu10 + (vk * zisq + psm)));  // :207
         zCdN = cd_n10_ncar(zUn10);
-        zsqrt_CdN = M::sqrt(zCdN);
-        R ztmp = R(1.) + zsqrt_CdN / vk * (h.log_zu10 - psm);           // :213
-        Cd = vmax(zCdN / (ztmp * ztmp), K<R>::Cx_min);
-        zsqrt_Cd = M::sqrt(Cd);
-        ztmp = (h.log_zu10 - psh) / vk / zsqrt_CdN;                     // :217
-        const R ztmp2 = zsqrt_Cd / zsqrt_CdN;
+        zsqrt_CdN = M::sqrt_pos(zCdN);
+        R ztmp = R(1.) + zsqrt_CdN * K<R>::inv_vk * (h.log_zu10 - psm);  // :213
+        Cd = vmax(M::div(zCdN, ztmp * ztmp), K<R>::Cx_min);
+        zsqrt_Cd = M::sqrt_pos(Cd);
+        const R ziN = M::rcp(zsqrt_CdN);
+        ztmp = (h.log_zu10 - psh) * K<R>::inv_vk * ziN;                 // :217
+        const R ztmp2 = zsqrt_Cd * ziN;
         stab = nonneg(zeta_u);                                          // :220
         const R zChN = R(1.e-3) * zsqrt_CdN * (stab ? R(18.) : R(32.7));
         const R zCeN = R(1.e-3) * (R(34.6) * zsqrt_CdN);
-        Ch = vmax(zChN * ztmp2 / (R(1.) + zChN * ztmp), K<R>::Cx_min);
-        Ce = vmax(zCeN * ztmp2 / (R(1.) + zCeN * ztmp), K<R>::Cx_min);
+        Ch = vmax(M::div(zChN * ztmp2, R(1.) + zChN * ztmp), K<R>::Cx_min);
+        Ce = vmax(M::div(zCeN * ztmp2, R(1.) + zCeN * ztmp), K<R>::Cx_min);
     }
     o.Cd = Cd; o.Ch = Ch; o.Ce = Ce; o.t_zu = t_zu; o.q_zu = q_zu; o.Ubzu = Ubzu; o.T_s = sst; o.q_s = ssq;
 }
@@ -742,15 +759,16 @@ template <class R> __device__ __forceinline__ R psi_m_andreas(R pz)
         const R zam = R(5.), zbm = R(5. / 6.5), zsr3 = R(1.7320508075688772);
         const R zbbm = R(0.6694329500821695);  // ((1-b_m)/b_m)^(1/3) = 0.3^(1/3)
         const R x = M::cbrt(M::abs(R(1.) + z));
-        const R l1 = (x + zbbm) / (R(1.) + zbbm);
-        const R l2 = (x * x - x * zbbm + zbbm * zbbm) / (R(1.) - zbbm + zbbm * zbbm);
-        return R(-3.) * zam / zbm * (x - R(1.))
+        const R l1 = (x + zbbm) * R(1. / (1. + 0.6694329500821695));
+        const R l2 = (x * x - x * zbbm + zbbm * zbbm) * R(1. / (1. - 0.6694329500821695 + 0.6694329500821695 * 0.6694329500821695));
+        return R(-3. * 5. / (5. / 6.5)) * (x - R(1.))
                + zam * zbbm / (R(2.) * zbm)
-                     * (M::log(l1 * l1 / l2)
-                        + R(2.) * zsr3 * (M::atan((R(2.) * x - zbbm) / (zsr3 * zbbm)) - M::atan((R(2.) - zbbm) / (zsr3 * zbbm))));
+                     * (M::log(M::div(l1 * l1, l2))
+                        + R(2.) * zsr3 * (M::atan((R(2.) * x - zbbm) * R(1. / (1.7320508075688772 * 0.6694329500821695)))
+                                          - R(0.8539936329836121)));  // ATAN((2-B_m)/(sqrt(3) B_m))
     }
-    const R x2 = vmax(M::sqrt(M::abs(R(1.) - R(16.) * z)), R(1.));
-    const R x = M::sqrt(x2);
+    const R x2 = vmax(M::sqrt_pos(M::abs(R(1.) - R(16.) * z)), R(1.));
+    const R x = M::sqrt_pos(x2);
     const R hx = (R(1.) + x) * R(0.5);
     return M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan(x) + K<R>::rpi * R(0.5);
 }
@@ -763,11 +781,11 @@ template <class R> __device__ __forceinline__ R psi_h_andreas(R pz)
         const R zah = R(5.), zbh = R(5.), zch = R(3.), zbbh = R(2.23606797749979);
         const R zz = R(2.) * z + zch;
         // LOG|(zz-B)/(zz+B)| - LOG|(c-B)/(c+B)|
-        const R r = ((zz - zbbh) / (zz + zbbh)) / ((zch - zbbh) / (zch + zbbh));
+        const R r = M::div(zz - zbbh, zz + zbbh) * R((3. + 2.23606797749979) / (3. - 2.23606797749979));
         return R(-0.5) * zbh * M::log(M::abs(R(1.) + zch * z + z * z))
                + (-zah / zbbh + R(0.5) * zbh * zch / zbbh) * M::log(M::abs(r));
     }
-    const R x2 = vmax(M::sqrt(M::abs(R(1.) - R(16.) * z)), R(1.));
+    const R x2 = vmax(M::sqrt_pos(M::abs(R(1.) - R(16.) * z)), R(1.));
     return R(2.) * M::log(R(0.5) * (R(1.) + x2));
 }
 // z0tq_LKB mod_phymbl.f90:1635-1701 (Liu, Katsaros & Businger 1979): both z0t (iflag 1) and z0q (iflag 2)
@@ -786,8 +804,9 @@ template <class R> __device__ __forceinline__ void z0tq_lkb(R zrr, R pz0, R &z0t
         else if (zrr <= R(300.))  { at = R(1667.19); bt = R(-2.907); aq = R(1448.68); bq = R(-2.682); }
         else                      { at = R(5.88e5);  bt = R(-3.935); aq = R(2.98e5);  bq = R(-3.616); }
         const R lr = M::log(zrr);
-        rt = at * M::exp(bt * lr) * pz0 / zrr;
-        rq = aq * M::exp(bq * lr) * pz0 / zrr;
+        const R zs = M::div(pz0, zrr);
+        rt = at * M::exp(bt * lr) * zs;
+        rq = aq * M::exp(bq * lr) * zs;
     }
     z0t = vmin(vmax(M::abs(rt), R(1.E-9)), R(0.05));
     z0q = vmin(vmax(M::abs(rq), R(1.E-9)), R(0.05));
@@ -800,47 +819,47 @@ __device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R
     const R vk = K<R>::vkarmn;
     const R psst = in.sst, pssq = in.ssq;
     const R pUbzu = vmax(R(0.25), in.wnd);                              // :157
+    const R ziUb = M::rcp(pUbzu);
     R UN10 = pUbzu;
     R pt_zu = in.theta_zt, pq_zu = in.q_zt;
-    const R sq0 = M::sqrt(R(1.1E-3));
-    R t_star = R(1.1E-3) / sq0 * (pt_zu - psst);                        // :168-170
-    R q_star = R(1.1E-3) / sq0 * (pq_zu - pssq);
+    R t_star = R(0.03316624790355400) * (pt_zu - psst);                 // Ch/SQRT(Cd), Cd=Ch=Ce=1.1e-3 :161-170
+    R q_star = R(0.03316624790355400) * (pq_zu - pssq);
     R RiB = ri_bulk(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);             // :173
     R u_star = R(0.);
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
         if (RiB < R(0.15)) {                                            // :183-191
             const R za = UN10 - R(8.271);                               // u_star_andreas_sclr :289-291
-            u_star = R(0.239) + R(0.0433) * (za + M::sqrt(R(0.12) * za * za + R(0.181)));
+            u_star = R(0.239) + R(0.0433) * (za + M::sqrt_pos(R(0.12) * za * za + R(0.181)));
         } else {
             u_star = R(0.01) * pUbzu;                                   // SQRT(Cx_min) = 1e-2
         }
         const R zeta_u = h.zu * one_on_l(pt_zu, pq_zu, u_star, t_star, q_star);  // :200
-        R ztmp0 = u_star / pUbzu;
+        R ztmp0 = u_star * ziUb;
         const R pCd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);                // :209
         const R psm = psi_m_andreas<R>(zeta_u);
-        const R z0 = vmin(h.zu * M::exp(-(vk / M::sqrt(pCd) + psm)), K<R>::z0_sea_max);  // :214
-        ztmp0 = z0 * u_star / visc_air(pt_zu);                          // :219 Re_r
+        const R z0 = vmin(h.zu * M::exp(-(M::div(vk, M::sqrt_pos(pCd)) + psm)), K<R>::z0_sea_max);  // :214
+        ztmp0 = M::div(z0 * u_star, visc_air(pt_zu));                   // :219 Re_r
         R z0t, z0q;
         z0tq_lkb(ztmp0, z0, z0t, z0q);                                  // :220-221
         const R psh = psi_h_andreas<R>(zeta_u);
-        t_star = (pt_zu - psst) * vk / (h.log_zu - M::log(z0t) - psh);  // :226-227
-        q_star = (pq_zu - pssq) * vk / (h.log_zu - M::log(z0q) - psh);
+        t_star = M::div((pt_zu - psst) * vk, h.log_zu - M::log(z0t) - psh);  // :226-227
+        q_star = M::div((pq_zu - pssq) * vk, h.log_zu - M::log(z0q) - psh);
         if ((!h.zt_eq_zu) && (jit > 1)) {                               // :229-236
-            const R zeta_t = zeta_u / h.zu * h.zt;
+            const R zeta_t = zeta_u * h.zt_o_zu;
             const R zp = h.log_ztu + psh - psi_h_andreas<R>(zeta_t);
-            pt_zu = in.theta_zt - t_star / vk * zp;
-            pq_zu = in.q_zt - q_star / vk * zp;
+            pt_zu = in.theta_zt - t_star * K<R>::inv_vk * zp;
+            pq_zu = in.q_zt - q_star * K<R>::inv_vk * zp;
             RiB = ri_bulk(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);
         }
-        UN10 = vmax(R(0.1), pUbzu - u_star / vk * (h.log_zu10 - psm));  // :239 (UN10_from_ustar mod_phymbl.f90:1508)
+        UN10 = vmax(R(0.1), pUbzu - u_star * K<R>::inv_vk * (h.log_zu10 - psm));  // :239 (UN10_from_ustar mod_phymbl.f90:1508)
     }
-    const R ztmp0 = u_star / pUbzu;                                     // :247-254
+    const R ztmp0 = u_star * ziUb;                                      // :247-254
     o.Cd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);
     const R d1 = sfloor(pt_zu - psst, R(1.E-6));
     const R d2 = sfloor(pq_zu - pssq, R(1.E-9));
-    o.Ch = vmax(ztmp0 * t_star / d1, R(0.35E-3));
-    o.Ce = vmax(ztmp0 * q_star / d2, R(0.35E-3));
+    o.Ch = vmax(M::div(ztmp0 * t_star, d1), R(0.35E-3));
+    o.Ce = vmax(M::div(ztmp0 * q_star, d2), R(0.35E-3));
     o.t_zu = pt_zu; o.q_zu = pq_zu; o.Ubzu = pUbzu; o.T_s = psst; o.q_s = pssq;
 }
 

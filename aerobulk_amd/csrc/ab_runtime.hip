@@ -414,6 +414,25 @@ int ab_synth_fields_device(void *sst, void *t_zt, void *q_zt, void *u, void *v, 
     return AB_OK;
 }
 
+/* test hook: elementwise fp64 device math (host arrays in/out) */
+int ab_test_math(int op, const double *x, const double *y, double *out, long n)
+{
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)n;
+    AB_HIP(hipMalloc((void **)&dx, bytes));
+    AB_HIP(hipMalloc((void **)&dout, bytes));
+    AB_HIP(hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
+    if (y) {
+        AB_HIP(hipMalloc((void **)&dy, bytes));
+        AB_HIP(hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice));
+    }
+    AB_HIP(ab::launch_math_test(op, dx, dy, dout, n, nullptr));
+    AB_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dout);
+    if (dy) (void)hipFree(dy);
+    return AB_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // AEROBULK_MODEL on a process-global session (mod_aerobulk.f90:176-269) — non-reentrant by contract.
 static ab_session *g_sess = nullptr;

@@ -128,6 +128,10 @@ int ab_synth_fields_device(void *sst, void *t_zt, void *q_zt, void *u_zu, void *
                            void *rad_sw, void *rad_lw, long ni, long j0, long nj_local, int precision,
                            void *stream);
 
+/* Test hook: apply the engine's fp64 device math function `op` elementwise to host arrays (y may be NULL):
+ * 0 div 1 rcp 2 sqrt 3 log 4 log10 5 exp 6 exp10 7 atan 8 cbrt 9 rcbrt 10 e_sat 11 pow.  tests/test_gpu_math.py */
+int ab_test_math(int op, const double *x, const double *y, double *out, long n);
+
 /* ---- the reference's own entry points --------------------------------------------------- */
 /* AEROBULK_MODEL (mod_aerobulk.f90:176-269) on a process-global session, with the reference's
  * call protocol: INIT at jt==1, BYE at jt==nt.  Non-reentrant exactly like the reference.

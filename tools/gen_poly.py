@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""tools/gen_poly.py — near-minimax polynomial coefficients for the device math in aerobulk_amd/csrc/ab_math.hpp.
+
+Chebyshev-node interpolation in 50-digit arithmetic (mpmath), coefficients rounded to double, maximum error of the
+ROUNDED polynomial re-measured on a dense grid.  Output: C initialiser lists to paste into ab_math.hpp.
+"""
+import mpmath as mp
+
+mp.mp.dps = 60
+
+
+def cheb_fit(f, a, b, deg):
+    n = deg + 1
+    xs = [(a + b) / 2 + (b - a) / 2 * mp.cos(mp.pi * (k + mp.mpf(1) / 2) / n) for k in range(n)]
+    A = mp.matrix(n, n)
+    y = mp.matrix(n, 1)
+    for i, x in enumerate(xs):
+        for j in range(n):
+            A[i, j] = x ** j
+        y[i] = f(x)
+    c = mp.lu_solve(A, y)
+    return [float(c[j]) for j in range(n)]
+
+
+def max_err(f, coef, a, b, npts=4001, rel=True):
+    worst = mp.mpf(0)
+    for k in range(npts):
+        x = a + (b - a) * mp.mpf(k) / (npts - 1)
+        p = mp.mpf(0)
+        for c in reversed(coef):
+            p = p * x + mp.mpf(c)
+        fx = f(x)
+        e = abs(p - fx)
+        if rel and fx != 0:
+            e = e / abs(fx)
+        worst = max(worst, e)
+    return float(worst)
+
+
+def show(name, coef):
+    print(f"// {name}")
+    print("{ " + ", ".join(f"{c!r}" for c in coef) + " }")
+
+
+ln2 = mp.log(2)
+# 1) exp(r) = 1 + r + r^2 * P(r),  |r| <= ln2/2
+fe = lambda r: (mp.exp(r) - 1 - r) / r ** 2 if abs(r) > mp.mpf(10) ** -15 else mp.mpf(1) / 2 + r / 6 + r * r / 24
+for deg in (7, 8, 9, 10):
+    c = cheb_fit(fe, -ln2 / 2, ln2 / 2, deg)
+    # error of the full exp
+    err = max_err(lambda r: mp.exp(r), [1.0, 1.0] + c, -ln2 / 2, ln2 / 2)
+    print("exp  deg", deg, "rel err of full exp", err)
+    show(f"EXP_P{deg}: exp(r) = 1 + r + r^2*P(r)", c)
+
+# 2) log(m) = 2 atanh(s), s=(m-1)/(m+1), |s| <= 0.17157288 ; 2 atanh(s) = 2s + s^3 * P(s^2)
+smax = (mp.sqrt(2) - 1) / (mp.sqrt(2) + 1)
+umax = smax ** 2
+fl = lambda u: (2 * mp.atanh(mp.sqrt(u)) / mp.sqrt(u) - 2) / u if u != 0 else mp.mpf(2) / 3
+for deg in (5, 6, 7):
+    c = cheb_fit(fl, mp.mpf(0), umax, deg)
+    # relative error of 2atanh(s)/s: (2 + u P(u)) vs exact
+    err = max_err(lambda u: 2 * mp.atanh(mp.sqrt(u)) / mp.sqrt(u) if u != 0 else mp.mpf(2), [2.0] + c, mp.mpf(0), umax)
+    print("log  deg", deg, "rel err of 2atanh(s)/s", err)
+    show(f"LOG_P{deg}: 2atanh(s) = 2s + s^3*P(s^2)", c)
+
+# 3) atan(t) = t + t^3 * P(t^2), |t| <= tan(pi/8)
+tmax = mp.tan(mp.pi / 8)
+fa = lambda u: (mp.atan(mp.sqrt(u)) / mp.sqrt(u) - 1) / u if u != 0 else -mp.mpf(1) / 3
+for deg in (8, 9, 10):
+    c = cheb_fit(fa, mp.mpf(0), tmax ** 2, deg)
+    err = max_err(lambda u: mp.atan(mp.sqrt(u)) / mp.sqrt(u) if u != 0 else mp.mpf(1), [1.0] + c, mp.mpf(0), tmax ** 2)
+    print("atan deg", deg, "rel err of atan(t)/t", err)
+    show(f"ATAN_P{deg}: atan(t) = t + t^3*P(t^2)", c)
+
+print("ln2_hi/lo etc.")
+for name, v in (("ln2", ln2), ("log2e", 1 / ln2), ("ln10", mp.log(10)), ("log2_10", mp.log(10) / ln2), ("log10_2", ln2 / mp.log(10)),
+                ("log10e", 1 / mp.log(10)), ("pi_2", mp.pi / 2), ("pi_4", mp.pi / 4)):
+    hi = float(v)
+    lo = float(v - mp.mpf(hi))
+    print(f"{name}: hi={hi!r} lo={lo!r}")
+# split ln2 with trailing zero bits so that k*ln2_hi is exact for |k| < 2^11
+import struct
+def trunc_bits(x, nbits):
+    b = struct.unpack("<Q", struct.pack("<d", x))[0]
+    b &= ~((1 << nbits) - 1)
+    return struct.unpack("<d", struct.pack("<Q", b))[0]
+for name, v in (("ln2", ln2), ("log10_2", ln2 / mp.log(10))):
+    hi = trunc_bits(float(v), 21)
+    lo = float(v - mp.mpf(hi))
+    print(f"{name} (hi with 21 trailing zero bits): hi={hi!r} lo={lo!r}")
