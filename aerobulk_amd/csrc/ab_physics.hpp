@@ -182,7 +182,6 @@ template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R 
     const R c0 = COARE ? R(0.137) : R(0.065);
     // invariants of the five delta evaluations
     const R zusw = vmax(pustar, R(1.E-4)) * K<R>::sq_radrw;
-    const R zusw2 = zusw * zusw;
     const R ziu = M::rcp(zusw);
     const R ziu2 = ziu * ziu;
     const R zA = palpha * K<R>::rcst_cs * (ziu2 * ziu2);
@@ -192,9 +191,9 @@ template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R 
     auto delta = [&](R pQd) -> R {
         const R zQd = pQd + zql;
         if (nonneg(zQd)) return zdwarm;                       // warming of the viscous layer (rare)
-        const R x = vmax(zA * zQd, R(0.));
-        const R sx = M::sqrt(x);
-        return R(6.) * M::rcbrt(R(1.) + sx * M::sqrt(sx)) * ztmp;  // 6 (1 + x^0.75)^(-1/3) nu/u*w
+        const R x = vmax(zA * zQd, R(1.E-280));                     // floor 0 -> tiny: 1 + x^0.75 is unchanged
+        const R sx = M::sqrt_pos(x);
+        return R(6.) * M::rcbrt(R(1.) + sx * M::sqrt_pos(sx)) * ztmp;  // 6 (1 + x^0.75)^(-1/3) nu/u*w
     };
     R zQabs = pQnsol;
     R zdelta = delta(zQabs);
@@ -245,7 +244,8 @@ __device__ __forceinline__ void wl_coare(R (&st)[4], const WlCoareCell<R> &c, R 
         ztac = st[3] + vmax(R(.002), pTau) * K<R>::rdt;                            // :199
 #pragma unroll 1
         for (int jl = 0; jl < 5; ++jl) {                                           // :204-211
-            zQabs = wl_absorb(zHwl) * pQsw + pQnsol;
+            // pass 0 re-evaluates the absorption at the same zHwl as the test above (:167-169): reuse it
+            if (jl > 0) zQabs = wl_absorb(zHwl) * pQsw + pQnsol;
             zqac = st[2] + zQabs * K<R>::rdt;
             if (zqac <= R(0.)) break;
             zHwl = vmax(vmin(Hwl_max, M::div(c.zcd1 * ztac, M::sqrt_pos(zqac))), R(0.1));
