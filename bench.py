@@ -43,7 +43,7 @@ def cpu_baseline(algo, skin, niter, zt, zu):
     bounded sample of the same synthetic workload; falls back to the C port if _ref did not travel."""
     import numpy as np
     from oracle import pyoracle as po
-    ni, nj = 1440, 720
+    ni, nj = 2160, 1440   # ~13 s of one-core reference work for the headline config
     f = po.synth_fields(ni, nj)
     rec = dict(sst=f["sst"], t_zt=f["t_zt"], hum_zt=f["hum_zt"], u_zu=f["u_zu"], v_zu=f["v_zu"], slp=f["slp"],
                rad_sw=f["rad_sw"] if skin else None, rad_lw=f["rad_lw"] if skin else None)
@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (kernel-only scaling)")
+    ap.add_argument("--chunks", type=int, default=4, help="N>1: row sub-blocks per rank (gather of one overlaps compute of the next)")
     a = ap.parse_args()
 
     import torch
@@ -98,30 +99,51 @@ def main():
     skin = (not a.no_skin) and a.algo in ("coare3p0", "coare3p6", "ecmwf")
     zt, zu = 2.0, 10.0
     j0, njl, per = shard_rows(nj, world, rank)
-    n_local, n_pad = ni * njl, ni * per
     esz = 8 if a.precision == "f64" else 4
     tdt = torch.float64 if a.precision == "f64" else torch.float32
+    n_local = ni * njl
 
-    # synthetic inputs generated straight into HBM, outputs packed [6, n_pad] for ONE gather
-    f = ab.synth_fields_device(ni, nj, j0, max(njl, 1), precision=a.precision, device=dev, with_rad=True)
+    # Each rank's j-block is cut into `chunks` row sub-blocks so that the RCCL gather of sub-block c overlaps the
+    # kernel of sub-block c+1 (N == 1: one chunk, no communication).
+    chunks = 1 if world == 1 else max(1, min(a.chunks, per))
+    cr = -(-per // chunks)                       # rows per chunk (padded, identical on every rank)
+    n_cpad = ni * cr
     nout = 6 if skin else 5
-    outbuf = torch.zeros((nout, n_pad), dtype=tdt, device=dev)
     names = ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")[:nout]
-    out = {k: outbuf[i, :max(n_local, 1)] for i, k in enumerate(names)}
-    gather_list = None
-    if world > 1 and rank == 0 and not a.no_gather:
-        gather_list = [torch.empty((nout, n_pad), dtype=tdt, device=dev) for _ in range(world)]
 
-    sess = ab.Session(a.algo, ni, max(njl, 1), 1, skin, precision=a.precision, device=local_rank)
-    sess.set_humidity("sh")
-    ins = [f[k] for k in IN6]
-    rs, rl = (f["rad_sw"], f["rad_lw"]) if skin else (None, None)
+    # synthetic inputs generated straight into HBM; outputs packed [chunk, field, cell] for ONE gather per chunk
+    f = ab.synth_fields_device(ni, nj, j0, max(njl, 1), precision=a.precision, device=dev, with_rad=True)
+    outbuf = torch.zeros((chunks, nout, n_cpad), dtype=tdt, device=dev)
+    gather_lists = None
+    if world > 1 and rank == 0 and not a.no_gather:
+        gather_lists = [[torch.empty((nout, n_cpad), dtype=tdt, device=dev) for _ in range(world)] for _ in range(chunks)]
+
+    work = []  # (session, inputs, rad, out) per non-empty chunk
+    for c in range(chunks):
+        r0 = min(c * cr, njl)
+        rows = max(min(cr, njl - r0), 0)
+        if rows == 0:
+            work.append(None)
+            continue
+        lo, hi = r0 * ni, (r0 + rows) * ni
+        sess = ab.Session(a.algo, ni, rows, 1, skin, precision=a.precision, device=local_rank)
+        sess.set_humidity("sh")
+        ins = [f[k][lo:hi] for k in IN6]
+        rad = (f["rad_sw"][lo:hi], f["rad_lw"][lo:hi]) if skin else (None, None)
+        out = {k: outbuf[c, i, :rows * ni] for i, k in enumerate(names)}
+        work.append((sess, ins, rad, out))
 
     def step():
-        if n_local > 0:
-            sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rs, rad_lw=rl, out=out, want_T_s=skin, check=False)
-        if world > 1 and not a.no_gather:
-            dist.gather(outbuf, gather_list, dst=0)
+        pending = []
+        for c in range(chunks):
+            w = work[c]
+            if w is not None:
+                sess, ins, rad, out = w
+                sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
+            if world > 1 and not a.no_gather:
+                pending.append(dist.gather(outbuf[c], gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
+        for p in pending:
+            p.wait()      # stream-level wait (does not block the host)
 
     def sync():
         torch.cuda.synchronize()
@@ -142,15 +164,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    sess.check()
+    for w in work:
+        if w is not None:
+            w[0].check()
 
-    # per-launch kernel duration: HIP events recorded by the library around the launch, on the launch stream.
+    # per-launch kernel duration: HIP events recorded by the library around each launch, on the launch stream.
     # Reading an event pair synchronises, so this is a separate pass over the same inputs (not in `elapsed`).
     kdur = []
     for _ in range(min(a.steps, 10)):
-        if n_local > 0:
-            sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rs, rad_lw=rl, out=out, want_T_s=skin, check=False)
-            kdur.append(sess.last_kernel_ms())
+        tot = 0.0
+        for w in work:
+            if w is not None:
+                sess, ins, rad, out = w
+                sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
+                tot += sess.last_kernel_ms()
+        kdur.append(tot)
     k_ms = sum(kdur) / max(len(kdur), 1)
 
     if rank == 0:
@@ -168,7 +196,8 @@ def main():
             "config": {"workload": f"{a.algo}{' + cool-skin/warm-layer' if skin else ''}, {ni}x{nj} grid, nb_iter={a.niter}, "
                                    f"zt=2 zu=10, one time record (jt=1=Nt), inputs/outputs resident in HBM",
                        "grid": [ni, nj], "algo": a.algo, "skin": skin, "nb_iter": a.niter,
-                       "sharding": f"j-block x{world}" + ("" if world == 1 or a.no_gather else " + RCCL gather of outputs to rank 0")},
+                       "sharding": f"j-block x{world}" + ("" if world == 1 or a.no_gather else
+                                                            f" + RCCL gather of outputs to rank 0, {chunks} overlapped row chunks per rank")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel": f"flux_kernel<{a.precision},{a.algo},{'skin' if skin else 'noskin'}>",
@@ -181,7 +210,9 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"value": None, "unit": "Mcell/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)
-    sess.close()
+    for w in work:
+        if w is not None:
+            w[0].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
