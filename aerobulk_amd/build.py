@@ -17,8 +17,10 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libaerobulk_amd.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"
+# -disable-machine-licm: keep the s_mov of polynomial coefficients next to their use.  Hoisted out of the iteration loop
+# they exhaust the 102 SGPRs and come back as v_readlane/v_mov_b64 VALU traffic (-13 % VALU instructions, profiles/r1_notes.md)
 HIPFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-disable-machine-licm"]
 
 
 def _newer(target, sources):

@@ -33,6 +33,19 @@ namespace fm {
 AB_FM double p_rcp(double x) { return __builtin_amdgcn_rcp(x); }      // v_rcp_f64, ~2^-23 relative
 AB_FM double p_rsq(double x) { return __builtin_amdgcn_rsq(x); }      // v_rsq_f64
 AB_FM double p_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// Horner step a*b + C with a compile-time coefficient C: forced to the 3-address VOP3 form with the coefficient in an
+// SGPR pair (2 SALU s_mov).  Left to itself hipcc selects the tied v_fmac_f64 and pays a v_mov_b64 (VALU) per step to
+// put the coefficient into the accumulator register (measured: 10 % of the VALU instructions of the iteration loop).
+AB_FM double p_fmac(double a, double b, double c)
+{
+#ifdef AB_NO_ASM_FMA
+    return __builtin_fma(a, b, c);
+#else
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#endif
+}
 AB_FM double p_mant(double x) { return __builtin_amdgcn_frexp_mant(x); }  // in [0.5,1)
 AB_FM int p_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
 AB_FM double p_ldexp(double x, int e) { return __builtin_amdgcn_ldexp(x, e); }
@@ -45,6 +58,7 @@ AB_FM double p_copysign(double a, double b) { return __builtin_copysign(a, b); }
 AB_FM double p_rcp(double x) { return (1.0 / x) * (1.0 + 1.2e-7); }   // deliberately float-grade (2^-23)
 AB_FM double p_rsq(double x) { return (1.0 / std::sqrt(x)) * (1.0 - 1.2e-7); }
 AB_FM double p_fma(double a, double b, double c) { return std::fma(a, b, c); }
+AB_FM double p_fmac(double a, double b, double c) { return std::fma(a, b, c); }
 AB_FM double p_mant(double x) { int e; return std::frexp(x, &e); }
 AB_FM int p_exp(double x) { int e; (void)std::frexp(x, &e); return e; }
 AB_FM double p_ldexp(double x, int e) { return std::ldexp(x, e); }
@@ -54,6 +68,22 @@ AB_FM float p_exp2f(float x) { return std::exp2(x) * (1.0f - 1e-7f); }
 AB_FM double p_abs(double x) { return std::fabs(x); }
 AB_FM double p_copysign(double a, double b) { return std::copysign(a, b); }
 #endif
+
+// Polynomial coefficient tables.  On the device they live in constant memory and are fetched with wide scalar loads
+// (s_load_dwordx8/x16: one SMEM instruction per 4-8 coefficients) instead of two s_mov_b32 per coefficient.
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST) && !defined(AB_NO_CONST_TABLES)
+#define AB_TAB __constant__
+#else
+#define AB_TAB static const
+#endif
+AB_TAB double kLogP[7] = {0.666666666666667, 0.39999999999899505, 0.28571428625975487, 0.2222221113479508,
+                          0.18182889125261723, 0.15331721600556042, 0.14616449685043406};
+AB_TAB double kExpP[10] = {0.5000000000000001, 0.16666666666666669, 0.041666666666624164, 0.008333333333330065,
+                           0.0013888888917196719, 0.00019841269863040545, 2.4801521322368692e-05,
+                           2.7557268480310024e-06, 2.7620075879983367e-07, 2.5100375832561234e-08};
+AB_TAB double kAtanP[11] = {-0.3333333333333333, 0.1999999999999552, -0.14285714284666542, 0.11111111015256361,
+                            -0.09090904578123903, 0.07692183190826087, -0.06664511447381948, 0.0585814891280221,
+                            -0.0508544973794026, 0.03923165829558719, -0.01917688711906226};
 
 // ---------------------------------------------------------------- division, reciprocal, square root
 // a/b: rcp seed, one Newton step on the reciprocal (2^-46), one residual correction of the quotient.
@@ -95,13 +125,9 @@ AB_FM double qlog(double x)
     const double f = m - 1.0;
     const double s = qdiv(f, 2.0 + f);
     const double u = s * s;
-    double p = 0.14616449685043406;
-    p = p_fma(p, u, 0.15331721600556042);
-    p = p_fma(p, u, 0.18182889125261723);
-    p = p_fma(p, u, 0.2222221113479508);
-    p = p_fma(p, u, 0.28571428625975487);
-    p = p_fma(p, u, 0.39999999999899505);
-    p = p_fma(p, u, 0.666666666666667);
+    double p = kLogP[6];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) p = p_fmac(p, u, kLogP[i]);
     const double ef = (double)e;
     const double t = p_fma(s * u, p, ef * 2.3190468138462996e-17);  // s^3 P + e ln2_lo
     return p_fma(ef, 0.6931471805599453, (s + s) + t);
@@ -112,16 +138,9 @@ AB_FM double qlog10(double x) { return qlog(x) * 0.4342944819032518; }
 // exp(r) = 1 + r + r^2 P(r) on |r| <= ln2/2, P degree 9 (truncation 1.6e-17 relative)
 AB_FM double exp_kernel(double r)
 {
-    double p = 2.5100375832561234e-08;
-    p = p_fma(p, r, 2.7620075879983367e-07);
-    p = p_fma(p, r, 2.7557268480310024e-06);
-    p = p_fma(p, r, 2.4801521322368692e-05);
-    p = p_fma(p, r, 0.00019841269863040545);
-    p = p_fma(p, r, 0.0013888888917196719);
-    p = p_fma(p, r, 0.008333333333330065);
-    p = p_fma(p, r, 0.041666666666624164);
-    p = p_fma(p, r, 0.16666666666666669);
-    p = p_fma(p, r, 0.5000000000000001);
+    double p = kExpP[9];
+#pragma unroll
+    for (int i = 8; i >= 0; --i) p = p_fmac(p, r, kExpP[i]);
     return 1.0 + p_fma(r * r, p, r);
 }
 // exp(x), any finite x (saturates to 0 / inf through ldexp)
@@ -154,17 +173,9 @@ AB_FM double qatan(double x)
     const double blo = big ? 6.123233995736766e-17 : (mid ? 3.061616997868383e-17 : 0.0);
     const double t = qdiv(num, den);
     const double u = t * t;
-    double p = -0.01917688711906226;
-    p = p_fma(p, u, 0.03923165829558719);
-    p = p_fma(p, u, -0.0508544973794026);
-    p = p_fma(p, u, 0.0585814891280221);
-    p = p_fma(p, u, -0.06664511447381948);
-    p = p_fma(p, u, 0.07692183190826087);
-    p = p_fma(p, u, -0.09090904578123903);
-    p = p_fma(p, u, 0.11111111015256361);
-    p = p_fma(p, u, -0.14285714284666542);
-    p = p_fma(p, u, 0.1999999999999552);
-    p = p_fma(p, u, -0.3333333333333333);
+    double p = kAtanP[10];
+#pragma unroll
+    for (int i = 9; i >= 0; --i) p = p_fmac(p, u, kAtanP[i]);
     const double r = bhi + (p_fma(t * u, p, blo) + t);
     return p_copysign(r, x);
 }
