@@ -56,16 +56,47 @@ template <class R> struct K {  // constants, mod_const.f90:38-114
 };
 
 // ---------------------------------------------------------------- thermodynamics (mod_phymbl.f90)
-// e_sat_sclr :777-800 — Goff (1957), T floored at 180 K
+// e_sat_sclr :777-800 — Goff (1957), T floored at 180 K:
+//   e_s = 100 * 10^A(T),  A = 10.79574(1-T0/T) - 5.028 log10(T/T0) + 1.50475e-4 (1 - 10^(-8.2969(T/T0-1)))
+//                             + 0.42873e-3 (10^(4.76955(1-T0/T)) - 1) + 0.78614
+// The formula is evaluated 13x per cell in the skin configuration (3 exp10 + log10 + a division each time), always at
+// sea-surface-like temperatures.  On 265 K <= T <= 312 K the exponent A(T) is therefore taken from its degree-14
+// near-minimax polynomial in x = (T-288.5)/23.5 (60-digit Chebyshev fit of the formula above, tools/gen_poly.py;
+// |dA| <= 9.2e-17, i.e. below the rounding of the direct evaluation); outside that range (polar air, masked cells)
+// the formula itself is evaluated.
+__constant__ double kGoffA[15] = {1.2415921763001385, 0.6554537644583072, -0.06042150514551698, 0.0052061867921480934,
+                                  -0.0004389902243182716, 4.0181440214509234e-05, -4.299303765658193e-06,
+                                  5.668664093041563e-07, -8.717077199072555e-08, 1.3977187155429886e-08,
+                                  -2.167668513463531e-09, 3.147964597951566e-10, -4.254827005592513e-11,
+                                  5.6079820609247194e-12, -6.519141017660851e-13};
+__device__ __forceinline__ double goff_poly(double x)
+{
+    double p = kGoffA[14];
+#pragma unroll
+    for (int i = 13; i >= 0; --i) p = fm::p_fmac(p, x, kGoffA[i]);
+    return p;
+}
+__device__ __forceinline__ float goff_poly(float x)
+{
+    float p = (float)kGoffA[8];   // fp32: the first 9 terms leave < 2e-8 in A
+#pragma unroll
+    for (int i = 7; i >= 0; --i) p = __builtin_fmaf(p, x, (float)kGoffA[i]);
+    return p;
+}
 template <class R> __device__ __forceinline__ R e_sat(R pTa)
 {
     using M = Mth<R>;
     const R zta = vmax(pTa, R(180.));
-    const R ztmp = M::div(K<R>::rt0, zta);
-    const R zx = zta * R(1. / 273.15);
-    const R e = R(10.79574) * (R(1.) - ztmp) - R(5.028) * M::log10(zx)
-                + R(1.50475E-4) * (R(1.) - M::exp10(R(-8.2969) * (zx - R(1.))))
-                + R(0.42873E-3) * (M::exp10(R(4.76955) * (R(1.) - ztmp)) - R(1.)) + R(0.78614);
+    R e;
+    if ((zta >= R(265.)) && (zta <= R(312.))) {
+        e = goff_poly((zta - R(288.5)) * R(1. / 23.5));
+    } else {
+        const R ztmp = M::div(K<R>::rt0, zta);
+        const R zx = zta * R(1. / 273.15);
+        e = R(10.79574) * (R(1.) - ztmp) - R(5.028) * M::log10(zx)
+            + R(1.50475E-4) * (R(1.) - M::exp10(R(-8.2969) * (zx - R(1.))))
+            + R(0.42873E-3) * (M::exp10(R(4.76955) * (R(1.) - ztmp)) - R(1.)) + R(0.78614);
+    }
     return R(100.) * M::exp10(e);
 }
 // q_sat_sclr :881-904

@@ -79,6 +79,7 @@ def test_e_sat_matches_oracle(oracle):
     t = RNG.uniform(170.0, 330.0, 200000)
     got = run("e_sat", t)
     want = np.array([oracle.lib().abo_e_sat(v) for v in t])
-    rel = np.max(np.abs(got - want) / want)
-    print("e_sat max rel err vs oracle", rel)
-    assert rel < 5e-15
+    rel = np.abs(got - want) / want
+    print("e_sat max rel err vs oracle", rel.max(), "at T =", t[np.argmax(rel)])
+    # both sides carry ~1e-15 of rounding in the exponent (A ~ 0.3..2, times ln 10)
+    assert rel.max() < 6e-15

@@ -88,3 +88,21 @@ for name, v in (("ln2", ln2), ("log10_2", ln2 / mp.log(10))):
     hi = trunc_bits(float(v), 21)
     lo = float(v - mp.mpf(hi))
     print(f"{name} (hi with 21 trailing zero bits): hi={hi!r} lo={lo!r}")
+
+# 4) Goff (1957) exponent A(T) of e_sat = 100*10^A(T) (reference: src/mod_phymbl.f90:792-798) on T in [265, 312] K,
+#    x = (T - 288.5)/23.5 in [-1, 1]: polynomial surrogate of the SAME analytic function (3 exp10 + log10 + division -> 14 FMAs)
+T0 = mp.mpf("273.15")
+
+
+def goff_A(T):
+    z, x = T0 / T, T / T0
+    return (mp.mpf("10.79574") * (1 - z) - mp.mpf("5.028") * mp.log10(x)
+            + mp.mpf("1.50475e-4") * (1 - mp.power(10, mp.mpf("-8.2969") * (x - 1)))
+            + mp.mpf("0.42873e-3") * (mp.power(10, mp.mpf("4.76955") * (1 - z)) - 1) + mp.mpf("0.78614"))
+
+
+for deg in (13, 14, 15):
+    c = cheb_fit(lambda x: goff_A(mp.mpf("288.5") + mp.mpf("23.5") * x), mp.mpf(-1), mp.mpf(1), deg)
+    err = max_err(lambda x: goff_A(mp.mpf("288.5") + mp.mpf("23.5") * x), c, mp.mpf(-1), mp.mpf(1), rel=False)
+    print("goff deg", deg, "abs err of A(T)", err)
+    show(f"GOFF_A{deg}: A(T), x=(T-288.5)/23.5", c)
