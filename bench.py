@@ -31,6 +31,20 @@ def algorithmic_bytes_per_cell(skin, esz):
     return (8 + 6) * esz if skin else (6 + 5) * esz
 
 
+def committed_pmc(algo, skin, ni, nj, niter, precision):
+    """PMC figures of the committed rocprofv3 run for exactly this workload (profiles/r1_pmc.json), or None.
+    bench.py cannot collect hardware counters itself; the numbers are measured by tools/prof_quick.sh on the same command."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as fh:
+            p = json.load(fh)
+        c = p["config"]
+        if (c["algo"], c["skin"], list(c["grid"]), c["nb_iter"], c["precision"]) == (algo, skin, [ni, nj], niter, precision):
+            return p
+    except Exception:
+        pass
+    return None
+
+
 def shard_rows(nj, world, rank):
     """Contiguous j-blocks: every rank owns ceil(nj/world) rows except possibly the last ones."""
     per = -(-nj // world)
@@ -187,6 +201,7 @@ def main():
         value = cells * a.steps / elapsed / 1e6
         bpc = algorithmic_bytes_per_cell(skin, esz)
         achieved = bpc * n_local / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        pmc = committed_pmc(a.algo, skin, ni, nj, a.niter, a.precision) if world == 1 else None
         res = {
             "metric": "Mcell/s COARE3p6+cool-skin on 4320x3600 grid" if (a.algo == "coare3p6" and skin and (ni, nj) == (4320, 3600))
                       else f"Mcell/s {a.algo}{'+skin' if skin else ''} on {ni}x{nj} grid",
@@ -199,10 +214,15 @@ def main():
                        "sharding": f"j-block x{world}" + ("" if world == 1 or a.no_gather else
                                                             f" + RCCL gather of outputs to rank 0, {chunks} overlapped row chunks per rank")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None,
                          "kernel": f"flux_kernel<{a.precision},{a.algo},{'skin' if skin else 'noskin'}>",
                          "kernel_ms": round(k_ms, 4), "bytes_per_cell": bpc, "cells_per_launch": n_local,
-                         "note": "kernel is fp64-VALU-bound (hundreds of transcendentals per cell), not HBM-bound: see DESIGN.md"},
+                         "binding_resource": "fp64 VALU issue" if a.precision == "f64" else "fp32 VALU issue",
+                         "valu_busy": round(pmc["valu_busy"], 3) if pmc else None,
+                         "valu_insts_per_cell": round(pmc["valu_insts_per_cell"]) if pmc else None,
+                         "note": "the kernel is VALU-bound (hundreds of fp64 transcendentals per cell), not HBM-bound; traffic/valu_* are "
+                                 "rocprofv3 PMC figures of the committed profile of this same command (profiles/), DESIGN.md §3.1"},
         }
         if not a.no_cpu_baseline and world == 1:
             try:
