@@ -89,6 +89,11 @@ def main():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (kernel-only scaling)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1 collective backend; gloo (outputs staged through host memory) exists only so that the sharded "
+                         "path can be exercised on a box with fewer GPUs than ranks")
+    ap.add_argument("--verify", action="store_true", help="N>1: rank 0 recomputes the whole grid alone and checks the gathered "
+                                                        "fields are bit-identical (outside the timed region)")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row sub-blocks per rank (gather of one overlaps compute of the next)")
     a = ap.parse_args()
 
@@ -101,13 +106,18 @@ def main():
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ngpu = torch.cuda.device_count()
+    dev_index = local_rank if a.backend == "nccl" else local_rank % max(ngpu, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     ni, nj = (int(x) for x in a.grid.lower().split("x"))
     skin = (not a.no_skin) and a.algo in ("coare3p0", "coare3p6", "ecmwf")
@@ -140,7 +150,7 @@ def main():
             work.append(None)
             continue
         lo, hi = r0 * ni, (r0 + rows) * ni
-        sess = ab.Session(a.algo, ni, rows, 1, skin, precision=a.precision, device=local_rank)
+        sess = ab.Session(a.algo, ni, rows, 1, skin, precision=a.precision, device=dev_index)
         sess.set_humidity("sh")
         ins = [f[k][lo:hi] for k in IN6]
         rad = (f["rad_sw"][lo:hi], f["rad_lw"][lo:hi]) if skin else (None, None)
@@ -155,7 +165,15 @@ def main():
                 sess, ins, rad, out = w
                 sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
             if world > 1 and not a.no_gather:
-                pending.append(dist.gather(outbuf[c], gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
+                if a.backend == "nccl":
+                    pending.append(dist.gather(outbuf[c], gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
+                else:  # test-only path: gloo gathers host tensors
+                    host = outbuf[c].cpu()
+                    gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                    dist.gather(host, gl, dst=0)
+                    if rank == 0:
+                        for r in range(world):
+                            gather_lists[c][r].copy_(gl[r])
         for p in pending:
             p.wait()      # stream-level wait (does not block the host)
 
@@ -164,6 +182,18 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def assemble():
+        """rank 0: global fields [nout, ni*nj] from the gathered chunk buffers (rank-major j-blocks, chunk-major inside)."""
+        glob = torch.empty((nout, ni * nj), dtype=tdt, device=dev)
+        for r in range(world):
+            rj0, rnjl, _ = shard_rows(nj, world, r)
+            for c in range(chunks):
+                r0 = min(c * cr, rnjl)
+                rows = max(min(cr, rnjl - r0), 0)
+                if rows:
+                    glob[:, (rj0 + r0) * ni:(rj0 + r0 + rows) * ni] = gather_lists[c][r][:, :rows * ni]
+        return glob
 
     for _ in range(a.warmup):
         step()
@@ -195,6 +225,19 @@ def main():
         kdur.append(tot)
     k_ms = sum(kdur) / max(len(kdur), 1)
 
+    verify_msg = None
+    if a.verify and world > 1 and not a.no_gather and rank == 0:
+        glob = assemble()
+        ff = ab.synth_fields_device(ni, nj, precision=a.precision, device=dev, with_rad=True)
+        with ab.Session(a.algo, ni, nj, 1, skin, precision=a.precision, device=dev_index) as s1:
+            s1.set_humidity("sh")
+            one = s1.compute(1, zt, zu, *[ff[k] for k in IN6], Niter=a.niter, rad_sw=ff["rad_sw"] if skin else None,
+                             rad_lw=ff["rad_lw"] if skin else None, want_T_s=skin)
+        bad = [k for i, k in enumerate(names) if not torch.equal(glob[i], one[k])]
+        verify_msg = "gathered == single-GPU (bit-identical)" if not bad else f"MISMATCH in {bad}"
+        if bad:
+            raise SystemExit("verify failed: " + verify_msg)
+
     if rank == 0:
         cells = ni * nj
         ms_per_step = elapsed / a.steps * 1e3
@@ -224,6 +267,8 @@ def main():
                          "note": "the kernel is VALU-bound (hundreds of fp64 transcendentals per cell), not HBM-bound; traffic/valu_* are "
                                  "rocprofv3 PMC figures of the committed profile of this same command (profiles/), DESIGN.md §3.1"},
         }
+        if verify_msg:
+            res["verify"] = verify_msg
         if not a.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(a.algo, skin, a.niter, zt, zu)

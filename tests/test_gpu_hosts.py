@@ -142,3 +142,22 @@ def test_init_checks_on_gpu_match_reference_conditions(oracle):
     lw = f["rad_lw"].copy(); lw[:4] = 5000.0
     with ab.Session("coare3p6", n, 1, 1, True) as s:
         assert s.init(*base, rad_sw=lw, rad_lw=lw)["n_masked"] == 4
+
+
+def test_bench_sharded_path_two_ranks_one_gpu():
+    """bench.py's N>1 path (j-block sharding, row chunks, packed gather, reassembly) run as 2 ranks that share the one
+    visible GPU, with the gloo backend standing in for RCCL (RCCL refuses two ranks per device).  --verify makes rank 0
+    recompute the whole grid alone and demand bit-identical gathered fields."""
+    import sys
+    import torch
+    if torch.cuda.device_count() < 1:
+        pytest.skip("no GPU")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--grid", "720x333", "--backend", "gloo", "--verify", "--chunks", "3", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["verify"].startswith("gathered == single-GPU")
+    assert res["scaling"] == "strong" and res["value"] > 0
