@@ -83,6 +83,21 @@ __device__ __forceinline__ float goff_poly(float x)
     for (int i = 7; i >= 0; --i) p = __builtin_fmaf(p, x, (float)kGoffA[i]);
     return p;
 }
+// Horner evaluation of a constant-memory coefficient table (coefficients fetched with scalar loads)
+template <int N> __device__ __forceinline__ double horner_tab(const double (&tab)[N], double x)
+{
+    double p = tab[N - 1];
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) p = fm::p_fmac(p, x, tab[i]);
+    return p;
+}
+template <int N> __device__ __forceinline__ float horner_tab(const double (&tab)[N], float x)
+{
+    float p = (float)tab[N - 1];
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) p = __builtin_fmaf(p, x, (float)tab[i]);
+    return p;
+}
 template <class R> __device__ __forceinline__ R e_sat(R pTa)
 {
     using M = Mth<R>;
@@ -351,6 +366,25 @@ template <class R> __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, R 
 }
 
 // ---------------------------------------------------------------- COARE stability functions (mod_common_coare.f90)
+// Convective ("free convection") profile function of COARE, mod_common_coare.f90:240-243 (psi_m) and :330-333 (psi_h):
+//    c = y**.3333 ,  psi_c = 1.5 LOG((1+c+c*c)/3) - 1.7320508 ATAN((1+2c)/1.7320508) + 1.813799447     (y = |1 - a zeta| >= 1)
+// With L = LOG(y) (needed anyway for the .3333 power) and w = 1/c = EXP(-.3333 L) in (0,1]:
+//    psi_c = 3 LOG(c) + G(w) = .9999 L + G(w),   G(w) = 1.5 LOG((w*w+w+1)/3) - 1.7320508 (pi/2 - ATAN(1.7320508 w/(w+2))) + 1.813799447
+// G is analytic on [0,1]; it is evaluated by its degree-20 near-minimax polynomial in x = 2w-1 (tools/gen_poly.py, fitted
+// to the reference's formula WITH its truncated literals; |dG| <= 3.2e-16) instead of a second log and an atan.
+__constant__ double kPsicG[21] = {-1.1378018661248832, 1.2857142823699836, -0.15306122324762675, -0.0029154522038313062,
+                                  0.012182424010797529, -0.005319212199747766, 0.001372727329966169, -0.00012957955060170255,
+                                  -8.228815772429666e-05, 5.619522847612674e-05, -1.9496010425207854e-05, 3.5584071875334317e-06,
+                                  4.569112576860545e-07, -6.688538104698402e-07, 2.9920447417445153e-07, -7.973350238907205e-08,
+                                  4.974190761282226e-09, 9.732585524385644e-09, -5.605322344298673e-09, 7.426603654517993e-10,
+                                  1.903681291004176e-10};
+template <class R> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
+{
+    using M = Mth<R>;
+    const R L = M::log(y);
+    const R w = M::exp(R(-.3333) * L);
+    return R(.9999) * L + horner_tab(kPsicG, R(2.) * w - R(1.));
+}
 // psi_m_coare_sclr :217-254 and psi_h_coare_sclr :305-344 at the same zeta
 template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
 {
@@ -371,17 +405,13 @@ template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
             const R x = M::sqrt_pos(x2);
             const R hx = R(0.5) * (R(1.) + x);
             const R psik = M::log(hx * hx * (R(0.5) * (R(1.) + x2))) - R(2.) * M::atan(x) + R(0.5) * K<R>::rpi;
-            const R c = pow_pos(M::abs(R(1.) - R(10.15) * z), R(.3333));
-            const R psic = R(1.5) * M::log((R(1.) + c + c * c) * R(1. / 3.))
-                           - R(1.7320508) * M::atan((R(1.) + R(2.) * c) * R(1. / 1.7320508)) + R(1.813799447);
+            const R psic = psic_coare(M::abs(R(1.) - R(10.15) * z));
             *pm = (R(1.) - zf) * psik + zf * psic;
         }
         if (ph) {
             const R x2 = M::sqrt_pos(M::abs(R(1.) - R(15.) * z));
             const R psik = R(2.) * M::log(R(0.5) * (R(1.) + x2));
-            const R c = pow_pos(M::abs(R(1.) - R(34.15) * z), R(.3333));
-            const R psic = R(1.5) * M::log((R(1.) + c + c * c) * R(1. / 3.))
-                           - R(1.7320508) * M::atan((R(1.) + R(2.) * c) * R(1. / 1.7320508)) + R(1.813799447);
+            const R psic = psic_coare(M::abs(R(1.) - R(34.15) * z));
             *ph = (R(1.) - zf) * psik + zf * psic;
         }
     }

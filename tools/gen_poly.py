@@ -106,3 +106,16 @@ for deg in (13, 14, 15):
     err = max_err(lambda x: goff_A(mp.mpf("288.5") + mp.mpf("23.5") * x), c, mp.mpf(-1), mp.mpf(1), rel=False)
     print("goff deg", deg, "abs err of A(T)", err)
     show(f"GOFF_A{deg}: A(T), x=(T-288.5)/23.5", c)
+
+# 5) COARE convective psi (reference: src/mod_common_coare.f90:240-243,330-333), with the reference's own truncated
+#    literals 1.7320508 and 1.813799447:
+#      psi_c(c) = 1.5 ln((1+c+c^2)/3) - 1.7320508 atan((1+2c)/1.7320508) + 1.813799447,  c = y^.3333 >= 1
+#    = 3 ln c + G(w), w = 1/c in (0,1]:  G(w) = 1.5 ln((w^2+w+1)/3) - S (pi/2 - atan(S w/(w+2))) + 1.813799447
+S3 = mp.mpf("1.7320508")
+G = lambda w: mp.mpf("1.5") * mp.log((w * w + w + 1) / 3) - S3 * (mp.pi / 2 - mp.atan(S3 * w / (w + 2))) + mp.mpf("1.813799447")
+for deg in (18, 20, 22, 24):
+    c = cheb_fit(lambda x: G((x + 1) / 2), mp.mpf(-1), mp.mpf(1), deg)
+    err = max_err(lambda x: G((x + 1) / 2), c, mp.mpf(-1), mp.mpf(1), rel=False)
+    print("psic G deg", deg, "abs err", err)
+    if deg in (20, 22):
+        show(f"PSIC_G{deg}: G(w), x = 2w-1", c)
