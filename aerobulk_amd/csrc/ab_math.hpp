@@ -35,22 +35,39 @@ template <> struct Mth<double> {
     static __device__ __forceinline__ R copysign(R a, R b) { return __builtin_copysign(a, b); }
 };
 
+// fp32 (config 5: tolerance restated at ~1e-4): hardware transcendentals (v_log_f32, v_exp_f32, v_rcp_f32, v_rsq_f32,
+// v_sqrt_f32, all ~1 ulp) and nothing else — no IEEE division/sqrt fix-up sequences, no library cbrt/atan.
 template <> struct Mth<float> {
     using R = float;
-    static __device__ __forceinline__ R log(R x) { return ::__logf(x); }
-    static __device__ __forceinline__ R log10(R x) { return ::__log10f(x); }
-    static __device__ __forceinline__ R exp(R x) { return ::__expf(x); }
-    static __device__ __forceinline__ R exp10(R x) { return ::__exp10f(x); }
-    static __device__ __forceinline__ R atan(R x) { return ::atanf(x); }
-    static __device__ __forceinline__ R sqrt(R x) { return ::__fsqrt_rn(x); }
-    static __device__ __forceinline__ R sqrt_pos(R x) { return ::__fsqrt_rn(x); }
-    static __device__ __forceinline__ R cbrt(R x) { return ::cbrtf(x); }
-    static __device__ __forceinline__ R rcbrt(R x) { return ::rcbrtf(x); }
-    static __device__ __forceinline__ R div(R a, R b) { return a / b; }
-    static __device__ __forceinline__ R rcp(R b) { return R(1.) / b; }
-    static __device__ __forceinline__ R abs(R x) { return ::fabsf(x); }
-    static __device__ __forceinline__ R floor(R x) { return ::floorf(x); }
-    static __device__ __forceinline__ R copysign(R a, R b) { return ::copysignf(a, b); }
+    static __device__ __forceinline__ R log2(R x) { return __builtin_amdgcn_logf(x); }
+    static __device__ __forceinline__ R exp2(R x) { return __builtin_amdgcn_exp2f(x); }
+    static __device__ __forceinline__ R log(R x) { return log2(x) * 0.6931471805599453f; }
+    static __device__ __forceinline__ R log10(R x) { return log2(x) * 0.3010299956639812f; }
+    static __device__ __forceinline__ R exp(R x) { return exp2(x * 1.4426950408889634f); }
+    static __device__ __forceinline__ R exp10(R x) { return exp2(x * 3.321928094887362f); }
+    static __device__ __forceinline__ R rcp(R b) { return __builtin_amdgcn_rcpf(b); }
+    static __device__ __forceinline__ R div(R a, R b) { return a * __builtin_amdgcn_rcpf(b); }
+    static __device__ __forceinline__ R sqrt(R x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ R sqrt_pos(R x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ R cbrt(R x) { return x > 0.f ? exp2(log2(x) * 0.33333334f) : 0.f; }
+    static __device__ __forceinline__ R rcbrt(R x) { return exp2(log2(x) * -0.33333334f); }
+    static __device__ __forceinline__ R abs(R x) { return __builtin_fabsf(x); }
+    static __device__ __forceinline__ R floor(R x) { return __builtin_floorf(x); }
+    static __device__ __forceinline__ R copysign(R a, R b) { return __builtin_copysignf(a, b); }
+    // atan: same argument reduction as the fp64 version, odd polynomial of degree 9 on |t| <= tan(pi/8) (|err| < 3e-8)
+    static __device__ __forceinline__ R atan(R x)
+    {
+        const R ax = abs(x);
+        const bool big = ax > 2.4142135f, mid = ax > 0.41421357f;
+        const R t = (big ? -1.f : (mid ? ax - 1.f : ax)) * rcp(big ? ax : (mid ? ax + 1.f : 1.f));
+        const R u = t * t;
+        R p = 0.0805374449538f;
+        p = __builtin_fmaf(p, u, -0.138776856032f);
+        p = __builtin_fmaf(p, u, 0.199777106478f);
+        p = __builtin_fmaf(p, u, -0.333329491539f);
+        const R r = (big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.f)) + __builtin_fmaf(t * u, p, t);
+        return copysign(r, x);
+    }
 };
 
 // x**y for x > 0 (returns 0 for x == 0 and y > 0, like pow)
