@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -56,7 +58,8 @@ struct ab_session {
     double *d_partials = nullptr;
     void *stage_in[8] = {nullptr};    // device staging for AB_MEM_HOST callers
     void *stage_out[6] = {nullptr};
-    hipStream_t stream = nullptr;     // session stream for host-mem calls
+    hipStream_t stream = nullptr;     // session stream for host-mem calls (kernels)
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;  // copy streams of the pipelined host path
     hipStream_t last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -126,6 +129,8 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     chk(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    chk(hipStreamCreateWithFlags(&s->s_h2d, hipStreamNonBlocking));
+    chk(hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking));
     chk(hipEventCreate(&s->ev0));
     chk(hipEventCreate(&s->ev1));
     chk(hipMalloc((void **)&s->d_flags, sizeof(int)));
@@ -157,6 +162,8 @@ int ab_session_destroy(ab_session *s)
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->s_h2d) (void)hipStreamDestroy(s->s_h2d);
+    if (s->s_d2h) (void)hipStreamDestroy(s->s_d2h);
     delete s;
     return AB_OK;
 }
@@ -180,6 +187,79 @@ int stage_inputs(ab_session *s, const void *const host[8], const void *dev[8])
 }
 
 struct FieldStat { double sum, mn, mx; };
+
+// Host calling convention for large grids: the record is cut into cell chunks and pipelined over three streams —
+// H2D of chunk c+1 (this thread), kernel of chunk c, D2H of chunk c-1 (helper thread) — so that both PCIe directions
+// and the kernel overlap.  `c` holds DEVICE staging pointers for the whole record; host_in/host_out are the caller's arrays.
+constexpr long kPipeChunk = 1L << 20;        // cells per chunk (8 MiB per fp64 field)
+constexpr long kPipeThreshold = 4L << 20;    // below this the plain path is as fast
+
+hipError_t compute_host_pipelined(ab_session *s, const ab::FluxCall &c, const void *const host_in[8], void *const host_out[6])
+{
+    const long n = s->n;
+    const int nch = (int)((n + kPipeChunk - 1) / kPipeChunk);
+    const size_t esz = s->esz;
+    const void *din[8] = {c.sst, c.t_zt, c.hum, c.u, c.v, c.slp, c.rad_sw, c.rad_lw};
+    void *dout[6] = {c.ql, c.qh, c.tau_x, c.tau_y, c.evap, c.t_s};
+    std::vector<hipEvent_t> kdone(nch, nullptr), h2d(nch, nullptr);
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < nch && err == hipSuccess; ++i) {
+        err = hipEventCreateWithFlags(&kdone[i], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&h2d[i], hipEventDisableTiming);
+    }
+    std::atomic<int> launched{0};
+    std::atomic<int> abort_flag{0};
+    hipError_t err_d2h = hipSuccess;
+    std::thread drain([&] {
+        if (hipSetDevice(s->device) != hipSuccess) { err_d2h = hipErrorInvalidDevice; return; }
+        for (int i = 0; i < nch; ++i) {
+            while (launched.load(std::memory_order_acquire) <= i) {
+                if (abort_flag.load()) return;
+                std::this_thread::yield();
+            }
+            hipError_t e = hipStreamWaitEvent(s->s_d2h, kdone[i], 0);
+            const long off = (long)i * kPipeChunk, cnt = (n - off < kPipeChunk) ? n - off : kPipeChunk;
+            for (int f = 0; f < 6 && e == hipSuccess; ++f)
+                if (host_out[f])
+                    e = hipMemcpyAsync((char *)host_out[f] + off * esz, (const char *)dout[f] + off * esz, cnt * esz,
+                                       hipMemcpyDeviceToHost, s->s_d2h);
+            if (e != hipSuccess) { err_d2h = e; return; }
+        }
+        err_d2h = hipStreamSynchronize(s->s_d2h);
+    });
+    if (err == hipSuccess) err = hipEventRecord(s->ev0, s->stream);
+    for (int i = 0; i < nch && err == hipSuccess; ++i) {
+        const long off = (long)i * kPipeChunk, cnt = (n - off < kPipeChunk) ? n - off : kPipeChunk;
+        for (int f = 0; f < 8 && err == hipSuccess; ++f)
+            if (host_in[f])
+                err = hipMemcpyAsync((char *)din[f] + off * esz, (const char *)host_in[f] + off * esz, cnt * esz,
+                                     hipMemcpyHostToDevice, s->s_h2d);
+        if (err == hipSuccess) err = hipEventRecord(h2d[i], s->s_h2d);
+        if (err == hipSuccess) err = hipStreamWaitEvent(s->stream, h2d[i], 0);
+        if (err != hipSuccess) break;
+        ab::FluxCall cc = c;
+        auto adv = [&](const void *p) -> const void * { return p ? (const char *)p + off * esz : nullptr; };
+        auto advw = [&](void *p) -> void * { return p ? (char *)p + off * esz : nullptr; };
+        cc.sst = adv(c.sst); cc.t_zt = adv(c.t_zt); cc.hum = adv(c.hum); cc.u = adv(c.u); cc.v = adv(c.v); cc.slp = adv(c.slp);
+        cc.rad_sw = adv(c.rad_sw); cc.rad_lw = adv(c.rad_lw); cc.lon = adv(c.lon);
+        cc.ql = advw(c.ql); cc.qh = advw(c.qh); cc.tau_x = advw(c.tau_x); cc.tau_y = advw(c.tau_y);
+        cc.evap = advw(c.evap); cc.t_s = advw(c.t_s);
+        for (int p = 0; p < 4; ++p) cc.wl[p] = advw(c.wl[p]);
+        cc.n = cnt;
+        err = ab::launch_flux(cc, s->stream);
+        if (err == hipSuccess) err = hipEventRecord(kdone[i], s->stream);
+        if (err == hipSuccess) launched.store(i + 1, std::memory_order_release);
+    }
+    if (err == hipSuccess) err = hipEventRecord(s->ev1, s->stream);
+    if (err != hipSuccess) abort_flag.store(1);
+    drain.join();
+    if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
+    for (int i = 0; i < nch; ++i) {
+        if (kdone[i]) (void)hipEventDestroy(kdone[i]);
+        if (h2d[i]) (void)hipEventDestroy(h2d[i]);
+    }
+    return err != hipSuccess ? err : err_d2h;
+}
 
 }  // namespace
 
@@ -315,9 +395,19 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     void *hout[6] = {ql, qh, tau_x, tau_y, evap, t_s};
     void *dout[6];
     const size_t bytes = s->esz * (size_t)s->n;
+    const bool pipelined = (mem == AB_MEM_HOST) && (s->n >= kPipeThreshold);
     if (mem == AB_MEM_HOST) {
-        int rc = stage_inputs(s, host_in, din);
-        if (rc) return rc;
+        if (pipelined) {   // staging buffers only; the copies are issued chunk by chunk below
+            for (int i = 0; i < 8; ++i) {
+                din[i] = nullptr;
+                if (!host_in[i]) continue;
+                if (!s->stage_in[i]) AB_HIP(hipMalloc(&s->stage_in[i], bytes));
+                din[i] = s->stage_in[i];
+            }
+        } else {
+            int rc = stage_inputs(s, host_in, din);
+            if (rc) return rc;
+        }
         for (int i = 0; i < 6; ++i) {
             dout[i] = nullptr;
             if (!hout[i]) continue;
@@ -343,6 +433,13 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     c.wl_store = (s->use_skin && jt < s->nt && s->wl[0]) ? 1 : 0;  // freed at kt == nitend, :411
     c.isecday = s->isecday;
 
+    if (pipelined) {
+        AB_HIP(compute_host_pipelined(s, c, host_in, hout));
+        s->timed = true;
+        s->last_stream = st;
+        s->last_jt = jt;
+        return ab_session_check(s);
+    }
     AB_HIP(hipEventRecord(s->ev0, st));
     AB_HIP(ab::launch_flux(c, st));
     AB_HIP(hipEventRecord(s->ev1, st));

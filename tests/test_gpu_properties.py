@@ -172,3 +172,24 @@ def test_warm_layer_with_real_solar_time_and_longitude(oracle, torch_mod):
         st = s.wl_state() if False else None
     # the dawn window must actually have been hit by part of the domain (state destroyed there)
     assert np.any(osess.wl[:n] == 0.0) and np.any(osess.wl[:n] > 0.0)
+
+
+def test_pipelined_host_path_equals_device_path(oracle, torch_mod):
+    """Grids >= 4 Mi cells take the chunk-pipelined host path (H2D | kernel | D2H on three streams, helper thread for the
+    drain): results must be bit-identical to one device-resident launch, including the ragged last chunk and WL state."""
+    import aerobulk_amd as ab
+    ni, nj = 2200, 2001          # 4.4 M cells: 4 full chunks of 2^20 + a ragged one
+    f = oracle.synth_fields(ni, nj)
+    names = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")
+    host = [f[k] for k in names]
+    dev = [torch_mod.from_numpy(a).cuda() for a in host]
+    rs, rl = torch_mod.from_numpy(f["rad_sw"]).cuda(), torch_mod.from_numpy(f["rad_lw"]).cuda()
+    with ab.Session("coare3p6", ni, nj, 2, True) as sh, ab.Session("coare3p6", ni, nj, 2, True) as sd:
+        for jt in (1, 2):
+            h = sh.compute(jt, 2.0, 10.0, *host, Niter=4, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+            d = sd.compute(jt, 2.0, 10.0, *dev, Niter=4, rad_sw=rs, rad_lw=rl)
+            for k in h:
+                np.testing.assert_array_equal(h[k], d[k].cpu().numpy(), err_msg=f"jt={jt} {k}")
+        wh, wd = sh.wl_state(), sd.wl_state()
+        for k in wh:
+            np.testing.assert_array_equal(wh[k], wd[k], err_msg=k)
