@@ -66,3 +66,18 @@ def test_oracle_flags_excessive_wind_stress(oracle):
              v_zu=np.full(n, 10.0), slp=np.full(n, 100000.0))
     o = oracle.OracleSession("coare3p6", n).compute(1, 2.0, 10.0, 5, *[f[k] for k in IN6])
     assert o["rc"] == 1
+
+
+def test_oracle_close_to_reference_readme_toy_table(oracle):
+    """README.md:188-211 (aerobulk_toy.x, nb_iter=20): printed with 4-5 digits from an older revision of the reference —
+    a sanity check (3e-4 on tau/E/QL, 3e-3 on QH whose theta(zt) conversion changed since), not a parity pin."""
+    d = json.load(open(os.path.join(GOLDEN, "readme_toy.json")))
+    i = d["inputs"]
+    a = lambda v: np.array([v], dtype=np.float64)
+    for algo, row in d["rows"].items():
+        o = oracle.OracleSession(algo, 1).compute(1, i["zt"], i["zu"], i["niter"], a(i["sst"]), a(i["t_zt"]), a(i["q_zt"]),
+                                                  a(i["u"]), a(i["v"]), a(i["slp"]))
+        assert o["tau_x"][0] * 1e3 == pytest.approx(row["tau_mN"], rel=3e-4)
+        assert -o["evap"][0] * 86400 == pytest.approx(row["evap_mm_day"], rel=3e-4)
+        assert o["ql"][0] == pytest.approx(row["ql"], rel=3e-4)
+        assert o["qh"][0] == pytest.approx(row["qh"], rel=3e-3)
