@@ -180,6 +180,25 @@ AB_FM double qatan(double x)
     return p_copysign(r, x);
 }
 
+// atan(x) for x >= 1 (every atan of the psi functions: x = (1-a zeta)^(1/4) >= 1 on the unstable side): two ranges only
+AB_FM double qatan_ge1(double x)
+{
+    const bool big = x > 2.414213562373095;
+    const double t = qdiv(big ? -1.0 : x - 1.0, big ? x : x + 1.0);
+    const double u = t * t;
+    double p = kAtanP[10];
+#pragma unroll
+    for (int i = 9; i >= 0; --i) p = p_fmac(p, u, kAtanP[i]);
+    return (big ? 1.5707963267948966 : 0.7853981633974483) + (p_fma(t * u, p, big ? 6.123233995736766e-17 : 3.061616997868383e-17) + t);
+}
+// 1/sqrt(x), x > 0 normal: rsq seed, one Newton step, one residual correction (<= 1 ulp)
+AB_FM double qrsqrt_pos(double x)
+{
+    double y = p_rsq(x);
+    y = p_fma(y * 0.5, p_fma(-(x * y), y, 1.0), y);
+    return p_fma(y * 0.5, p_fma(-(x * y), y, 1.0), y);
+}
+
 // ---------------------------------------------------------------- cube roots
 // x^(-1/3) for x in [2^-100, 2^100] (float range): fp32 log2/exp2 seed (~3e-7), one Halley step (cubic)
 AB_FM double qrcbrt_mid(double x)

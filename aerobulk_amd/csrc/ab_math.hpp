@@ -24,6 +24,8 @@ template <> struct Mth<double> {
     static __device__ __forceinline__ R exp(R x) { return fm::qexp(x); }
     static __device__ __forceinline__ R exp10(R x) { return fm::qexp10(x); }
     static __device__ __forceinline__ R atan(R x) { return fm::qatan(x); }
+    static __device__ __forceinline__ R atan_ge1(R x) { return fm::qatan_ge1(x); }   // x >= 1
+    static __device__ __forceinline__ R rsqrt_pos(R x) { return fm::qrsqrt_pos(x); }  // x > 0
     static __device__ __forceinline__ R sqrt(R x) { return fm::qsqrt(x); }        // x >= 0
     static __device__ __forceinline__ R sqrt_pos(R x) { return fm::qsqrt_pos(x); }  // x > 0 strictly
     static __device__ __forceinline__ R cbrt(R x) { return fm::qcbrt(x); }        // x >= 0
@@ -49,6 +51,7 @@ template <> struct Mth<float> {
     static __device__ __forceinline__ R div(R a, R b) { return a * __builtin_amdgcn_rcpf(b); }
     static __device__ __forceinline__ R sqrt(R x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ R sqrt_pos(R x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ R rsqrt_pos(R x) { return __builtin_amdgcn_rsqf(x); }
     static __device__ __forceinline__ R cbrt(R x) { return x > 0.f ? exp2(log2(x) * 0.33333334f) : 0.f; }
     static __device__ __forceinline__ R rcbrt(R x) { return exp2(log2(x) * -0.33333334f); }
     static __device__ __forceinline__ R abs(R x) { return __builtin_fabsf(x); }
@@ -68,6 +71,7 @@ template <> struct Mth<float> {
         const R r = (big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.f)) + __builtin_fmaf(t * u, p, t);
         return copysign(r, x);
     }
+    static __device__ __forceinline__ R atan_ge1(R x) { return atan(x); }
 };
 
 // x**y for x > 0 (returns 0 for x == 0 and y > 0, like pow)

@@ -243,6 +243,8 @@ template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R 
     };
     R zQabs = pQnsol;
     R zdelta = delta(zQabs);
+    // no insolation (night side): zQabs = pQnsol + zfr*0 never changes, the four sub-iterations reproduce zdelta exactly
+    if (pQsw != R(0.))
 #pragma unroll 1
     for (int jc = 0; jc < 4; ++jc) {
         const R zfr = vmax(c0 + R(11.) * zdelta - M::div(R(6.6E-5), zdelta) * (R(1.) - M::exp(zdelta * R(-1. / 8.E-4))), R(0.01));
@@ -294,7 +296,7 @@ __device__ __forceinline__ void wl_coare(R (&st)[4], const WlCoareCell<R> &c, R 
             if (jl > 0) zQabs = wl_absorb(zHwl) * pQsw + pQnsol;
             zqac = st[2] + zQabs * K<R>::rdt;
             if (zqac <= R(0.)) break;
-            zHwl = vmax(vmin(Hwl_max, M::div(c.zcd1 * ztac, M::sqrt_pos(zqac))), R(0.1));
+            zHwl = vmax(vmin(Hwl_max, c.zcd1 * ztac * M::rsqrt_pos(zqac)), R(0.1));
         }
         if (zqac <= R(0.)) {
             l_destroy = true;
@@ -404,7 +406,7 @@ template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
             const R x2 = M::sqrt_pos(M::abs(R(1.) - R(15.) * z));
             const R x = M::sqrt_pos(x2);
             const R hx = R(0.5) * (R(1.) + x);
-            const R psik = M::log(hx * hx * (R(0.5) * (R(1.) + x2))) - R(2.) * M::atan(x) + R(0.5) * K<R>::rpi;
+            const R psik = M::log(hx * hx * (R(0.5) * (R(1.) + x2))) - R(2.) * M::atan_ge1(x) + R(0.5) * K<R>::rpi;
             const R psic = psic_coare(M::abs(R(1.) - R(10.15) * z));
             *pm = (R(1.) - zf) * psik + zf * psic;
         }
@@ -614,7 +616,7 @@ template <class R> __device__ __forceinline__ void psi_ecmwf(R pz, R *pm, R *ph)
         if (pm) {
             const R x = M::sqrt_pos(x2);
             const R t = R(1.) + x;
-            *pm = M::log(R(0.125) * t * t * (R(1.) + x2)) - R(2.) * M::atan(x) + R(0.5) * K<R>::rpi;
+            *pm = M::log(R(0.125) * t * t * (R(1.) + x2)) - R(2.) * M::atan_ge1(x) + R(0.5) * K<R>::rpi;
         }
         if (ph) *ph = R(2.) * M::log(R(0.5) * (R(1.) + x2));
     }
@@ -746,7 +748,7 @@ template <class R> __device__ __forceinline__ void psi_ncar(R z, R *pm, R *ph)
         if (pm) {
             const R x = M::sqrt_pos(x2);
             const R hx = (R(1.) + x) * R(0.5);
-            *pm = M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan(x) + K<R>::rpi * R(0.5);
+            *pm = M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan_ge1(x) + K<R>::rpi * R(0.5);
         }
         if (ph) *ph = R(2.) * M::log(R(0.5) * (R(1.) + x2));
     }
@@ -831,7 +833,7 @@ template <class R> __device__ __forceinline__ R psi_m_andreas(R pz)
     const R x2 = vmax(M::sqrt_pos(M::abs(R(1.) - R(16.) * z)), R(1.));
     const R x = M::sqrt_pos(x2);
     const R hx = (R(1.) + x) * R(0.5);
-    return M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan(x) + K<R>::rpi * R(0.5);
+    return M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan_ge1(x) + K<R>::rpi * R(0.5);
 }
 // psi_h_andreas :363-410
 template <class R> __device__ __forceinline__ R psi_h_andreas(R pz)
