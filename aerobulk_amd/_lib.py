@@ -31,6 +31,8 @@ SYMBOLS = {
     "ab_session_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ab_session_destroy": (C.c_int, [vp]),
     "ab_session_init": (C.c_int, [vp] + [vp] * 8 + [C.c_int, C.POINTER(InitReport)]),
+    "ab_session_init_stats": (C.c_int, [vp] + [vp] * 8 + [C.c_int, dp]),
+    "ab_session_init_apply": (C.c_int, [vp, dp, C.c_int, C.POINTER(InitReport)]),
     "ab_session_set_humidity": (C.c_int, [vp, C.c_int]),
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),
     "ab_session_check": (C.c_int, [vp]),

@@ -100,6 +100,29 @@ class Session:
         self.hum_type = report["hum_type"]
         return report
 
+    # -- AEROBULK_INIT for a sharded grid: local statistics, then decisions on the combined statistics
+    def init_stats(self, sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw=None, rad_lw=None):
+        """29 doubles: [0:11] combine by SUM, [11:20] by MIN, [20:29] by MAX (include/aerobulk_amd.h)."""
+        fields = [sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw, rad_lw]
+        ptrs, keep = zip(*[_ptr(f, self.dtype, self.n) for f in fields])
+        st = np.empty(29)
+        rc = self._lib.ab_session_init_stats(self._h, *ptrs, AB_MEM_DEVICE if _is_torch(sst) else AB_MEM_HOST,
+                                             st.ctypes.data_as(_lib.dp))
+        if rc:
+            _raise(rc)
+        return st
+
+    def init_apply(self, stats, have_rad=False):
+        st = np.ascontiguousarray(stats, dtype=np.float64)
+        rep = _lib.InitReport()
+        rc = self._lib.ab_session_init_apply(self._h, st.ctypes.data_as(_lib.dp), int(have_rad), C.byref(rep))
+        report = dict(n_cells=rep.n_cells, n_masked=rep.n_masked, hum_type=HUM_TYPES.get(rep.hum_type),
+                      bad_field=rep.bad_field, bad_min=rep.bad_min, bad_max=rep.bad_max, bad_mean=rep.bad_mean)
+        if rc:
+            _raise(rc)
+        self.hum_type = report["hum_type"]
+        return report
+
     def set_humidity(self, hum_type):
         rc = self._lib.ab_session_set_humidity(self._h, HUM_IDS[hum_type])
         if rc:

@@ -288,11 +288,11 @@ int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, i
     return AB_OK;
 }
 
-int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt, const void *u_zu,
-                    const void *v_zu, const void *slp, const void *rad_sw, const void *rad_lw, int mem,
-                    ab_init_report *report)
+int ab_session_init_stats(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt, const void *u_zu,
+                          const void *v_zu, const void *slp, const void *rad_sw, const void *rad_lw, int mem,
+                          double stats[AB_INIT_NSTATS])
 {
-    if (!s) return fail(AB_ERR_ARG, "NULL session");
+    if (!s || !stats) return fail(AB_ERR_ARG, "NULL argument");
     if (!sst || !t_zt || !hum_zt || !u_zu || !v_zu || !slp) return fail(AB_ERR_ARG, "ab_session_init: NULL input field");
     AB_HIP(hipSetDevice(s->device));
     const void *host[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw};
@@ -313,22 +313,32 @@ int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void
     AB_HIP(hipMemcpyAsync(part.data(), s->d_partials, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     AB_HIP(hipStreamSynchronize(s->stream));
 
-    double cnt = 0.;
-    FieldStat st[ab::kStatFields];
-    for (auto &f : st) { f.sum = 0.; f.mn = 1.e300; f.mx = -1.e300; }
+    // fold the per-block rows into [count, n_cells | 9 sums | 9 mins | 9 maxs] (layout of AB_INIT_NSTATS, see header)
+    double *sum = stats + 2, *mn = stats + 2 + ab::kStatFields, *mx = stats + 2 + 2 * ab::kStatFields;
+    stats[0] = 0.;
+    stats[1] = (double)s->n;
+    for (int f = 0; f < ab::kStatFields; ++f) { sum[f] = 0.; mn[f] = 1.e300; mx[f] = -1.e300; }
     for (int b = 0; b < ab::kStatBlocks; ++b) {
         const double *p = &part[(size_t)b * ab::kStatStride];
-        cnt += p[0];
+        stats[0] += p[0];
         for (int f = 0; f < ab::kStatFields; ++f) {
-            st[f].sum += p[1 + 3 * f];
-            if (p[2 + 3 * f] < st[f].mn) st[f].mn = p[2 + 3 * f];
-            if (p[3 + 3 * f] > st[f].mx) st[f].mx = p[3 + 3 * f];
+            sum[f] += p[1 + 3 * f];
+            if (p[2 + 3 * f] < mn[f]) mn[f] = p[2 + 3 * f];
+            if (p[3 + 3 * f] > mx[f]) mx[f] = p[3 + 3 * f];
         }
     }
+    return AB_OK;
+}
+
+int ab_session_init_apply(ab_session *s, const double stats[AB_INIT_NSTATS], int have_rad, ab_init_report *report)
+{
+    if (!s || !stats) return fail(AB_ERR_ARG, "NULL argument");
+    const double cnt = stats[0];
+    const double *sum = stats + 2, *mn = stats + 2 + ab::kStatFields, *mx = stats + 2 + 2 * ab::kStatFields;
     ab_init_report rep;
     memset(&rep, 0, sizeof rep);
-    rep.n_cells = s->n;
-    rep.n_masked = s->n - (long)cnt;
+    rep.n_cells = (long)stats[1];
+    rep.n_masked = (long)(stats[1] - cnt);
     rep.hum_type = -1;
     rep.bad_field = -1;
     if (report) *report = rep;
@@ -336,7 +346,7 @@ int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void
         return fail(AB_ERR_ALL_MASKED, "the whole domain is masked!\n check unit consistency of input fields");
 
     // type_of_humidity, mod_phymbl.f90:1984-2003
-    const double hmean = st[6].sum / cnt, hmin = st[6].mn, hmax = st[6].mx;
+    const double hmean = sum[6] / cnt, hmin = mn[6], hmax = mx[6];
     double hlo, hhi;
     if ((hmean >= 0.) && (hmean < 0.08) && (hmin >= 0.) && (hmax < 0.08)) { rep.hum_type = AB_HUM_SH; hlo = 0.; hhi = 0.08; }
     else if ((hmean >= 150.) && (hmean < 330.) && (hmin >= 150.) && (hmax < 330.)) { rep.hum_type = AB_HUM_DP; hlo = 150.; hhi = 330.; }
@@ -355,20 +365,30 @@ int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void
     static const char *units[9] = {"K", "K", "Pa", "m/s", "m/s", "m/s", "kg/kg", "W/m^2", "W/m^2"};
     const double lo[9] = {270., 180., 80000., -50., -50., 0., hlo, 0., 0.};
     const double hi[9] = {320., 330., 110000., 50., 50., 50., hhi, 1500., 750.};
-    const int nf = rad ? 9 : 7;
+    const int nf = have_rad ? 9 : 7;
     for (int f = 0; f < nf; ++f) {
-        const double mean = st[f].sum / cnt;
-        if ((st[f].mx > hi[f]) || (st[f].mn < lo[f]) || (mean < lo[f]) || (mean > hi[f])) {
-            rep.bad_field = f; rep.bad_min = st[f].mn; rep.bad_max = st[f].mx; rep.bad_mean = mean;
+        const double mean = sum[f] / cnt;
+        if ((mx[f] > hi[f]) || (mn[f] < lo[f]) || (mean < lo[f]) || (mean > hi[f])) {
+            rep.bad_field = f; rep.bad_min = mn[f]; rep.bad_max = mx[f]; rep.bad_mean = mean;
             if (report) *report = rep;
             return fail(AB_ERR_UNITS,
                         " *** ERROR (check_unit_consistency@mod_phymbl): field `%s` does not seem to be in %s !\n"
                         " min value = %10.3e max value = %10.3e mean value = %10.3e",
-                        names[f], units[f], st[f].mn, st[f].mx, mean);
+                        names[f], units[f], mn[f], mx[f], mean);
         }
     }
     if (report) *report = rep;
     return AB_OK;
+}
+
+int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt, const void *u_zu,
+                    const void *v_zu, const void *slp, const void *rad_sw, const void *rad_lw, int mem,
+                    ab_init_report *report)
+{
+    double stats[AB_INIT_NSTATS];
+    int rc = ab_session_init_stats(s, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, mem, stats);
+    if (rc) return rc;
+    return ab_session_init_apply(s, stats, (rad_sw && rad_lw) ? 1 : 0, report);
 }
 
 int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, const void *sst, const void *t_zt,

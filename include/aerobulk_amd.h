@@ -89,6 +89,16 @@ int ab_session_destroy(ab_session *s);
 int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt,
                     const void *u_zu, const void *v_zu, const void *slp,
                     const void *rad_sw, const void *rad_lw, int mem, ab_init_report *report);
+/* The same in two steps, for a grid sharded over several GPUs/processes (AEROBULK_INIT's statistics are the one global
+ * exchange of the path): every rank reduces its own cells with ab_session_init_stats(), the ranks combine
+ * the AB_INIT_NSTATS doubles — stats[0..10] by SUM (count of unmasked cells, number of cells, 9 masked sums),
+ * stats[11..19] by MIN, stats[20..28] by MAX; field order sst,t_air,slp,u10,v10,wnd,hum,rad_sw,rad_lw — and every rank
+ * takes the decisions on the combined numbers with ab_session_init_apply().  ab_session_init == stats + apply. */
+#define AB_INIT_NSTATS 29
+int ab_session_init_stats(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt,
+                          const void *u_zu, const void *v_zu, const void *slp,
+                          const void *rad_sw, const void *rad_lw, int mem, double stats[AB_INIT_NSTATS]);
+int ab_session_init_apply(ab_session *s, const double stats[AB_INIT_NSTATS], int have_rad, ab_init_report *report);
 /* Skip the detection and force the humidity type (device-resident callers that already know). */
 int ab_session_set_humidity(ab_session *s, int hum_type);
 

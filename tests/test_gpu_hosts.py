@@ -161,3 +161,28 @@ def test_bench_sharded_path_two_ranks_one_gpu():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["verify"].startswith("gathered == single-GPU")
     assert res["scaling"] == "strong" and res["value"] > 0
+
+
+def test_sharded_init_statistics_match_global_init(oracle):
+    """AEROBULK_INIT on a grid sharded over ranks (SURVEY §8e "the one true exchange"): per-shard ab_session_init_stats,
+    SUM/MIN/MAX combination (what an all-reduce does), ab_session_init_apply -> same report as one global init."""
+    import aerobulk_amd as ab
+    ni, nj = 200, 90
+    f = oracle.synth_fields(ni, nj)
+    fields = [f[k].copy() for k in IN6]
+    fields[0][[3, 4000, 17000]] = 0.0      # silly SST in both shards
+    fields[5][9000:9005] = 0.0             # silly SLP in the second shard
+    n = ni * nj
+    cut = ni * 41                          # ragged j-blocks: 41 + 49 rows
+    with ab.Session("coare3p6", n, 1, 1, True) as g:
+        want = g.init(*fields, rad_sw=f["rad_lw"], rad_lw=f["rad_lw"])
+    parts = []
+    sessions = [ab.Session("coare3p6", cut, 1, 1, True), ab.Session("coare3p6", n - cut, 1, 1, True)]
+    for s, sl in zip(sessions, (slice(0, cut), slice(cut, n))):
+        parts.append(s.init_stats(*[a[sl] for a in fields], rad_sw=f["rad_lw"][sl], rad_lw=f["rad_lw"][sl]))
+    st = np.concatenate([np.sum([p[0:11] for p in parts], axis=0), np.min([p[11:20] for p in parts], axis=0),
+                         np.max([p[20:29] for p in parts], axis=0)])
+    for s in sessions:
+        got = s.init_apply(st, have_rad=True)
+        assert (got["n_cells"], got["n_masked"], got["hum_type"]) == (want["n_cells"], want["n_masked"], want["hum_type"]) == (n, 8, "sh")
+        s.close()
