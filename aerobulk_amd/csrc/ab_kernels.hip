@@ -14,6 +14,14 @@
 namespace ab {
 
 constexpr int kBlock = 256;  // 4 waves of 64 lanes, one per SIMD
+// Which wave-uniform values are laundered into VGPRs (see flux_kernel): measured on the MI355X (profiles/r1_notes.md) —
+// heights help every kernel (-2 % skin, -5 % no skin); output addresses help only the no-skin kernels (-4 %), the skin
+// kernels would cross 168 VGPRs (3 -> 2 waves/SIMD) and lose 9 %.
+#ifndef AB_LAUNDER_HEIGHTS
+#define AB_LAUNDER_HEIGHTS(skin) true
+#define AB_LAUNDER_OUT(skin) (!(skin))
+#define AB_LAUNDER_WL false
+#endif
 #ifndef AB_WAVES_PER_EU
 #define AB_WAVES_PER_EU 2    // fp64 skin kernels want ~240 VGPRs: 2 waves/SIMD (measured best)
 #endif
@@ -34,6 +42,27 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
     using M = Mth<R>;
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
     if (k >= a.n) return;
+#ifndef AB_NO_VGPR_LAUNDERING
+    // The wave-uniform height constants are used all over the iteration loop.  Left in SGPRs they are spilled to VGPR
+    // lanes (the kernel holds >100 scalar values) and every use pays two v_readlane; there are spare VGPRs, so they are
+    // laundered into vector registers once.
+    Heights<R> hh = a.h;
+    if (AB_LAUNDER_HEIGHTS(SKIN))
+        asm volatile("" : "+v"(hh.zt), "+v"(hh.zu), "+v"(hh.log_zt), "+v"(hh.log_zu), "+v"(hh.log_10), "+v"(hh.log_ztu),
+                          "+v"(hh.log_zu10), "+v"(hh.inv_zu), "+v"(hh.zt_o_zu));
+    // same for the per-lane output / state addresses: formed now (20 VGPRs), so that the 10 base pointers stop
+    // occupying SGPRs for the whole kernel
+    R *pql = a.ql + k, *pqh = a.qh + k, *ptx = a.tau_x + k, *pty = a.tau_y + k;
+    R *pev = a.evap ? a.evap + k : nullptr, *pts = a.t_s ? a.t_s + k : nullptr;
+    R *pw0 = a.wl0 + k, *pw1 = a.wl1 + k, *pw2 = a.wl2 + k, *pw3 = a.wl3 + k;
+    if (AB_LAUNDER_OUT(SKIN)) asm volatile("" : "+v"(pql), "+v"(pqh), "+v"(ptx), "+v"(pty), "+v"(pev), "+v"(pts));
+    if (SKIN && AB_LAUNDER_WL) asm volatile("" : "+v"(pw0), "+v"(pw1), "+v"(pw2), "+v"(pw3));
+#else
+    const Heights<R> &hh = a.h;
+    R *pql = a.ql + k, *pqh = a.qh + k, *ptx = a.tau_x + k, *pty = a.tau_y + k;
+    R *pev = a.evap ? a.evap + k : nullptr, *pts = a.t_s ? a.t_s + k : nullptr;
+    R *pw0 = a.wl0 + k, *pw1 = a.wl1 + k, *pw2 = a.wl2 + k, *pw3 = a.wl3 + k;
+#endif
 
     // ---- coalesced loads of the input fields
     const R sst = a.sst[k];
@@ -52,7 +81,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
     else in.q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));                  // 'rh' :105
     in.wnd = M::sqrt(uu * uu + vv * vv);                                       // :111
     in.ssq = K<R>::rdct_qsat_salt * q_sat(sst, slp);                           // :114
-    in.theta_zt = theta_from_z_p0_t_q(a.h.zt, slp, t_zt, in.q_zt);             // :118
+    in.theta_zt = theta_from_z_p0_t_q(hh.zt, slp, t_zt, in.q_zt);             // :118
     in.qsw = R(0.);
     in.rlw = R(0.);
 
@@ -62,9 +91,9 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         in.qsw = (R(1.) - K<R>::roce_alb0) * a.rad_sw[k];                      // :135,146,161
         in.rlw = a.rad_lw[k];
         if (a.wl_load) {
-            wl[0] = a.wl0[k];
-            wl[1] = a.wl1[k];
-            if (ALGO != 4) { wl[2] = a.wl2[k]; wl[3] = a.wl3[k]; }
+            wl[0] = *pw0;
+            wl[1] = *pw1;
+            if (ALGO != 4) { wl[2] = *pw2; wl[3] = *pw3; }
         } else {  // COARE3Px_INIT mod_blk_coare3p6.f90:84-87 ; ECMWF_INIT mod_blk_ecmwf.f90:403-404
             wl[1] = (ALGO == 4) ? R(3.) : R(20.);
         }
@@ -73,21 +102,21 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
 
     // ---- TURB_<algo>, mod_aerobulk_compute.f90:129-176
     CellOut<R> o;
-    if (ALGO == 1) turb_coare<R, false, SKIN>(a.h, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 2) turb_coare<R, true, SKIN>(a.h, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 3) turb_ncar<R>(a.h, in, a.nb_iter, o);
-    else if (ALGO == 4) turb_ecmwf<R, SKIN>(a.h, in, a.nb_iter, wl, o);
-    else turb_andreas<R>(a.h, in, a.nb_iter, o);
+    if (ALGO == 1) turb_coare<R, false, SKIN>(hh, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 2) turb_coare<R, true, SKIN>(hh, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 3) turb_ncar<R>(hh, in, a.nb_iter, o);
+    else if (ALGO == 4) turb_ecmwf<R, SKIN>(hh, in, a.nb_iter, wl, o);
+    else turb_andreas<R>(hh, in, a.nb_iter, o);
 
     if (SKIN && a.wl_store) {
-        a.wl0[k] = wl[0];
-        a.wl1[k] = wl[1];
-        if (ALGO != 4) { a.wl2[k] = wl[2]; a.wl3[k] = wl[3]; }
+        *pw0 = wl[0];
+        *pw1 = wl[1];
+        if (ALGO != 4) { *pw2 = wl[2]; *pw3 = wl[3]; }
     }
 
     // ---- BULK_FORMULA + stress vector, :184-194
     R zTaum, QH, QL, zEvap;
-    bulk_formula(a.h.zu, o.T_s, o.q_s, o.t_zu, o.q_zu, o.Cd, o.Ch, o.Ce, in.wnd, o.Ubzu, slp, zTaum, QH, QL, zEvap);
+    bulk_formula(hh.zu, o.T_s, o.q_s, o.t_zu, o.q_zu, o.Cd, o.Ch, o.Ce, in.wnd, o.Ubzu, slp, zTaum, QH, QL, zEvap);
     if (zTaum > R(10.)) atomicOr(a.flags, 1);                                  // mod_phymbl.f90:1250-1253
     R tx = R(0.), ty = R(0.);
     if (in.wnd > R(1.E-3)) {
@@ -95,12 +124,12 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         tx = s * uu;
         ty = s * vv;
     }
-    a.ql[k] = QL;
-    a.qh[k] = QH;
-    a.tau_x[k] = tx;
-    a.tau_y[k] = ty;
-    if (a.evap) a.evap[k] = zEvap;                                             // :208
-    if (a.t_s) a.t_s[k] = o.T_s;                                               // :206
+    *pql = QL;
+    *pqh = QH;
+    *ptx = tx;
+    *pty = ty;
+    if (pev) *pev = zEvap;                                                     // :208
+    if (pts) *pts = o.T_s;                                                     // :206
 }
 
 template <class R> static Heights<R> make_heights(double zt, double zu)
