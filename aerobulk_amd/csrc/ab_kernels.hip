@@ -14,16 +14,16 @@
 namespace ab {
 
 constexpr int kBlock = 256;  // 4 waves of 64 lanes, one per SIMD
-// Which wave-uniform values are laundered into VGPRs (see flux_kernel): measured on the MI355X (profiles/r1_notes.md) —
-// heights help every kernel (-2 % skin, -5 % no skin); output addresses help only the no-skin kernels (-4 %), the skin
-// kernels would cross 168 VGPRs (3 -> 2 waves/SIMD) and lose 9 %.
+// Which wave-uniform values are laundered into VGPRs (see flux_kernel), measured on the MI355X (profiles/r1_notes.md):
+// heights -2 % (skin) / -5 % (no skin); output addresses -4 % (no skin) and -1 % (skin) PROVIDED the kernel stays at
+// 3 waves/SIMD (<= 168 VGPRs, enforced by __launch_bounds__ below): at 170 VGPRs (2 waves/SIMD) the skin kernel loses 9 %.
 #ifndef AB_LAUNDER_HEIGHTS
 #define AB_LAUNDER_HEIGHTS(skin) true
-#define AB_LAUNDER_OUT(skin) (!(skin))
+#define AB_LAUNDER_OUT(skin) true
 #define AB_LAUNDER_WL false
 #endif
 #ifndef AB_WAVES_PER_EU
-#define AB_WAVES_PER_EU 2    // fp64 skin kernels want ~240 VGPRs: 2 waves/SIMD (measured best)
+#define AB_WAVES_PER_EU 3    // <= 168 VGPRs: scalar-load / SALU latencies want the third wave (no scratch needed)
 #endif
 
 template <class R> struct FluxArgs {
