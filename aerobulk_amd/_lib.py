@@ -21,6 +21,12 @@ class InitReport(C.Structure):
                 ("bad_min", C.c_double), ("bad_max", C.c_double), ("bad_mean", C.c_double)]
 
 
+class Diag(C.Structure):
+    """ab_diag: 16 optional output pointers, in this order."""
+    NAMES = ("Cd", "Ch", "Ce", "t_zu", "q_zu", "Ubzu", "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10", "dT_cs", "dT_wl", "Hz_wl")
+    _fields_ = [(n, C.c_void_p) for n in NAMES]
+
+
 # every symbol include/aerobulk_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ab_algo_from_string": (C.c_int, [C.c_char_p, C.c_int]),
@@ -34,6 +40,7 @@ SYMBOLS = {
     "ab_session_init_stats": (C.c_int, [vp] + [vp] * 8 + [C.c_int, dp]),
     "ab_session_init_apply": (C.c_int, [vp, dp, C.c_int, C.POINTER(InitReport)]),
     "ab_session_set_humidity": (C.c_int, [vp, C.c_int]),
+    "ab_session_set_diagnostics": (C.c_int, [vp, C.POINTER(Diag), C.c_int]),
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),
     "ab_session_check": (C.c_int, [vp]),
     "ab_session_set_solar_time": (C.c_int, [vp, C.c_int, vp, C.c_int]),

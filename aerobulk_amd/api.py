@@ -129,6 +129,32 @@ class Session:
             _raise(rc)
         self.hum_type = hum_type
 
+    def set_diagnostics(self, names=None, device=None):
+        """Ask every following compute() for the TURB_* diagnostics in `names` (any of _lib.Diag.NAMES; None/empty switches
+        them off).  Returns the dict of arrays that will be (re)written: numpy arrays, or torch tensors on `device`."""
+        self._diag = {}
+        if not names:
+            rc = self._lib.ab_session_set_diagnostics(self._h, None, 0)
+            if rc:
+                _raise(rc)
+            return self._diag
+        d = _lib.Diag()
+        for k in names:
+            if k not in _lib.Diag.NAMES:
+                raise ValueError(f"unknown diagnostic {k}")
+            if device is not None:
+                import torch
+                a = torch.empty(self.n, dtype=torch.float64 if self.dtype == np.float64 else torch.float32, device=device)
+                setattr(d, k, a.data_ptr())
+            else:
+                a = np.empty(self.n, dtype=self.dtype)
+                setattr(d, k, a.ctypes.data)
+            self._diag[k] = a
+        rc = self._lib.ab_session_set_diagnostics(self._h, C.byref(d), AB_MEM_DEVICE if device is not None else AB_MEM_HOST)
+        if rc:
+            _raise(rc)
+        return self._diag
+
     def set_solar_time(self, isecday_utc, lon=None):
         p, keep = _ptr(lon, self.dtype, self.n)
         rc = self._lib.ab_session_set_solar_time(self._h, int(isecday_utc), p,

@@ -36,8 +36,13 @@ template <class R> struct FluxArgs {
     int nb_iter, hum_type, wl_load, wl_store, isecday, dawn_uniform;
 };
 
-template <class R, int ALGO, bool SKIN>
-__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a)
+// optional per-cell diagnostics of TURB_* (ab_session_set_diagnostics); read only by the DIAG instantiations
+template <class R> struct DiagArgs {
+    R *p[16];   // Cd Ch Ce t_zu q_zu Ubzu | CdN ChN CeN z0 u_star L UN10 | dT_cs dT_wl Hz_wl ; nullptr = not wanted
+};
+
+template <class R, int ALGO, bool SKIN, bool DIAG>
+__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
 {
     using M = Mth<R>;
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -102,11 +107,18 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
 
     // ---- TURB_<algo>, mod_aerobulk_compute.f90:129-176
     CellOut<R> o;
-    if (ALGO == 1) turb_coare<R, false, SKIN>(hh, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 2) turb_coare<R, true, SKIN>(hh, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 3) turb_ncar<R>(hh, in, a.nb_iter, o);
-    else if (ALGO == 4) turb_ecmwf<R, SKIN>(hh, in, a.nb_iter, wl, o);
-    else turb_andreas<R>(hh, in, a.nb_iter, o);
+    if (ALGO == 1) turb_coare<R, false, SKIN, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 2) turb_coare<R, true, SKIN, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 3) turb_ncar<R, DIAG>(hh, in, a.nb_iter, o);
+    else if (ALGO == 4) turb_ecmwf<R, SKIN, DIAG>(hh, in, a.nb_iter, wl, o);
+    else turb_andreas<R, DIAG>(hh, in, a.nb_iter, o);
+    if (DIAG) {
+        const R d[16] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
+                         o.dT_cs, o.dT_wl, o.Hz_wl};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (dg.p[i]) dg.p[i][k] = d[i];
+    }
 
     if (SKIN && a.wl_store) {
         *pw0 = wl[0];
@@ -160,6 +172,9 @@ static int dawn_at_lon0(int isd)
 
 template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
 {
+    DiagArgs<R> dg;
+    bool diag = false;
+    for (int i = 0; i < 16; ++i) { dg.p[i] = (R *)c.diag[i]; diag = diag || (c.diag[i] != nullptr); }
     FluxArgs<R> a;
     a.sst = (const R *)c.sst; a.t_zt = (const R *)c.t_zt; a.hum = (const R *)c.hum;
     a.u = (const R *)c.u; a.v = (const R *)c.v; a.slp = (const R *)c.slp;
@@ -175,7 +190,8 @@ template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCal
     a.dawn_uniform = dawn_at_lon0(c.isecday);
     const long nblk = (c.n + kBlock - 1) / kBlock;
     if (nblk <= 0) return hipSuccess;
-    hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a);
+    if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
+    else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     return hipGetLastError();
 }
 

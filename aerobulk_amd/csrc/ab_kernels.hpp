@@ -13,6 +13,7 @@ struct FluxCall {
     void *ql, *qh, *tau_x, *tau_y, *evap, *t_s;
     // warm-layer state planes dT_wl, Hz_wl, Qnt_ac, Tau_ac (mod_skin_coare.f90:31-36)
     void *wl[4];
+    void *diag[16]; // optional TURB_* diagnostics (all nullptr: the lean kernels run); order of ab_diag in the C ABI
     int *flags;     // bit0: wind stress > 10 N/m^2 somewhere (mod_phymbl.f90:1250)
     long n;
     double zt, zu;

@@ -495,12 +495,15 @@ template <class R> struct CellIn {
 };
 template <class R> struct CellOut {
     R Cd, Ch, Ce, t_zu, q_zu, Ubzu, T_s, q_s;
+    // OPTIONAL outputs of the TURB_* routines (CdN ChN CeN xz0 xu_star xL xUN10 pdT_cs pdT_wl pHz_wl), filled only by the
+    // DIAG instantiations (ab_session_set_diagnostics); dead code otherwise
+    R CdN, ChN, CeN, z0, us, L, UN10, dT_cs, dT_wl, Hz_wl;
 };
 
 // ---------------------------------------------------------------- TURB_COARE3P6 / turb_coare3p0
 // mod_blk_coare3p6.f90:123-413, mod_blk_coare3p0.f90:54-358.  V36 selects the version; SKIN = cool-skin AND
 // warm-layer (aerobulk_compute always switches both on together, mod_aerobulk_compute.f90:133,144).
-template <class R, bool V36, bool SKIN>
+template <class R, bool V36, bool SKIN, bool DIAG = false>
 __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
                                            bool dawn, CellOut<R> &o)
 {
@@ -531,6 +534,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
     R zdt = sfloor(t_zu - T_s, R(1.E-09));
     R zdq = sfloor(q_zu - q_s, R(1.E-12));
     R zdT_cs = R(0.);
+    R d_1oL = R(0.), d_lz0t = R(0.);   // DIAG only
 
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
@@ -554,6 +558,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
         const R zlog_z0t = vmax(V36 ? vmin(R(-8.740336742730447), R(-9.755067547417855) + R(0.72) * zlog_rr)
                                     : vmin(R(-9.115030192171858), R(-9.808177372731803) + R(0.6) * zlog_rr),
                                 R(-20.72326583694641));
+        if (DIAG) { d_1oL = z1oL; d_lz0t = zlog_z0t; }
         // turbulent scales :339-344
         R psm, psh;
         psi_coare<R>(zzta_u, &psm, &psh);
@@ -595,6 +600,14 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
     o.Ch = vmax(M::div(ztmp0 * zts, zdt), K<R>::Cx_min);
     o.Ce = vmax(M::div(ztmp0 * zqs, zdq), K<R>::Cx_min);
     o.t_zu = t_zu; o.q_zu = q_zu; o.Ubzu = Ubzu; o.T_s = T_s; o.q_s = q_s;
+    if (DIAG) {   // optional outputs :392-407 (3p0 :337-352)
+        const R zi = M::rcp(h.log_zu - zlog_z0);
+        o.CdN = vmax(K<R>::vkarmn2 * zi * zi, K<R>::Cx_min);
+        o.ChN = vmax(M::div(K<R>::vkarmn2 * zi, h.log_zu - d_lz0t), K<R>::Cx_min);
+        o.CeN = o.ChN;
+        o.z0 = zz0; o.us = zus; o.L = M::rcp(d_1oL); o.UN10 = zus * K<R>::inv_vk * (h.log_10 - zlog_z0);
+        o.dT_cs = zdT_cs; o.dT_wl = SKIN ? wl[0] : R(0.); o.Hz_wl = SKIN ? wl[1] : R(0.);
+    }
 }
 
 // ---------------------------------------------------------------- ECMWF (mod_blk_ecmwf.f90)
@@ -625,7 +638,7 @@ template <class R> __device__ __forceinline__ R psi_m_ecmwf(R z) { R m; psi_ecmw
 template <class R> __device__ __forceinline__ R psi_h_ecmwf(R z) { R v; psi_ecmwf<R>(z, nullptr, &v); return v; }
 
 // turb_ecmwf :63-383
-template <class R, bool SKIN>
+template <class R, bool SKIN, bool DIAG = false>
 __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
                                            CellOut<R> &o)
 {
@@ -720,6 +733,14 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
     o.Ch = vmax(M::div(ziFm, zFh), K<R>::Cx_min);
     o.Ce = vmax(M::div(ziFm, zFq), K<R>::Cx_min);
     o.t_zu = zt_zu; o.q_zu = zq_zu; o.Ubzu = zUbzu; o.T_s = zT_s; o.q_s = zq_s;
+    if (DIAG) {   // optional outputs :362-377
+        const R zi = M::rcp(h.log_zu - zlog_z0);
+        o.CdN = vmax(K<R>::vkarmn2 * zi * zi, K<R>::Cx_min);
+        o.ChN = vmax(M::div(K<R>::vkarmn2 * zi, h.log_zu - zlog_z0t), K<R>::Cx_min);
+        o.CeN = o.ChN;
+        o.z0 = zz0; o.us = zus; o.L = M::rcp(z1oL); o.UN10 = zus * K<R>::inv_vk * (h.log_10 - zlog_z0);
+        o.dT_cs = zdT_cs; o.dT_wl = SKIN ? wl[0] : R(0.); o.Hz_wl = SKIN ? wl[1] : R(0.);
+    }
 }
 
 // ---------------------------------------------------------------- NCAR (mod_blk_ncar.f90, Large & Yeager 2004/2008)
@@ -754,7 +775,7 @@ template <class R> __device__ __forceinline__ void psi_ncar(R z, R *pm, R *ph)
     }
 }
 // turb_ncar :57-240
-template <class R>
+template <class R, bool DIAG = false>
 __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &in, int nb_iter, CellOut<R> &o)
 {
     using M = Mth<R>;
@@ -770,6 +791,7 @@ __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &
     R zsqrt_Cd = zsqrt_CdN;
     R t_zu = vmax(in.theta_zt, R(180.));
     R q_zu = vmax(in.q_zt, R(1.e-6));
+    R d_us = R(0.), d_1oL = R(0.), d_un10 = R(0.), d_chn = R(0.), d_cen = R(0.);   // DIAG only
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
         const R zdt = t_zu - sst;                                       // :177-178 (not floored)
@@ -808,8 +830,14 @@ __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &
         const R zCeN = R(1.e-3) * (R(34.6) * zsqrt_CdN);
         Ch = vmax(M::div(zChN * ztmp2, R(1.) + zChN * ztmp), K<R>::Cx_min);
         Ce = vmax(M::div(zCeN * ztmp2, R(1.) + zCeN * ztmp), K<R>::Cx_min);
+        if (DIAG) { d_us = zus; d_1oL = z1oL; d_un10 = zUn10; d_chn = zChN; d_cen = zCeN; }
     }
     o.Cd = Cd; o.Ch = Ch; o.Ce = Ce; o.t_zu = t_zu; o.q_zu = q_zu; o.Ubzu = Ubzu; o.T_s = sst; o.q_s = ssq;
+    if (DIAG) {   // optional outputs :229-235 ; z0_from_Cd without psi mod_phymbl.f90:1349
+        o.CdN = zCdN; o.CeN = d_cen; o.ChN = d_chn; o.UN10 = d_un10; o.L = M::rcp(d_1oL); o.us = d_us;
+        o.z0 = vmin(h.zu * M::exp(-M::div(vk, M::sqrt_pos(zCdN))), K<R>::z0_sea_max);
+        o.dT_cs = R(0.); o.dT_wl = R(0.); o.Hz_wl = R(0.);
+    }
 }
 
 // ---------------------------------------------------------------- ANDREAS (mod_blk_andreas.f90, Andreas et al. 2015)
@@ -875,7 +903,7 @@ template <class R> __device__ __forceinline__ void z0tq_lkb(R zrr, R pz0, R &z0t
     z0q = vmin(vmax(M::abs(rq), R(1.E-9)), R(0.05));
 }
 // turb_andreas :66-272
-template <class R>
+template <class R, bool DIAG = false>
 __device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R> &in, int nb_iter, CellOut<R> &o)
 {
     using M = Mth<R>;
@@ -889,6 +917,7 @@ __device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R
     R q_star = R(0.03316624790355400) * (pq_zu - pssq);
     R RiB = ri_bulk(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);             // :173
     R u_star = R(0.);
+    R d_z0 = R(0.), d_zeta = R(0.);   // DIAG only
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
         if (RiB < R(0.15)) {                                            // :183-191
@@ -902,6 +931,7 @@ __device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R
         const R pCd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);                // :209
         const R psm = psi_m_andreas<R>(zeta_u);
         const R z0 = vmin(h.zu * M::exp(-(M::div(vk, M::sqrt_pos(pCd)) + psm)), K<R>::z0_sea_max);  // :214
+        if (DIAG) { d_z0 = z0; d_zeta = zeta_u; }
         ztmp0 = M::div(z0 * u_star, visc_air(pt_zu));                   // :219 Re_r
         R z0t, z0q;
         z0tq_lkb(ztmp0, z0, z0t, z0q);                                  // :220-221
@@ -924,6 +954,17 @@ __device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R
     o.Ch = vmax(M::div(ztmp0 * t_star, d1), R(0.35E-3));
     o.Ce = vmax(M::div(ztmp0 * q_star, d2), R(0.35E-3));
     o.t_zu = pt_zu; o.q_zu = pq_zu; o.Ubzu = pUbzu; o.T_s = psst; o.q_s = pssq;
+    if (DIAG) {   // optional outputs :256-267
+        const R zi = M::rcp(M::log(M::div(h.zu, d_z0)));
+        o.CdN = vmax(K<R>::vkarmn2 * zi * zi, K<R>::Cx_min);
+        R z0t, z0q;
+        z0tq_lkb(M::div(d_z0 * u_star, visc_air(pt_zu)), d_z0, z0t, z0q);
+        o.ChN = M::div(K<R>::vkarmn2 * zi, M::log(M::div(h.zu, z0t)));
+        o.CeN = M::div(K<R>::vkarmn2 * zi, M::log(M::div(h.zu, z0q)));
+        o.z0 = d_z0; o.us = u_star; o.L = M::div(h.zu, d_zeta);
+        o.UN10 = pUbzu - u_star * K<R>::inv_vk * (h.log_zu10 - psi_m_andreas<R>(d_zeta));
+        o.dT_cs = R(0.); o.dT_wl = R(0.); o.Hz_wl = R(0.);
+    }
 }
 
 }  // namespace ab

@@ -58,6 +58,10 @@ struct ab_session {
     double *d_partials = nullptr;
     void *stage_in[8] = {nullptr};    // device staging for AB_MEM_HOST callers
     void *stage_out[6] = {nullptr};
+    void *diag_user[16] = {nullptr};  // caller's diagnostic arrays (ab_session_set_diagnostics), host or device
+    void *diag_dev[16] = {nullptr};   // device staging when the caller's arrays are host memory
+    int diag_mem = AB_MEM_DEVICE;
+    bool diag_on = false;
     hipStream_t stream = nullptr;     // session stream for host-mem calls (kernels)
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;  // copy streams of the pipelined host path
     hipStream_t last_stream = nullptr;
@@ -156,6 +160,7 @@ int ab_session_destroy(ab_session *s)
     for (auto &p : s->wl) if (p) (void)hipFree(p);
     for (auto &p : s->stage_in) if (p) (void)hipFree(p);
     for (auto &p : s->stage_out) if (p) (void)hipFree(p);
+    for (auto &p : s->diag_dev) if (p) (void)hipFree(p);
     if (s->d_lon) (void)hipFree(s->d_lon);
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_partials) (void)hipFree(s->d_partials);
@@ -270,6 +275,22 @@ int ab_session_set_humidity(ab_session *s, int hum_type)
     if (!s) return fail(AB_ERR_ARG, "NULL session");
     if (hum_type < AB_HUM_SH || hum_type > AB_HUM_RH) return fail(AB_ERR_HUM_TYPE, "humidty type %d is unknown!!!", hum_type);
     s->hum_type = hum_type;
+    return AB_OK;
+}
+
+int ab_session_set_diagnostics(ab_session *s, const ab_diag *d, int mem)
+{
+    if (!s) return fail(AB_ERR_ARG, "NULL session");
+    s->diag_on = false;
+    for (auto &p : s->diag_user) p = nullptr;
+    if (!d) return AB_OK;
+    void *const ptrs[16] = {d->Cd, d->Ch, d->Ce, d->t_zu, d->q_zu, d->Ubzu, d->CdN, d->ChN, d->CeN, d->z0, d->u_star, d->L,
+                            d->UN10, d->dT_cs, d->dT_wl, d->Hz_wl};
+    for (int i = 0; i < 16; ++i) {
+        s->diag_user[i] = ptrs[i];
+        s->diag_on = s->diag_on || (ptrs[i] != nullptr);
+    }
+    s->diag_mem = mem;
     return AB_OK;
 }
 
@@ -415,7 +436,7 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     void *hout[6] = {ql, qh, tau_x, tau_y, evap, t_s};
     void *dout[6];
     const size_t bytes = s->esz * (size_t)s->n;
-    const bool pipelined = (mem == AB_MEM_HOST) && (s->n >= kPipeThreshold);
+    const bool pipelined = (mem == AB_MEM_HOST) && (s->n >= kPipeThreshold) && !s->diag_on;
     if (mem == AB_MEM_HOST) {
         if (pipelined) {   // staging buffers only; the copies are issued chunk by chunk below
             for (int i = 0; i < 8; ++i) {
@@ -445,6 +466,14 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     c.rad_sw = din[6]; c.rad_lw = din[7]; c.lon = s->d_lon;
     c.ql = dout[0]; c.qh = dout[1]; c.tau_x = dout[2]; c.tau_y = dout[3]; c.evap = dout[4]; c.t_s = dout[5];
     for (int p = 0; p < 4; ++p) c.wl[p] = s->wl[p];
+    if (s->diag_on) {
+        for (int i = 0; i < 16; ++i) {
+            if (!s->diag_user[i]) continue;
+            if (s->diag_mem == AB_MEM_DEVICE) { c.diag[i] = s->diag_user[i]; continue; }
+            if (!s->diag_dev[i]) AB_HIP(hipMalloc(&s->diag_dev[i], bytes));
+            c.diag[i] = s->diag_dev[i];
+        }
+    }
     c.flags = s->d_flags;
     c.n = s->n; c.zt = zt; c.zu = zu;
     c.algo = s->algo; c.skin = s->use_skin; c.f32 = s->f32;
@@ -467,6 +496,11 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     s->last_stream = st;
     s->last_jt = jt;
 
+    if (s->diag_on && s->diag_mem == AB_MEM_HOST) {
+        for (int i = 0; i < 16; ++i)
+            if (s->diag_user[i]) AB_HIP(hipMemcpyAsync(s->diag_user[i], s->diag_dev[i], bytes, hipMemcpyDeviceToHost, st));
+        if (mem != AB_MEM_HOST) AB_HIP(hipStreamSynchronize(st));
+    }
     if (mem == AB_MEM_HOST) {
         for (int i = 0; i < 6; ++i)
             if (hout[i]) AB_HIP(hipMemcpyAsync(hout[i], dout[i], bytes, hipMemcpyDeviceToHost, st));

@@ -123,6 +123,20 @@ int ab_session_check(ab_session *s);
  * :345-377) set them here.  `lon` (degrees East, same layout/mem/precision as the fields) may be NULL. */
 int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int mem);
 
+/* Optional per-cell diagnostics: what the TURB_* routines return besides the fluxes — their mandatory outputs Cd, Ch, Ce,
+ * t_zu, q_zu, Ubzu and their OPTIONAL ones CdN, ChN, CeN, xz0, xu_star, xL, xUN10, pdT_cs, pdT_wl, pHz_wl
+ * (mod_blk_coare3p6.f90:207-230,392-407; mod_blk_coare3p0.f90:337-352; mod_blk_ecmwf.f90:362-377; mod_blk_ncar.f90:229-235;
+ * mod_blk_andreas.f90:256-267), as consumed by the reference's toy driver (src/tests/aerobulk_toy.F90:324-393).
+ * Any member may be NULL (not wanted).  The arrays (same layout / precision / `mem` as the fields) are written by every
+ * following ab_session_compute() until ab_session_set_diagnostics(s, NULL, 0) switches them off again; with diagnostics on,
+ * a slightly heavier kernel instantiation runs (the default one does not carry them). */
+typedef struct ab_diag {
+    void *Cd, *Ch, *Ce, *t_zu, *q_zu, *Ubzu;                 /* transfer coefficients, theta/q adjusted to zu, bulk wind */
+    void *CdN, *ChN, *CeN, *z0, *u_star, *L, *UN10;          /* neutral coefficients, roughness, u*, Obukhov length, UN10 */
+    void *dT_cs, *dT_wl, *Hz_wl;                             /* skin: cool-skin / warm-layer increments, warm-layer depth */
+} ab_diag;
+int ab_session_set_diagnostics(ab_session *s, const ab_diag *d, int mem);
+
 /* Copy the persistent warm-layer state (planes dT_wl, Hz_wl, Qnt_ac, Tau_ac; ECMWF uses the
  * first two) to host doubles — diagnostics pdT_wl/pHz_wl of TURB_COARE3P6, mod_blk_coare3p6.f90:406-407. */
 int ab_session_get_wl_state(ab_session *s, double *state4n);

@@ -468,6 +468,8 @@ static void wl_ecmwf(double *st, double pQsw, double pQnsol, double pustar, doub
 /* ---- COARE 3.0 / 3.6: mod_blk_coare3p6.f90:123-413, mod_blk_coare3p0.f90:54-358 ------ */
 typedef struct {
     double Cd, Ch, Ce, t_zu, q_zu, Ubzu, T_s, q_s;
+    /* optional diagnostics of the TURB_* routines (CdN ChN CeN xz0 xu_star xL xUN10 pdT_cs pdT_wl pHz_wl) */
+    double CdN, ChN, CeN, z0, us, L, UN10, dT_cs, dT_wl, Hz_wl;
 } turb_out;
 
 static void turb_coare(int v36, double zt, double zu, double sst, double t_zt, double q_s_in, double q_zt,
@@ -492,12 +494,13 @@ static void turb_coare(int v36, double zt, double zu, double sst, double t_zt, d
     double znu_a = abo_visc_air(v36 ? t_zu : t_zt);  /* 3p6 :294 vs 3p0 :237 */
     double zdt = t_zu - T_s;  zdt = fsign(dmax(fabs(zdt), 1.E-09), zdt);
     double zdq = q_zu - q_s;  zdq = fsign(dmax(fabs(zdq), 1.E-12), zdq);
-    double zdT_cs = 0., zzta_t = 0.;
+    double zdT_cs = 0., zzta_t = 0., zlog_z0t_last = 0., z1oL_last = 0.;
 
     for (int jit = 1; jit <= nb_iter; ++jit) {
         double zus2 = zus * zus;
         double z1oL = abo_one_on_l(t_zu, q_zu, zus, zts, zqs);
         z1oL = fsign(dmin(fabs(z1oL), 200.), z1oL);
+        z1oL_last = z1oL;
         double zgust2 = Beta0 * Beta0 * zus2 * pow(dmax(-zi0 * z1oL / vkarmn, 0.), (2. / 3.));
         Ubzu = dmax(sqrt(zUzu * zUzu + zgust2), 0.2);
         double zzta_u = zu * z1oL;
@@ -520,6 +523,7 @@ static void turb_coare(int v36, double zt, double zu, double sst, double t_zt, d
         }
         zz0t = dmin(dmax(fabs(zz0t), 1.E-9), 1.);
         double zlog_z0t = log(zz0t);
+        zlog_z0t_last = zlog_z0t;
         double ztmp0 = abo_psi_h_coare(zzta_u);
         ztmp1 = vkarmn / (zlog_zu - zlog_z0t - ztmp0);
         zts = zdt * ztmp1;
@@ -561,6 +565,16 @@ static void turb_coare(int v36, double zt, double zu, double sst, double t_zt, d
     o->Ch = dmax(ztmp0 * zts / zdt, Cx_min);
     o->Ce = dmax(ztmp0 * zqs / zdq, Cx_min);
     o->t_zu = t_zu; o->q_zu = q_zu; o->Ubzu = Ubzu; o->T_s = T_s; o->q_s = q_s;
+    /* optional outputs, mod_blk_coare3p6.f90:392-407 (3p0 :337-352) */
+    ztmp0 = 1. / (zlog_zu - zlog_z0);
+    o->CdN = dmax(vkarmn2 * ztmp0 * ztmp0, Cx_min);
+    {
+        double zt1 = vkarmn2 * ztmp0 / (zlog_zu - zlog_z0t_last);
+        o->ChN = dmax(zt1, Cx_min);
+        o->CeN = dmax(zt1, Cx_min);
+    }
+    o->z0 = zz0; o->us = zus; o->L = 1. / z1oL_last; o->UN10 = zus / vkarmn * (zlog_10 - zlog_z0);
+    o->dT_cs = zdT_cs; o->dT_wl = l_skin ? wl[0] : 0.; o->Hz_wl = l_skin ? wl[1] : 0.;
 }
 
 /* ---- ECMWF: mod_blk_ecmwf.f90 ------------------------------------------------------ */
@@ -679,6 +693,16 @@ static void turb_ecmwf(double zt, double zu, double sst, double zt_zt, double q_
     o->Ch = dmax(vkarmn2 / (zFm * zFh), Cx_min);
     o->Ce = dmax(vkarmn2 / (zFm * zFq), Cx_min);
     o->t_zu = zt_zu; o->q_zu = zq_zu; o->Ubzu = zUbzu; o->T_s = zT_s; o->q_s = zq_s;
+    /* optional outputs, mod_blk_ecmwf.f90:362-377 */
+    {
+        double zt0 = 1. / (zlog_zu - zlog_z0);
+        double zt1 = vkarmn2 * zt0 / (zlog_zu - zlog_z0t);
+        o->CdN = dmax(vkarmn2 * zt0 * zt0, Cx_min);
+        o->ChN = dmax(zt1, Cx_min);
+        o->CeN = dmax(zt1, Cx_min);
+    }
+    o->z0 = zz0; o->us = zus; o->L = 1. / z1oL; o->UN10 = zus / vkarmn * (zlog_10 - zlog_z0);
+    o->dT_cs = zdT_cs; o->dT_wl = l_skin ? wl[0] : 0.; o->Hz_wl = l_skin ? wl[1] : 0.;
 }
 
 /* ---- NCAR: mod_blk_ncar.f90 -------------------------------------------------------- */
@@ -730,6 +754,7 @@ static void turb_ncar(double zt, double zu, double sst, double t_zt, double ssq,
     double zsqrt_Cd = zsqrt_CdN;
     double t_zu = dmax(t_zt, 180.);
     double q_zu = dmax(q_zt, 1.e-6);
+    double d_us = 0., d_1oL = 0., d_un10 = 0., d_chn = 0., d_cen = 0.;
     for (int jit = 1; jit <= nb_iter; ++jit) {
         double zdt = t_zu - sst;
         double zdq = q_zu - ssq;
@@ -761,9 +786,14 @@ static void turb_ncar(double zt, double zu, double sst, double t_zt, double ssq,
         double zCeN = 1.e-3 * (34.6 * zsqrt_CdN);
         Ch = dmax(zChN * ztmp2 / (1. + zChN * ztmp), Cx_min);
         Ce = dmax(zCeN * ztmp2 / (1. + zCeN * ztmp), Cx_min);
+        d_us = zus; d_1oL = z1oL; d_un10 = zUn10; d_chn = zChN; d_cen = zCeN;
     }
     o->Cd = Cd; o->Ch = Ch; o->Ce = Ce; o->t_zu = t_zu; o->q_zu = q_zu; o->Ubzu = Ubzu;
     o->T_s = sst; o->q_s = ssq;
+    /* optional outputs, mod_blk_ncar.f90:229-235 (z0_from_Cd without psi, mod_phymbl.f90:1349) */
+    o->CdN = zCdN; o->CeN = d_cen; o->ChN = d_chn; o->UN10 = d_un10; o->L = 1. / d_1oL; o->us = d_us;
+    o->z0 = dmin(zu * exp(-vkarmn / sqrt(zCdN)), z0_sea_max);
+    o->dT_cs = 0.; o->dT_wl = 0.; o->Hz_wl = 0.;
 }
 
 /* ---- ANDREAS: mod_blk_andreas.f90 -------------------------------------------------- */
@@ -824,7 +854,7 @@ static void turb_andreas(double zt, double zu, double psst, double pt_zt, double
     double t_star = pCh / ztmp0 * (pt_zu - psst);
     double q_star = pCe / ztmp0 * (pq_zu - pssq);
     double RiB = abo_ri_bulk(zu, psst, pt_zu, pssq, pq_zu, pUbzu);
-    double u_star = 0.;
+    double u_star = 0., d_z0 = 0., d_zeta = 0.;
     for (int jit = 1; jit <= nb_iter; ++jit) {
         if (RiB < rRi_max) u_star = abo_u_star_andreas(UN10);
         else u_star = sqrt(Cx_min) * pUbzu;
@@ -832,6 +862,7 @@ static void turb_andreas(double zt, double zu, double psst, double pt_zt, double
         ztmp0 = u_star / pUbzu;
         pCd = dmax(ztmp0 * ztmp0, Cx_min);
         double z0 = dmin(z0_from_cd_psi(zu, pCd, abo_psi_m_andreas(zeta_u)), z0_sea_max);
+        d_z0 = z0; d_zeta = zeta_u;
         ztmp0 = z0 * u_star / abo_visc_air(pt_zu);
         double ztmp1 = abo_z0tq_lkb(1, ztmp0, z0);
         double ztmp2 = abo_z0tq_lkb(2, ztmp0, z0);
@@ -856,16 +887,25 @@ static void turb_andreas(double zt, double zu, double psst, double pt_zt, double
     pCe = dmax(ztmp0 * q_star / ztmp2, rCs_min);
     o->Cd = pCd; o->Ch = pCh; o->Ce = pCe; o->t_zu = pt_zu; o->q_zu = pq_zu; o->Ubzu = pUbzu;
     o->T_s = psst; o->q_s = pssq;
+    /* optional outputs, mod_blk_andreas.f90:256-267 */
+    ztmp0 = 1. / log(zu / d_z0);
+    o->CdN = dmax(vkarmn2 * ztmp0 * ztmp0, Cx_min);
+    ztmp1 = d_z0 * u_star / abo_visc_air(pt_zu);
+    o->ChN = vkarmn2 * ztmp0 / log(zu / abo_z0tq_lkb(1, ztmp1, d_z0));
+    o->CeN = vkarmn2 * ztmp0 / log(zu / abo_z0tq_lkb(2, ztmp1, d_z0));
+    o->z0 = d_z0; o->us = u_star; o->L = zu / d_zeta;
+    o->UN10 = pUbzu - u_star / vkarmn * (log(zu / 10.) - abo_psi_m_andreas(d_zeta));
+    o->dT_cs = 0.; o->dT_wl = 0.; o->Hz_wl = 0.;
 }
 
 /* ---- aerobulk_compute: mod_aerobulk_compute.f90:22-213 ------------------------------ */
-int abo_compute(int algo, int jt, int nt, long n, double zt, double zu, int nb_iter,
-                int use_skin, int hum_type,
-                const double *sst, const double *t_zt, const double *hum_zt,
-                const double *u_zu, const double *v_zu, const double *slp,
-                const double *rad_sw, const double *rad_lw,
-                double *ql, double *qh, double *tau_x, double *tau_y, double *evap, double *t_s,
-                double *wl_state, int isecday_utc, const double *lon)
+int abo_compute_diag(int algo, int jt, int nt, long n, double zt, double zu, int nb_iter,
+                     int use_skin, int hum_type,
+                     const double *sst, const double *t_zt, const double *hum_zt,
+                     const double *u_zu, const double *v_zu, const double *slp,
+                     const double *rad_sw, const double *rad_lw,
+                     double *ql, double *qh, double *tau_x, double *tau_y, double *evap, double *t_s,
+                     double *wl_state, int isecday_utc, const double *lon, double *diag)
 {
     (void)nt;
     if (algo < ABO_COARE3P0 || algo > ABO_ANDREAS) return 2;
@@ -933,8 +973,25 @@ int abo_compute(int algo, int jt, int nt, long n, double zt, double zu, int nb_i
         }
         if (t_s) t_s[k] = o.T_s;                                              /* :206 */
         if (evap) evap[k] = zEvap;                                            /* :208 */
+        if (diag) {
+            const double d[16] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
+                                  o.dT_cs, o.dT_wl, o.Hz_wl};
+            for (int s = 0; s < 16; ++s) diag[(long)s * n + k] = d[s];
+        }
     }
     return rc;
+}
+
+int abo_compute(int algo, int jt, int nt, long n, double zt, double zu, int nb_iter,
+                int use_skin, int hum_type,
+                const double *sst, const double *t_zt, const double *hum_zt,
+                const double *u_zu, const double *v_zu, const double *slp,
+                const double *rad_sw, const double *rad_lw,
+                double *ql, double *qh, double *tau_x, double *tau_y, double *evap, double *t_s,
+                double *wl_state, int isecday_utc, const double *lon)
+{
+    return abo_compute_diag(algo, jt, nt, n, zt, zu, nb_iter, use_skin, hum_type, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw,
+                            rad_lw, ql, qh, tau_x, tau_y, evap, t_s, wl_state, isecday_utc, lon, NULL);
 }
 
 /* ---- AEROBULK_INIT host checks: mod_aerobulk.f90:104-153 ---------------------------- */

@@ -47,7 +47,15 @@ int abo_compute(int algo, int jt, int nt, long n, double zt, double zu, int nb_i
                 double *ql, double *qh, double *tau_x, double *tau_y, double *evap, double *t_s,
                 double *wl_state, int isecday_utc, const double *lon);
 
-/* OpenMP-free multi-threaded variant is not provided: the reference is single-threaded. */
+/* Same, plus the diagnostics the TURB_* routines return (mandatory and OPTIONAL outputs, e.g. mod_blk_coare3p6.f90:207-230):
+ * diag = 16 planes of n doubles: Cd Ch Ce t_zu q_zu Ubzu | CdN ChN CeN z0 u_star L UN10 | dT_cs dT_wl Hz_wl (NULL: skip). */
+int abo_compute_diag(int algo, int jt, int nt, long n, double zt, double zu, int nb_iter,
+                     int use_skin, int hum_type,
+                     const double *sst, const double *t_zt, const double *hum_zt,
+                     const double *u_zu, const double *v_zu, const double *slp,
+                     const double *rad_sw, const double *rad_lw,
+                     double *ql, double *qh, double *tau_x, double *tau_y, double *evap, double *t_s,
+                     double *wl_state, int isecday_utc, const double *lon, double *diag);
 
 /* AEROBULK_INIT host checks (mod_aerobulk.f90:24-160): mask, humidity type, unit ranges.
  * Returns 0 ok; negative error codes:

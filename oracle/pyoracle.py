@@ -29,6 +29,9 @@ REF_SO = os.path.join(HERE, "_ref", "libaerobulk_ref.so")
 ALGOS = {"coare3p0": 1, "coare3p6": 2, "ncar": 3, "ecmwf": 4, "andreas": 5}
 HUM = {"sh": 0, "dp": 1, "rh": 2}
 SKIN_ALGOS = ("coare3p0", "coare3p6", "ecmwf")
+# diagnostics of the TURB_* routines, in the plane order of abo_compute_diag / oracle/ref_turb_driver.f90
+DIAG_NAMES = ("Cd", "Ch", "Ce", "t_zu", "q_zu", "Ubzu", "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10", "dT_cs", "dT_wl", "Hz_wl")
+REF_TURB_EXE = os.path.join(HERE, "_ref", "ref_turb_driver.x")
 
 _dp = C.POINTER(C.c_double)
 
@@ -52,6 +55,8 @@ def lib():
         L.abo_compute.restype = C.c_int
         L.abo_compute.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, C.c_double, C.c_double, C.c_int,
                                   C.c_int, C.c_int] + [_dp] * 8 + [_dp] * 6 + [_dp, C.c_int, _dp]
+        L.abo_compute_diag.restype = C.c_int
+        L.abo_compute_diag.argtypes = L.abo_compute.argtypes + [_dp]
         L.abo_init_checks.restype = C.c_int
         L.abo_init_checks.argtypes = [C.c_long] + [_dp] * 8 + [C.POINTER(C.c_int), C.POINTER(C.c_long),
                                                                C.POINTER(C.c_int)]
@@ -96,14 +101,17 @@ class OracleSession:
         self.wl = np.zeros(4 * self.n)
 
     def compute(self, jt, zt, zu, niter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw=None, rad_lw=None,
-                isecday_utc=12, lon=None):
+                isecday_utc=12, lon=None, diag=False):
         n = self.n
         o = {k: np.empty(n) for k in ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")}
-        rc = lib().abo_compute(ALGOS[self.algo], jt, self.nt, n, zt, zu, niter, int(self.use_skin),
-                               HUM[self.hum_type], _p(sst), _p(t_zt), _p(hum_zt), _p(u_zu), _p(v_zu), _p(slp),
-                               _p(rad_sw), _p(rad_lw), _p(o["ql"]), _p(o["qh"]), _p(o["tau_x"]), _p(o["tau_y"]),
-                               _p(o["evap"]), _p(o["t_s"]), _p(self.wl), isecday_utc, _p(lon))
+        d = np.empty(16 * n) if diag else None
+        rc = lib().abo_compute_diag(ALGOS[self.algo], jt, self.nt, n, zt, zu, niter, int(self.use_skin),
+                                    HUM[self.hum_type], _p(sst), _p(t_zt), _p(hum_zt), _p(u_zu), _p(v_zu), _p(slp),
+                                    _p(rad_sw), _p(rad_lw), _p(o["ql"]), _p(o["qh"]), _p(o["tau_x"]), _p(o["tau_y"]),
+                                    _p(o["evap"]), _p(o["t_s"]), _p(self.wl), isecday_utc, _p(lon), _p(d))
         o["rc"] = rc
+        if diag:
+            o.update(dict(zip(DIAG_NAMES, d.reshape(16, n))))
         return o
 
 
@@ -176,6 +184,23 @@ def run_reference(algo, records, zt, zu, niter, use_skin=False, with_rad=None, t
             raise RuntimeError("reference aborted (STOP):\n" + pr.stdout[-2000:] + pr.stderr[-2000:])
         with open(fout, "rb") as fh:
             return pickle.load(fh)
+
+
+def run_reference_turb(algo, f, zt, zu, niter, use_skin=False):
+    """TURB_<algo> of the UNMODIFIED reference with all optional diagnostics (oracle/ref_turb_driver.f90, specific humidity,
+    one record).  `f` = dict of flat float64 fields; returns dict of DIAG_NAMES arrays."""
+    n = f["sst"].size
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        zero = np.zeros(n)
+        np.concatenate([np.ascontiguousarray(f.get(k, zero) if f.get(k) is not None else zero, dtype=np.float64)
+                        for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")]).tofile(fin)
+        pr = subprocess.run([REF_TURB_EXE, algo, "1" if use_skin else "0", str(int(niter)), repr(float(zt)), repr(float(zu)),
+                             str(n), fin, fout], capture_output=True, text=True, timeout=3600)
+        if not os.path.exists(fout):
+            raise RuntimeError("reference TURB driver failed:\n" + pr.stdout[-2000:] + pr.stderr[-2000:])
+        d = np.fromfile(fout, dtype=np.float64).reshape(16, n)
+    return dict(zip(DIAG_NAMES, d))
 
 
 def ref_scalar(symbol, *args):

@@ -104,6 +104,22 @@ def main():
     with open(os.path.join(OUT, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1)
 
+    # TURB_* diagnostics (mandatory + OPTIONAL outputs) from the reference's routines called directly
+    # (oracle/ref_turb_driver.f90), first 1024 cells of the sweep
+    nd = 1024
+    fd = {k: np.ascontiguousarray(v[:nd]) for k, v in f.items()}
+    diag_manifest = []
+    for algo in po.ALGOS:
+        for skin in ((False, True) if algo in po.SKIN_ALGOS else (False,)):
+            for zt, niter in ((2.0, 5), (10.0, 8)):
+                r = po.run_reference_turb(algo, fd, zt, 10.0, niter, skin)
+                name = f"diag_{algo}_{'skin' if skin else 'noskin'}_n{niter}_zt{int(zt)}"
+                np.savez_compressed(os.path.join(OUT, name + ".npz"), **r)
+                diag_manifest.append(dict(name=name, algo=algo, zt=zt, zu=10.0, niter=niter, skin=skin, n=nd))
+                print("wrote", name)
+    with open(os.path.join(OUT, "diag_manifest.json"), "w") as fh:
+        json.dump(diag_manifest, fh, indent=1)
+
     # the reference's own captured example output doc/ex_ab.dat (nb_iter=50, 7 significant digits):
     # inputs from src/tests/example_call_aerobulk.f90:29-44, printed values from doc/ex_ab.dat:28-33,62-67,96-101,130-134,163-167
     ex = dict(
