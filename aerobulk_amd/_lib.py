@@ -27,6 +27,12 @@ class Diag(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in NAMES]
 
 
+class TurbFields(C.Structure):
+    """ab_turb_fields: the mandatory arguments of a TURB_* routine."""
+    NAMES = ("T_s", "theta_zt", "q_s", "q_zt", "U_zu", "Qsw", "rad_lw", "slp", "Cd", "Ch", "Ce", "t_zu", "q_zu", "Ubzu")
+    _fields_ = [(n, C.c_void_p) for n in NAMES]
+
+
 # every symbol include/aerobulk_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ab_algo_from_string": (C.c_int, [C.c_char_p, C.c_int]),
@@ -41,6 +47,9 @@ SYMBOLS = {
     "ab_session_init_apply": (C.c_int, [vp, dp, C.c_int, C.POINTER(InitReport)]),
     "ab_session_set_humidity": (C.c_int, [vp, C.c_int]),
     "ab_session_set_diagnostics": (C.c_int, [vp, C.POINTER(Diag), C.c_int]),
+    "ab_session_turb": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(TurbFields), C.c_int, vp]),
+    "ab_turb": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, dp] + [dp] * 8 + [dp] * 6
+                + [C.POINTER(Diag), C.c_long, C.c_long]),
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),
     "ab_session_check": (C.c_int, [vp]),
     "ab_session_set_solar_time": (C.c_int, [vp, C.c_int, vp, C.c_int]),

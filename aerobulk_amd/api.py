@@ -194,6 +194,41 @@ class Session:
             self.check()
         return out
 
+    # -- TURB_<algo> itself (mod_blk_coare3p6.f90:123-131 and siblings)
+    def turb(self, kt, zt, zu, T_s, theta_zt, q_s, q_zt, U_zu, l_use_cs=False, l_use_wl=False, Qsw=None, rad_lw=None, slp=None,
+             nb_iter=5, stream=None):
+        """One call of the session algorithm's TURB_* routine.  `T_s` and `q_s` are updated IN PLACE when a skin scheme is on
+        (INTENT(inout) in the reference); returns the dict of the mandatory outputs Cd Ch Ce t_zu q_zu Ubzu.  OPTIONAL
+        outputs: set_diagnostics().  Arrays: numpy (host) or torch (device), flat, session precision."""
+        dev = _is_torch(T_s)
+        for a in (T_s, q_s):
+            if not dev and not (isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"] and a.dtype == self.dtype):
+                raise ValueError("T_s / q_s are updated in place: contiguous arrays of the session precision required")
+        f = _lib.TurbFields()
+        keep = []
+        for k, a in (("T_s", T_s), ("theta_zt", theta_zt), ("q_s", q_s), ("q_zt", q_zt), ("U_zu", U_zu), ("Qsw", Qsw),
+                     ("rad_lw", rad_lw), ("slp", slp)):
+            p, kp = _ptr(a, self.dtype, self.n)
+            keep.append(kp)
+            setattr(f, k, p)
+        if dev:
+            import torch
+            out = {k: torch.empty(self.n, dtype=T_s.dtype, device=T_s.device) for k in _lib.Diag.NAMES[:6]}
+            if stream is None:
+                stream = torch.cuda.current_stream().cuda_stream
+        else:
+            out = {k: np.empty(self.n, dtype=self.dtype) for k in _lib.Diag.NAMES[:6]}
+        for k, a in out.items():
+            setattr(f, k, _ptr(a, self.dtype, self.n)[0])
+        rc = self._lib.ab_session_turb(self._h, int(kt), float(zt), float(zu), int(bool(l_use_cs)), int(bool(l_use_wl)),
+                                       int(nb_iter), C.byref(f), AB_MEM_DEVICE if dev else AB_MEM_HOST, C.c_void_p(stream or 0))
+        if rc:
+            _raise(rc)
+        if dev:
+            import torch
+            torch.cuda.synchronize()
+        return out
+
     def check(self):
         rc = self._lib.ab_session_check(self._h)
         if rc:

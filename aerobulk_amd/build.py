@@ -36,7 +36,7 @@ def _run(cmd, **kw):
 
 
 def build_engine(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_runtime.hip", "ab_cxx.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_runtime.hip", "ab_cxx.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [
         os.path.join(ROOT, "include", "aerobulk_amd.h"), os.path.join(ROOT, "include", "aerobulk.hpp"), os.path.abspath(__file__)]
     if not force and not _newer(LIB, deps):
@@ -68,6 +68,14 @@ def build_fortran_host(force=False):
         _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-c", src, "-o", os.path.join(fdir, "mod_aerobulk.o")])
         _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, drv, os.path.join(fdir, "mod_aerobulk.o"),
               "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", exe])
+    # TURB_* modules (mod_blk_coare3p6 ...) + the station time-series driver
+    tsrc = os.path.join(fdir, "mod_blk_turb.f90")
+    tdrv = os.path.join(fdir, "turb_series_driver.f90")
+    texe = os.path.join(fdir, "turb_series_driver.x")
+    if force or _newer(texe, [src, tsrc, tdrv, LIB]):
+        _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-I", fdir, "-c", tsrc, "-o", os.path.join(fdir, "mod_blk_turb.o")])
+        _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, tdrv, os.path.join(fdir, "mod_blk_turb.o"),
+              os.path.join(fdir, "mod_aerobulk.o"), "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", texe])
     return exe
 
 

@@ -10,10 +10,10 @@
 // ≈100 B/cell stream is hidden under thousands of VALU cycles per cell by wave-level parallelism.
 #include "ab_kernels.hpp"
 #include "ab_physics.hpp"
+#include "ab_launch.hpp"
 
 namespace ab {
 
-constexpr int kBlock = 256;  // 4 waves of 64 lanes, one per SIMD
 // Which wave-uniform values are laundered into VGPRs (see flux_kernel), measured on the MI355X (profiles/r1_notes.md):
 // heights -2 % (skin) / -5 % (no skin); output addresses -4 % (no skin) and -1 % (skin) PROVIDED the kernel stays at
 // 3 waves/SIMD (<= 168 VGPRs, enforced by __launch_bounds__ below): at 170 VGPRs (2 waves/SIMD) the skin kernel loses 9 %.
@@ -107,10 +107,11 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
 
     // ---- TURB_<algo>, mod_aerobulk_compute.f90:129-176
     CellOut<R> o;
-    if (ALGO == 1) turb_coare<R, false, SKIN, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 2) turb_coare<R, true, SKIN, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
+    constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
+    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
     else if (ALGO == 3) turb_ncar<R, DIAG>(hh, in, a.nb_iter, o);
-    else if (ALGO == 4) turb_ecmwf<R, SKIN, DIAG>(hh, in, a.nb_iter, wl, o);
+    else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG>(hh, in, a.nb_iter, wl, o);
     else turb_andreas<R, DIAG>(hh, in, a.nb_iter, o);
     if (DIAG) {
         const R d[16] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
@@ -142,32 +143,6 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
     *pty = ty;
     if (pev) *pev = zEvap;                                                     // :208
     if (pts) *pts = o.T_s;                                                     // :206
-}
-
-template <class R> static Heights<R> make_heights(double zt, double zu)
-{
-    Heights<R> h;
-    h.zt = (R)zt;
-    h.zu = (R)zu;
-    h.log_zt = (R)log(zt);
-    h.log_zu = (R)log(zu);
-    h.log_10 = (R)log(10.);
-    h.log_ztu = (R)log(zt / zu);
-    h.log_zu10 = (R)log(zu / 10.);
-    h.fg_ca = (R)(0.035 * log(10. / 0.0001) / log(zu / 0.0001));  // mod_common_coare.f90:107
-    h.inv_zu = (R)(1. / zu);
-    h.zt_o_zu = (R)(zt / zu);
-    h.zt_eq_zu = (fabs(zu - zt) < 0.01) ? 1 : 0;
-    return h;
-}
-
-// host copy of WL_COARE's solar-time test for uniform longitude 0 (mod_skin_coare.f90:146-163)
-static int dawn_at_lon0(int isd)
-{
-    int s = isd % 86400;
-    if (s < 0) s += 86400;
-    const double hr = (double)s / 3600.;
-    return (hr > 4.) && (hr <= 6.5);
 }
 
 template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)

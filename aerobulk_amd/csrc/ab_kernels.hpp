@@ -29,6 +29,21 @@ struct FluxCall {
 
 hipError_t launch_flux(const FluxCall &c, hipStream_t stream);
 
+// One call of a TURB_<algo> routine (e.g. mod_blk_coare3p6.f90:123-131): no pre-processing, no bulk formula.
+struct TurbCall {
+    void *T_s, *q_s;                         // INOUT: overwritten with the skin values when skin != 0
+    const void *theta_zt, *q_zt, *U_zu;      // potential temperature and specific humidity at zt, scalar wind at zu
+    const void *qsw, *rad_lw, *slp, *lon;    // net solar, downwelling LW, SLP (skin != 0 only); lon: WL_COARE solar time
+    void *out[16];                           // Cd Ch Ce t_zu q_zu Ubzu (required) | CdN..UN10, dT_cs dT_wl Hz_wl (nullptr: skip)
+    void *wl[4];
+    long n;
+    double zt, zu;
+    int algo;
+    int skin;        // bit 0: l_use_cs, bit 1: l_use_wl
+    int f32, nb_iter, wl_load, wl_store, isecday;
+};
+hipError_t launch_turb(const TurbCall &c, hipStream_t stream);
+
 // AEROBULK_INIT statistics (mod_aerobulk.f90:104-153): per-block partial reductions.
 //  fields order: 0 sst,1 t_air,2 slp,3 u,4 v,5 wnd,6 hum,7 rad_sw,8 rad_lw
 //  partials layout per block: [count, then for each of 9 fields: sum, min, max] = 28 doubles

@@ -501,9 +501,11 @@ template <class R> struct CellOut {
 };
 
 // ---------------------------------------------------------------- TURB_COARE3P6 / turb_coare3p0
-// mod_blk_coare3p6.f90:123-413, mod_blk_coare3p0.f90:54-358.  V36 selects the version; SKIN = cool-skin AND
-// warm-layer (aerobulk_compute always switches both on together, mod_aerobulk_compute.f90:133,144).
-template <class R, bool V36, bool SKIN, bool DIAG = false>
+// mod_blk_coare3p6.f90:123-413, mod_blk_coare3p0.f90:54-358.  V36 selects the version; SKIN is a bit mask: bit 0 =
+// l_use_cs (cool skin), bit 1 = l_use_wl (warm layer).  aerobulk_compute always switches both on together
+// (mod_aerobulk_compute.f90:133,144: SKIN = 3); callers of TURB_* may choose either (ab_session_turb).
+constexpr int kSkinCS = 1, kSkinWL = 2, kSkinBoth = 3;
+template <class R, bool V36, int SKIN, bool DIAG = false>
 __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
                                            bool dawn, CellOut<R> &o)
 {
@@ -516,14 +518,17 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
     R T_s = in.sst, q_s = in.ssq;
     R zalpha = R(0.);
     WlCoareCell<R> wc{R(0.), R(0.), dawn};
+    constexpr bool CS = (SKIN & kSkinCS) != 0, WL = (SKIN & kSkinWL) != 0;
     if (SKIN) {
-        T_s = T_s - R(0.25);                                           // :274
+        if (CS) T_s = T_s - R(0.25);                                   // :274
         q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);  // :275
         zalpha = alpha_sw(xSST);                                       // hoisted from CS_COARE :81 / WL_COARE :153
-        const R Rich0 = R(0.65);
-        wc.zcd1 = M::sqrt(M::div(R(2.) * Rich0 * K<R>::rCp0_w, zalpha * K<R>::grav * K<R>::rho0_w));   // :155
-        wc.zcd2 = M::sqrt(R(2.) * zalpha * K<R>::grav * R(1. / (0.65 * 1025.)))
-                  * R(1. / 271219.5770957547);                        // / rCp0_w**1.5 :156
+        if (WL) {
+            const R Rich0 = R(0.65);
+            wc.zcd1 = M::sqrt(M::div(R(2.) * Rich0 * K<R>::rCp0_w, zalpha * K<R>::grav * K<R>::rho0_w));   // :155
+            wc.zcd2 = M::sqrt(R(2.) * zalpha * K<R>::grav * R(1. / (0.65 * 1025.)))
+                      * R(1. / 271219.5770957547);                    // / rCp0_w**1.5 :156
+        }
     }
     R zus, zts, zqs, t_zu, q_zu, Ubzu, zz0;
     first_guess_coare(h, T_s, in.theta_zt, q_s, in.q_zt, zUzu, V36 ? charn_coare3p6(zUzu) : charn_coare3p0(zUzu),
@@ -575,19 +580,22 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             t_zu = in.theta_zt;
             q_zu = in.q_zt;
         }
-        if (SKIN) {
+        if (CS) {
             R zQns, zTau, zQlat;
             update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
                              zQlat);                                   // :355-356
             zdT_cs = cool_skin<R, true>(in.qsw, zQns, zus, zalpha, zQlat);  // :358
             T_s = xSST + zdT_cs;
-            T_s = T_s + wl[0];                                         // :360-361
+            if (WL) T_s = T_s + wl[0];                                 // :360-361
             q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
+        }
+        if (WL) {
+            R zQns, zTau, zQlat;
             update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
                              zQlat);                                   // :367-368
             wl_coare(wl, wc, in.qsw, zQns, zTau, (nb_iter % jit) == 0);  // :370  iwait = MOD(nb_iter,jit)
             T_s = xSST + wl[0];
-            T_s = T_s + zdT_cs;                                        // :373-374
+            if (CS) T_s = T_s + zdT_cs;                                // :373-374
             q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
         }
         if (!V36 || SKIN || !h.zt_eq_zu) {                             // :378-381 (3p0 :317-318 unconditional)
@@ -606,7 +614,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
         o.ChN = vmax(M::div(K<R>::vkarmn2 * zi, h.log_zu - d_lz0t), K<R>::Cx_min);
         o.CeN = o.ChN;
         o.z0 = zz0; o.us = zus; o.L = M::rcp(d_1oL); o.UN10 = zus * K<R>::inv_vk * (h.log_10 - zlog_z0);
-        o.dT_cs = zdT_cs; o.dT_wl = SKIN ? wl[0] : R(0.); o.Hz_wl = SKIN ? wl[1] : R(0.);
+        o.dT_cs = zdT_cs; o.dT_wl = (SKIN & kSkinWL) ? wl[0] : R(0.); o.Hz_wl = (SKIN & kSkinWL) ? wl[1] : R(0.);
     }
 }
 
@@ -638,7 +646,7 @@ template <class R> __device__ __forceinline__ R psi_m_ecmwf(R z) { R m; psi_ecmw
 template <class R> __device__ __forceinline__ R psi_h_ecmwf(R z) { R v; psi_ecmwf<R>(z, nullptr, &v); return v; }
 
 // turb_ecmwf :63-383
-template <class R, bool SKIN, bool DIAG = false>
+template <class R, int SKIN, bool DIAG = false>
 __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
                                            CellOut<R> &o)
 {
@@ -649,8 +657,9 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
     const R zUzu = in.wnd, zSST = in.sst;
     R zT_s = in.sst, zq_s = in.ssq;
     R zalpha = R(0.);
+    constexpr bool CS = (SKIN & kSkinCS) != 0, WL = (SKIN & kSkinWL) != 0;
     if (SKIN) {
-        zT_s = zT_s - R(0.25);                                          // :214
+        if (CS) zT_s = zT_s - R(0.25);                                  // :214
         zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
         zalpha = alpha_sw(zSST);
     }
@@ -709,19 +718,22 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
         zq_zu = vmax(in.q_zt - zm_ztzu * zqs * K<R>::inv_vk * ztmp1, R(0.));
         zFm = h.log_zu - zlog_z0 - zpsi_m_u + zpsi_m_z0;                // :316-317
         zFh = h.log_zu - zlog_z0t - zpsi_h_u + zpsi_h_z0t;
-        if (SKIN) {
+        if (CS) {
             R zQns, zTau, zQlat;
             update_qnsol_tau(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
                              zQlat);                                    // :321-322
             zdT_cs = cool_skin<R, false>(in.qsw, zQns, zus, zalpha, R(0.));  // :324
             zT_s = zSST + zdT_cs;
-            zT_s = zT_s + wl[0];
+            if (WL) zT_s = zT_s + wl[0];
             zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
+        }
+        if (WL) {
+            R zQns, zTau, zQlat;
             update_qnsol_tau(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
                              zQlat);                                    // :333-334
             wl_ecmwf(wl[0], wl[1], in.qsw, zQns, zus, zalpha);          // :335
             zT_s = zSST + wl[0];
-            zT_s = zT_s + zdT_cs;
+            if (CS) zT_s = zT_s + zdT_cs;
             zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
         }
         zdt = sfloor(zt_zu - zT_s, R(1.E-09));                          // :342-343
@@ -739,7 +751,7 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
         o.ChN = vmax(M::div(K<R>::vkarmn2 * zi, h.log_zu - zlog_z0t), K<R>::Cx_min);
         o.CeN = o.ChN;
         o.z0 = zz0; o.us = zus; o.L = M::rcp(z1oL); o.UN10 = zus * K<R>::inv_vk * (h.log_10 - zlog_z0);
-        o.dT_cs = zdT_cs; o.dT_wl = SKIN ? wl[0] : R(0.); o.Hz_wl = SKIN ? wl[1] : R(0.);
+        o.dT_cs = zdT_cs; o.dT_wl = (SKIN & kSkinWL) ? wl[0] : R(0.); o.Hz_wl = (SKIN & kSkinWL) ? wl[1] : R(0.);
     }
 }
 

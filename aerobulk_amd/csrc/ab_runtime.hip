@@ -509,6 +509,85 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     return AB_OK;
 }
 
+int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int use_wl, int nb_iter,
+                    const ab_turb_fields *f, int mem, void *stream)
+{
+    if (!s || !f) return fail(AB_ERR_ARG, "ab_session_turb: NULL argument");
+    if (kt < 1) return fail(AB_ERR_JT, "TURB_%s => kt < 1 !??", ab_algo_name(s->algo));
+    if (nb_iter < 0) return fail(AB_ERR_ARG, "nb_iter < 0");
+    if (!f->T_s || !f->theta_zt || !f->q_s || !f->q_zt || !f->U_zu) return fail(AB_ERR_ARG, "ab_session_turb: NULL input field");
+    if (!f->Cd || !f->Ch || !f->Ce || !f->t_zu || !f->q_zu || !f->Ubzu) return fail(AB_ERR_ARG, "ab_session_turb: NULL output field");
+    const int skin = (use_cs ? 1 : 0) | (use_wl ? 2 : 0);
+    if (skin && !algo_has_skin(s->algo))
+        return fail(AB_ERR_SKIN_ALGO, "TURB_%s has no cool-skin / warm-layer scheme", ab_algo_name(s->algo));
+    if (skin && (!f->Qsw || !f->rad_lw || !f->slp))   // mod_blk_coare3p6.f90:263-269
+        return fail(AB_ERR_SKIN_NORAD, "you need to provide Qsw, rad_lw & slp to use cool-skin / warm-layer param!");
+    AB_HIP(hipSetDevice(s->device));
+    const size_t bytes = s->esz * (size_t)s->n;
+    if (use_wl) {
+        const int np = (s->algo == AB_ALGO_ECMWF) ? 2 : 4;
+        if (kt > 1 && !s->wl[0]) return fail(AB_ERR_STATE, "warm-layer state: kt=%d requested before kt=1", kt);
+        for (int p = 0; p < np; ++p)
+            if (!s->wl[p]) AB_HIP(hipMalloc(&s->wl[p], bytes));
+    }
+    hipStream_t st = (mem == AB_MEM_HOST) ? s->stream : (hipStream_t)stream;
+    const void *hin[8] = {f->T_s, f->theta_zt, f->q_s, f->q_zt, f->U_zu, skin ? f->Qsw : nullptr, skin ? f->rad_lw : nullptr,
+                          skin ? f->slp : nullptr};
+    void *hout[6] = {f->Cd, f->Ch, f->Ce, f->t_zu, f->q_zu, f->Ubzu};
+    const void *din[8];
+    void *dout[6];
+    if (mem == AB_MEM_HOST) {
+        int rc = stage_inputs(s, hin, din);
+        if (rc) return rc;
+        for (int i = 0; i < 6; ++i) {
+            if (!s->stage_out[i]) AB_HIP(hipMalloc(&s->stage_out[i], bytes));
+            dout[i] = s->stage_out[i];
+        }
+    } else {
+        for (int i = 0; i < 8; ++i) din[i] = hin[i];
+        for (int i = 0; i < 6; ++i) dout[i] = hout[i];
+    }
+    ab::TurbCall c;
+    memset(&c, 0, sizeof c);
+    c.T_s = const_cast<void *>(din[0]); c.theta_zt = din[1]; c.q_s = const_cast<void *>(din[2]); c.q_zt = din[3]; c.U_zu = din[4];
+    c.qsw = din[5]; c.rad_lw = din[6]; c.slp = din[7]; c.lon = s->d_lon;
+    for (int i = 0; i < 6; ++i) c.out[i] = dout[i];
+    if (s->diag_on) {
+        for (int i = 6; i < 16; ++i) {
+            if (!s->diag_user[i]) continue;
+            if (s->diag_mem == AB_MEM_DEVICE) { c.out[i] = s->diag_user[i]; continue; }
+            if (!s->diag_dev[i]) AB_HIP(hipMalloc(&s->diag_dev[i], bytes));
+            c.out[i] = s->diag_dev[i];
+        }
+    }
+    for (int p = 0; p < 4; ++p) c.wl[p] = s->wl[p];
+    c.n = s->n; c.zt = zt; c.zu = zu;
+    c.algo = s->algo; c.skin = skin; c.f32 = s->f32; c.nb_iter = nb_iter;
+    c.wl_load = (use_wl && kt > 1) ? 1 : 0;
+    c.wl_store = use_wl ? 1 : 0;
+    c.isecday = s->isecday;
+    AB_HIP(hipEventRecord(s->ev0, st));
+    AB_HIP(ab::launch_turb(c, st));
+    AB_HIP(hipEventRecord(s->ev1, st));
+    s->timed = true;
+    s->last_stream = st;
+    s->last_jt = kt;
+    if (s->diag_on && s->diag_mem == AB_MEM_HOST) {
+        for (int i = 6; i < 16; ++i)
+            if (s->diag_user[i]) AB_HIP(hipMemcpyAsync(s->diag_user[i], s->diag_dev[i], bytes, hipMemcpyDeviceToHost, st));
+        if (mem != AB_MEM_HOST) AB_HIP(hipStreamSynchronize(st));
+    }
+    if (mem == AB_MEM_HOST) {
+        for (int i = 0; i < 6; ++i) AB_HIP(hipMemcpyAsync(hout[i], dout[i], bytes, hipMemcpyDeviceToHost, st));
+        if (skin) {
+            AB_HIP(hipMemcpyAsync(f->T_s, din[0], bytes, hipMemcpyDeviceToHost, st));
+            AB_HIP(hipMemcpyAsync(f->q_s, din[2], bytes, hipMemcpyDeviceToHost, st));
+        }
+        AB_HIP(hipStreamSynchronize(st));
+    }
+    return AB_OK;
+}
+
 int ab_session_check(ab_session *s)
 {
     if (!s) return fail(AB_ERR_ARG, "NULL session");
@@ -627,6 +706,42 @@ int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double
     // rad present but l_use_skin false => no skin, T_s = sst (mod_aerobulk_compute.f90:132,206)
     return ab_session_compute(g_sess, jt, zt, zu, g_nb_iter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, ql, qh,
                               tau_x, tau_y, evap, lsrad ? t_s : nullptr, AB_MEM_HOST, nullptr);
+}
+
+// TURB_* on process-global state: one hidden session per algorithm (the reference's module SAVE arrays)
+static ab_session *g_turb[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int nb_iter, int isecday_utc, const double *lon,
+            double *T_s, const double *theta_zt, double *q_s, const double *q_zt, const double *U_zu, const double *Qsw,
+            const double *rad_lw, const double *slp, double *Cd, double *Ch, double *Ce, double *t_zu, double *q_zu,
+            double *Ubzu, const ab_diag *opt, long ni, long nj)
+{
+    if (algo < AB_ALGO_COARE3P0 || algo > AB_ALGO_ANDREAS) return fail(AB_ERR_ALGO, "bulk algorithm id %d is unknown!!!", algo);
+    ab_session *&s = g_turb[algo];
+    if (s && (s->ni != ni || s->nj != nj)) {
+        if (kt > 1 && use_wl) return fail(AB_ERR_STATE, "TURB_%s: shape changed between time steps", ab_algo_name(algo));
+        ab_session_destroy(s);
+        s = nullptr;
+    }
+    if (!s) {
+        int rc = ab_session_create(&s, algo, ni, nj, 1, 0, AB_F64, -1);
+        if (rc) return rc;
+    }
+    int rc = ab_session_set_solar_time(s, isecday_utc, (use_wl && algo != AB_ALGO_ECMWF) ? lon : nullptr, AB_MEM_HOST);
+    if (rc) return rc;
+    ab_diag d;
+    memset(&d, 0, sizeof d);
+    if (opt) {
+        d = *opt;
+        d.Cd = d.Ch = d.Ce = d.t_zu = d.q_zu = d.Ubzu = nullptr;
+    }
+    rc = ab_session_set_diagnostics(s, opt ? &d : nullptr, AB_MEM_HOST);
+    if (rc) return rc;
+    ab_turb_fields f;
+    f.T_s = T_s; f.theta_zt = theta_zt; f.q_s = q_s; f.q_zt = q_zt; f.U_zu = U_zu;
+    f.Qsw = Qsw; f.rad_lw = rad_lw; f.slp = slp;
+    f.Cd = Cd; f.Ch = Ch; f.Ce = Ce; f.t_zu = t_zu; f.q_zu = q_zu; f.Ubzu = Ubzu;
+    return ab_session_turb(s, kt, zt, zu, use_cs, use_wl, nb_iter, &f, AB_MEM_HOST, nullptr);
 }
 
 static void stop_like_fortran(int rc)

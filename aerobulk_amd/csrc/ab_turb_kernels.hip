@@ -1,0 +1,123 @@
+// ab_turb_kernels.hip — the TURB_<algo> routines as stand-alone kernels (gfx950).
+//
+// turb_kernel<R,ALGO,SKIN>: what a caller of TURB_COARE3P6 / turb_coare3p0 / turb_ecmwf / turb_ncar / turb_andreas gets
+// (mod_blk_coare3p6.f90:123-131, mod_blk_coare3p0.f90:54, mod_blk_ecmwf.f90:63, mod_blk_ncar.f90:57, mod_blk_andreas.f90:66):
+// transfer coefficients, air temperature / humidity adjusted to zu, bulk wind, the OPTIONAL diagnostics, and T_s / q_s
+// updated in place by the cool-skin (bit 0 of SKIN) and / or warm-layer (bit 1) scheme.  This is the entry the reference's
+// station drivers use (tests/test_aerobulk_buoy_series_oce.f90:452-487), with the real solar time of WL_COARE.
+// Same per-cell physics (ab_physics.hpp) and the same one-lane-per-cell streaming layout as flux_kernel (ab_kernels.hip);
+// the lean flux kernels are not touched by this file.
+#include "ab_kernels.hpp"
+#include "ab_physics.hpp"
+#include "ab_launch.hpp"
+
+namespace ab {
+
+template <class R> struct TurbArgs {
+    R *T_s, *q_s;
+    const R *theta_zt, *q_zt, *U_zu, *qsw, *rad_lw, *slp, *lon;
+    R *out[16];
+    R *wl0, *wl1, *wl2, *wl3;
+    long n;
+    Heights<R> h;
+    int nb_iter, wl_load, wl_store, isecday, dawn_uniform;
+};
+
+template <class R, int ALGO, int SKIN>
+__global__ void __launch_bounds__(kBlock) turb_kernel(const TurbArgs<R> a)
+{
+    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= a.n) return;
+    constexpr bool WL = (SKIN & kSkinWL) != 0;
+    CellIn<R> in;
+    in.sst = a.T_s[k];
+    in.theta_zt = a.theta_zt[k];
+    in.ssq = a.q_s[k];
+    in.q_zt = a.q_zt[k];
+    in.wnd = a.U_zu[k];
+    in.slp = SKIN ? a.slp[k] : R(101000.);
+    in.qsw = SKIN ? a.qsw[k] : R(0.);
+    in.rlw = SKIN ? a.rad_lw[k] : R(0.);
+
+    R wl[4] = {R(0.), R(0.), R(0.), R(0.)};
+    bool dawn = false;
+    if (WL) {
+        if (a.wl_load) {
+            wl[0] = a.wl0[k];
+            wl[1] = a.wl1[k];
+            if (ALGO != 4) { wl[2] = a.wl2[k]; wl[3] = a.wl3[k]; }
+        } else {  // COARE3Px_INIT mod_blk_coare3p6.f90:84-87 ; ECMWF_INIT mod_blk_ecmwf.f90:403-404
+            wl[1] = (ALGO == 4) ? R(3.) : R(20.);
+        }
+        if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>(a.lon[k], a.isecday) : (a.dawn_uniform != 0);
+    }
+
+    CellOut<R> o;
+    if (ALGO == 1) turb_coare<R, false, SKIN, true>(a.h, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 2) turb_coare<R, true, SKIN, true>(a.h, in, a.nb_iter, wl, dawn, o);
+    else if (ALGO == 3) turb_ncar<R, true>(a.h, in, a.nb_iter, o);
+    else if (ALGO == 4) turb_ecmwf<R, SKIN, true>(a.h, in, a.nb_iter, wl, o);
+    else turb_andreas<R, true>(a.h, in, a.nb_iter, o);
+
+    const R d[16] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
+                     o.dT_cs, o.dT_wl, o.Hz_wl};
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (a.out[i]) a.out[i][k] = d[i];
+    if (SKIN) {   // T_s, q_s are INTENT(inout): skin temperature and its saturation humidity on return
+        a.T_s[k] = o.T_s;
+        a.q_s[k] = o.q_s;
+    }
+    if (WL && a.wl_store) {
+        a.wl0[k] = wl[0];
+        a.wl1[k] = wl[1];
+        if (ALGO != 4) { a.wl2[k] = wl[2]; a.wl3[k] = wl[3]; }
+    }
+}
+
+template <class R, int ALGO, int SKIN> static hipError_t launch_t(const TurbCall &c, hipStream_t stream)
+{
+    TurbArgs<R> a;
+    a.T_s = (R *)c.T_s; a.q_s = (R *)c.q_s;
+    a.theta_zt = (const R *)c.theta_zt; a.q_zt = (const R *)c.q_zt; a.U_zu = (const R *)c.U_zu;
+    a.qsw = (const R *)c.qsw; a.rad_lw = (const R *)c.rad_lw; a.slp = (const R *)c.slp; a.lon = (const R *)c.lon;
+    for (int i = 0; i < 16; ++i) a.out[i] = (R *)c.out[i];
+    a.wl0 = (R *)c.wl[0]; a.wl1 = (R *)c.wl[1]; a.wl2 = (R *)c.wl[2]; a.wl3 = (R *)c.wl[3];
+    a.n = c.n;
+    a.h = make_heights<R>(c.zt, c.zu);
+    a.nb_iter = c.nb_iter; a.wl_load = c.wl_load; a.wl_store = c.wl_store; a.isecday = c.isecday;
+    a.dawn_uniform = dawn_at_lon0(c.isecday);
+    const long nblk = (c.n + kBlock - 1) / kBlock;
+    if (nblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL((turb_kernel<R, ALGO, SKIN>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <class R, int ALGO> static hipError_t launch_s(const TurbCall &c, hipStream_t s)
+{
+    switch (c.skin & 3) {
+    case 0: return launch_t<R, ALGO, 0>(c, s);
+    case 1: return launch_t<R, ALGO, kSkinCS>(c, s);
+    case 2: return launch_t<R, ALGO, kSkinWL>(c, s);
+    default: return launch_t<R, ALGO, kSkinBoth>(c, s);
+    }
+}
+
+template <class R> static hipError_t launch_r(const TurbCall &c, hipStream_t s)
+{
+    switch (c.algo) {
+    case 1: return launch_s<R, 1>(c, s);
+    case 2: return launch_s<R, 2>(c, s);
+    case 3: return (c.skin & 3) ? hipErrorInvalidValue : launch_t<R, 3, 0>(c, s);
+    case 4: return launch_s<R, 4>(c, s);
+    case 5: return (c.skin & 3) ? hipErrorInvalidValue : launch_t<R, 5, 0>(c, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_turb(const TurbCall &c, hipStream_t stream)
+{
+    return c.f32 ? launch_r<float>(c, stream) : launch_r<double>(c, stream);
+}
+
+}  // namespace ab

@@ -23,13 +23,16 @@ MODULE mod_const
    REAL(wp), PARAMETER :: rt0  = 273.15_wp   ! freezing point of fresh water [K]
    REAL(wp), PARAMETER :: grav = 9.8_wp
    REAL(wp), PARAMETER :: Patm = 101000._wp
+   INTEGER,  PARAMETER :: nit000 = 1          ! first time step                                  (mod_const.f90:21)
+   INTEGER,  SAVE      :: nitend = 1          ! last time step; AEROBULK_INIT sets it to Nt      (mod_const.f90:22)
+   INTEGER,  SAVE      :: nb_iter = 5         ! iterations of the bulk algorithms, set by `Niter` (mod_const.f90:33)
 END MODULE mod_const
 
 
 MODULE mod_aerobulk
 
    USE, INTRINSIC :: ISO_C_BINDING
-   USE mod_const, ONLY: wp
+   USE mod_const, ONLY: wp, nb_iter, nitend
 
    IMPLICIT NONE
    PRIVATE
@@ -71,7 +74,6 @@ MODULE mod_aerobulk
       END FUNCTION c_strlen
    END INTERFACE
 
-   INTEGER, SAVE :: nb_iter_now = 5   ! what the library uses until `Niter` is given (sticky, like nb_iter)
 
 CONTAINS
 
@@ -115,7 +117,7 @@ CONTAINS
       END IF
       WRITE(6,'("     *** Computational domain shape: Ni x Nj = ",i5.5," x ",i5.5)') Ni, Nj
       WRITE(6,*)'    *** Number of time records that will be treated:', Nt
-      WRITE(6,*)'    *** Number of iterations in bulk algos: nb_iter  =', INT(nb_iter_now,1)
+      WRITE(6,*)'    *** Number of iterations in bulk algos: nb_iter  =', INT(nb_iter,1)
       WRITE(6,*)'    *** Filling the `mask` array...'
       IF( rep%n_masked == 0 ) THEN
          WRITE(6,*)'        ==> no points need to be masked! :)'
@@ -188,7 +190,8 @@ CONTAINS
       LOGICAL :: lskin, lsrad
       INTEGER :: Ni, Nj
       !!
-      IF( PRESENT(Niter) ) nb_iter_now = Niter
+      IF( PRESENT(Niter) ) nb_iter = Niter   ! sticky module variable of mod_const, like the reference (:236)
+      IF( jt == 1 ) nitend = Nt             ! mod_aerobulk.f90:99
 
       lskin = .FALSE.
       IF( PRESENT(l_use_skin) ) lskin = l_use_skin
@@ -251,7 +254,7 @@ CONTAINS
          istat = ab_model( INT(jt,C_INT), INT(Nt,C_INT), c_algo, INT(LEN_TRIM(calgo),C_INT), REAL(zt,C_DOUBLE), REAL(zu,C_DOUBLE), &
             &              C_LOC(p1), C_LOC(p2), C_LOC(p3), C_LOC(p4), C_LOC(p5), C_LOC(p6),                                    &
             &              C_LOC(o1), C_LOC(o2), C_LOC(o3), C_LOC(o4), C_LOC(o5),                                               &
-            &              INT(nb_iter_now,C_INT), MERGE(1_C_INT, 0_C_INT, lskin), cr1, cr2, co6,                               &
+            &              INT(nb_iter,C_INT), MERGE(1_C_INT, 0_C_INT, lskin), cr1, cr2, co6,                               &
             &              INT(Ni,C_LONG), INT(Nj,C_LONG), rep )
          !! banner first (the reference prints it before computing), then a possible STOP
          IF( (jt==1) .AND. ((istat==0).OR.(istat==8)) ) CALL print_init_banner( calgo, Ni, Nj, Nt, lskin, rep )

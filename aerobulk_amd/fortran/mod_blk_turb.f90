@@ -1,0 +1,280 @@
+! mod_blk_turb.f90 -- Fortran hosts of the TURB_* routines of the MI355X-native engine.
+!
+! Drop-in for callers that USE the reference's bulk-algorithm modules directly (NEMO's sbcblk, the reference's station
+! drivers src/tests/test_aerobulk_buoy_series_oce.f90:452-487, aerobulk_toy.F90:324-393):
+!    mod_blk_coare3p6 : TURB_COARE3P6   (reference: src/mod_blk_coare3p6.f90:123-131)
+!    mod_blk_coare3p0 : TURB_COARE3P0   (src/mod_blk_coare3p0.f90:54-59)
+!    mod_blk_ecmwf    : TURB_ECMWF      (src/mod_blk_ecmwf.f90:63-67)
+!    mod_blk_ncar     : TURB_NCAR       (src/mod_blk_ncar.f90:57-59)
+!    mod_blk_andreas  : TURB_ANDREAS    (src/mod_blk_andreas.f90:66-68)
+! Same module names, routine names, dummy-argument names (keyword calls keep working), kinds, INTENTs and OPTIONALs.
+! Nothing is computed here: every call goes through ISO_C_BINDING to `ab_turb` (include/aerobulk_amd.h), i.e. to the
+! HIP kernel turb_kernel (aerobulk_amd/csrc/ab_turb_kernels.hip).  `nb_iter` is read from mod_const like the reference
+! does (mod_const.f90:33).  Compile after mod_aerobulk.f90 (which provides mod_const), with -fdefault-real-8.
+
+MODULE mod_ab_turb
+   !! shared ISO_C_BINDING plumbing of the five modules below (not part of the reference's interface)
+   USE, INTRINSIC :: ISO_C_BINDING
+   USE mod_const, ONLY: wp, nb_iter
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: ab_turb_generic
+
+   !! mirror of `ab_diag` (include/aerobulk_amd.h)
+   TYPE, BIND(C) :: ab_diag
+      TYPE(C_PTR) :: Cd, Ch, Ce, t_zu, q_zu, Ubzu, CdN, ChN, CeN, z0, u_star, L, UN10, dT_cs, dT_wl, Hz_wl
+   END TYPE ab_diag
+
+   INTERFACE
+      FUNCTION ab_turb( algo, kt, zt, zu, use_cs, use_wl, niter, isecday_utc, lon, T_s, theta_zt, q_s, q_zt, U_zu,  &
+         &              Qsw, rad_lw, slp, Cd, Ch, Ce, t_zu, q_zu, Ubzu, opt, ni, nj ) BIND(C, NAME='ab_turb') RESULT(istat)
+         IMPORT :: C_INT, C_LONG, C_DOUBLE, C_PTR, ab_diag
+         INTEGER(C_INT),  VALUE :: algo, kt, use_cs, use_wl, niter, isecday_utc
+         REAL(C_DOUBLE),  VALUE :: zt, zu
+         TYPE(C_PTR),     VALUE :: lon, T_s, theta_zt, q_s, q_zt, U_zu, Qsw, rad_lw, slp, Cd, Ch, Ce, t_zu, q_zu, Ubzu
+         TYPE(ab_diag), INTENT(in) :: opt
+         INTEGER(C_LONG), VALUE :: ni, nj
+         INTEGER(C_INT) :: istat
+      END FUNCTION ab_turb
+      FUNCTION ab_last_error() BIND(C, NAME='ab_last_error') RESULT(cptr)
+         IMPORT :: C_PTR
+         TYPE(C_PTR) :: cptr
+      END FUNCTION ab_last_error
+      FUNCTION c_strlen(s) BIND(C, NAME='strlen') RESULT(n)
+         IMPORT :: C_PTR, C_SIZE_T
+         TYPE(C_PTR), VALUE :: s
+         INTEGER(C_SIZE_T) :: n
+      END FUNCTION c_strlen
+   END INTERFACE
+
+CONTAINS
+
+   SUBROUTINE stop_with_library_message()
+      TYPE(C_PTR) :: cp
+      CHARACTER(KIND=C_CHAR), DIMENSION(:), POINTER :: cs
+      INTEGER :: n, i
+      CHARACTER(len=1024) :: cmsg
+      cp = ab_last_error()
+      cmsg = ''
+      IF( C_ASSOCIATED(cp) ) THEN
+         n = MIN( INT(c_strlen(cp)), 1024 )
+         CALL C_F_POINTER( cp, cs, (/ n /) )
+         DO i = 1, n
+            cmsg(i:i) = cs(i)
+         END DO
+      END IF
+      WRITE(6,'(" *** E R R O R :  ")')
+      WRITE(6,*) TRIM(cmsg)
+      WRITE(6,*) ''
+      STOP
+   END SUBROUTINE stop_with_library_message
+
+
+   SUBROUTINE ab_turb_generic( ialgo, kt, zt, zu, T_s, t_zt, q_s, q_zt, U_zu, l_use_cs, l_use_wl, &
+      &                        Cd, Ch, Ce, t_zu, q_zu, Ubzu,                                       &
+      &                        Qsw, rad_lw, slp, pdT_cs, isecday_utc, plong, pdT_wl, pHz_wl,       &
+      &                        CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      INTEGER,                  INTENT(in)    :: ialgo, kt
+      REAL(wp),                 INTENT(in)    :: zt, zu
+      REAL(wp), DIMENSION(:,:), INTENT(inout) :: T_s, q_s
+      REAL(wp), DIMENSION(:,:), INTENT(in)    :: t_zt, q_zt, U_zu
+      LOGICAL,                  INTENT(in)    :: l_use_cs, l_use_wl
+      REAL(wp), DIMENSION(:,:), INTENT(out)   :: Cd, Ch, Ce, t_zu, q_zu, Ubzu
+      REAL(wp), DIMENSION(:,:), INTENT(in),  OPTIONAL :: Qsw, rad_lw, slp, plong
+      INTEGER,                  INTENT(in),  OPTIONAL :: isecday_utc
+      REAL(wp), DIMENSION(:,:), INTENT(out), OPTIONAL :: pdT_cs, pdT_wl, pHz_wl, CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      INTEGER :: Ni, Nj, isd
+      Ni = SIZE(T_s,1) ; Nj = SIZE(T_s,2)
+      isd = 12
+      IF( PRESENT(isecday_utc) ) isd = isecday_utc
+      !! explicit-shape dummies: the compiler hands over contiguous storage (copy-in/out only for strided actuals)
+      CALL turb_contig( Ni*Nj, T_s, t_zt, q_s, q_zt, U_zu, Cd, Ch, Ce, t_zu, q_zu, Ubzu, Qsw, rad_lw, slp, plong, &
+         &              pdT_cs, pdT_wl, pHz_wl, CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+   CONTAINS
+      SUBROUTINE turb_contig( n, a1, a2, a3, a4, a5, o1, o2, o3, o4, o5, o6, r1, r2, r3, r4, d1, d2, d3, d4, d5, d6, d7, d8, d9, d10 )
+         INTEGER, INTENT(in) :: n
+         REAL(wp), DIMENSION(n), INTENT(inout), TARGET :: a1, a3
+         REAL(wp), DIMENSION(n), INTENT(in),    TARGET :: a2, a4, a5
+         REAL(wp), DIMENSION(n), INTENT(out),   TARGET :: o1, o2, o3, o4, o5, o6
+         REAL(wp), DIMENSION(n), INTENT(in),    TARGET, OPTIONAL :: r1, r2, r3, r4
+         REAL(wp), DIMENSION(n), INTENT(out),   TARGET, OPTIONAL :: d1, d2, d3, d4, d5, d6, d7, d8, d9, d10
+         TYPE(ab_diag) :: opt
+         TYPE(C_PTR)   :: c1, c2, c3, c4
+         INTEGER(C_INT) :: istat
+         c1 = C_NULL_PTR ; c2 = C_NULL_PTR ; c3 = C_NULL_PTR ; c4 = C_NULL_PTR
+         IF( PRESENT(r1) ) c1 = C_LOC(r1)
+         IF( PRESENT(r2) ) c2 = C_LOC(r2)
+         IF( PRESENT(r3) ) c3 = C_LOC(r3)
+         IF( PRESENT(r4) ) c4 = C_LOC(r4)
+         opt%Cd = C_NULL_PTR ; opt%Ch = C_NULL_PTR ; opt%Ce = C_NULL_PTR
+         opt%t_zu = C_NULL_PTR ; opt%q_zu = C_NULL_PTR ; opt%Ubzu = C_NULL_PTR
+         opt%dT_cs = C_NULL_PTR ; opt%dT_wl = C_NULL_PTR ; opt%Hz_wl = C_NULL_PTR
+         opt%CdN = C_NULL_PTR ; opt%ChN = C_NULL_PTR ; opt%CeN = C_NULL_PTR
+         opt%z0 = C_NULL_PTR ; opt%u_star = C_NULL_PTR ; opt%L = C_NULL_PTR ; opt%UN10 = C_NULL_PTR
+         !! pdT_cs is only assigned when the cool skin runs, pdT_wl / pHz_wl when the warm layer does
+         !! (mod_blk_coare3p6.f90:359,406-407): otherwise the caller's arrays are left untouched
+         IF( PRESENT(d1) .AND. l_use_cs ) opt%dT_cs = C_LOC(d1)
+         IF( PRESENT(d2) .AND. l_use_wl ) opt%dT_wl = C_LOC(d2)
+         IF( PRESENT(d3) .AND. l_use_wl ) opt%Hz_wl = C_LOC(d3)
+         IF( PRESENT(d4) ) opt%CdN    = C_LOC(d4)
+         IF( PRESENT(d5) ) opt%ChN    = C_LOC(d5)
+         IF( PRESENT(d6) ) opt%CeN    = C_LOC(d6)
+         IF( PRESENT(d7) ) opt%z0     = C_LOC(d7)
+         IF( PRESENT(d8) ) opt%u_star = C_LOC(d8)
+         IF( PRESENT(d9) ) opt%L      = C_LOC(d9)
+         IF( PRESENT(d10)) opt%UN10   = C_LOC(d10)
+         istat = ab_turb( INT(ialgo,C_INT), INT(kt,C_INT), REAL(zt,C_DOUBLE), REAL(zu,C_DOUBLE),            &
+            &             MERGE(1_C_INT,0_C_INT,l_use_cs), MERGE(1_C_INT,0_C_INT,l_use_wl), INT(nb_iter,C_INT), &
+            &             INT(isd,C_INT), c4, C_LOC(a1), C_LOC(a2), C_LOC(a3), C_LOC(a4), C_LOC(a5), c1, c2, c3, &
+            &             C_LOC(o1), C_LOC(o2), C_LOC(o3), C_LOC(o4), C_LOC(o5), C_LOC(o6), opt,             &
+            &             INT(Ni,C_LONG), INT(Nj,C_LONG) )
+         IF( istat /= 0 ) CALL stop_with_library_message()
+      END SUBROUTINE turb_contig
+   END SUBROUTINE ab_turb_generic
+
+END MODULE mod_ab_turb
+
+
+MODULE mod_blk_coare3p6
+   USE mod_const, ONLY: wp
+   USE mod_ab_turb
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_COARE3P6
+CONTAINS
+   SUBROUTINE TURB_COARE3P6( kt, zt, zu, T_s, t_zt, q_s, q_zt, U_zu, l_use_cs, l_use_wl, &
+      &                      Cd, Ch, Ce, t_zu, q_zu, Ubzu,                               &
+      &                      Qsw, rad_lw, slp, pdT_cs,                                   &
+      &                      isecday_utc, plong, pdT_wl, pHz_wl,                         &
+      &                      CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      INTEGER,  INTENT(in   )                 ::   kt
+      REAL(wp), INTENT(in   )                 ::   zt, zu
+      REAL(wp), INTENT(inout), DIMENSION(:,:) ::   T_s, q_s
+      REAL(wp), INTENT(in   ), DIMENSION(:,:) ::   t_zt, q_zt, U_zu
+      LOGICAL , INTENT(in   )                 ::   l_use_cs, l_use_wl
+      REAL(wp), INTENT(  out), DIMENSION(:,:) ::   Cd, Ch, Ce, t_zu, q_zu, Ubzu
+      REAL(wp), INTENT(in   ), OPTIONAL, DIMENSION(:,:) ::   Qsw, rad_lw, slp
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   pdT_cs
+      INTEGER,  INTENT(in   ), OPTIONAL                 ::   isecday_utc
+      REAL(wp), INTENT(in   ), OPTIONAL, DIMENSION(:,:) ::   plong
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   pdT_wl, pHz_wl
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      IF( l_use_wl .AND. (.NOT.(PRESENT(isecday_utc) .AND. PRESENT(plong))) ) THEN   ! mod_blk_coare3p6.f90:266-269
+         WRITE(6,*) ' *** E R R O R :  [turb_coare3p6] => you need to provide Qsw, rad_lw, slp, isecday_utc & plong to use warm-layer param!'
+         STOP
+      END IF
+      CALL ab_turb_generic( 2, kt, zt, zu, T_s, t_zt, q_s, q_zt, U_zu, l_use_cs, l_use_wl, Cd, Ch, Ce, t_zu, q_zu, Ubzu, &
+         &                  Qsw, rad_lw, slp, pdT_cs, isecday_utc, plong, pdT_wl, pHz_wl, CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+   END SUBROUTINE TURB_COARE3P6
+END MODULE mod_blk_coare3p6
+
+
+MODULE mod_blk_coare3p0
+   USE mod_const, ONLY: wp
+   USE mod_ab_turb
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_COARE3P0
+CONTAINS
+   SUBROUTINE TURB_COARE3P0( kt, zt, zu, pT_s, pt_zt, pq_s, pq_zt, pU_zu, l_use_cs, l_use_wl, &
+      &                      pCd, pCh, pCe, pt_zu, pq_zu, pUbzu,                             &
+      &                      pQsw, prad_lw, pslp, pdT_cs,                                    &
+      &                      isecday_utc, plong,                                             &
+      &                      pdT_wl, pHz_wl,                                                 &
+      &                      pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10 )
+      INTEGER,  INTENT(in   )                 ::   kt
+      REAL(wp), INTENT(in   )                 ::   zt, zu
+      REAL(wp), INTENT(inout), DIMENSION(:,:) ::   pT_s, pq_s
+      REAL(wp), INTENT(in   ), DIMENSION(:,:) ::   pt_zt, pq_zt, pU_zu
+      LOGICAL , INTENT(in   )                 ::   l_use_cs, l_use_wl
+      REAL(wp), INTENT(  out), DIMENSION(:,:) ::   pCd, pCh, pCe, pt_zu, pq_zu, pUbzu
+      REAL(wp), INTENT(in   ), OPTIONAL, DIMENSION(:,:) ::   pQsw, prad_lw, pslp
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   pdT_cs
+      INTEGER,  INTENT(in   ), OPTIONAL                 ::   isecday_utc
+      REAL(wp), INTENT(in   ), OPTIONAL, DIMENSION(:,:) ::   plong
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   pdT_wl, pHz_wl
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10
+      IF( l_use_wl .AND. (.NOT.(PRESENT(isecday_utc) .AND. PRESENT(plong))) ) THEN   ! mod_blk_coare3p0.f90:201-204
+         WRITE(6,*) ' *** E R R O R :  [turb_coare3p0] => you need to provide Qsw, rad_lw, slp, isecday_utc & plong to use warm-layer param!'
+         STOP
+      END IF
+      CALL ab_turb_generic( 1, kt, zt, zu, pT_s, pt_zt, pq_s, pq_zt, pU_zu, l_use_cs, l_use_wl, pCd, pCh, pCe, pt_zu, pq_zu, pUbzu, &
+         &                  pQsw, prad_lw, pslp, pdT_cs, isecday_utc, plong, pdT_wl, pHz_wl, pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10 )
+   END SUBROUTINE TURB_COARE3P0
+END MODULE mod_blk_coare3p0
+
+
+MODULE mod_blk_ecmwf
+   USE mod_const, ONLY: wp
+   USE mod_ab_turb
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_ECMWF
+CONTAINS
+   SUBROUTINE TURB_ECMWF(    kt, zt, zu, pT_s, pt_zt, pq_s, pq_zt, pU_zu, l_use_cs, l_use_wl, &
+      &                      pCd, pCh, pCe, pt_zu, pq_zu, pUbzu,                             &
+      &                      pQsw, prad_lw, pslp, pdT_cs,                                    &
+      &                      pdT_wl, pHz_wl,                                                 &
+      &                      pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10 )
+      INTEGER,  INTENT(in   )                 ::   kt
+      REAL(wp), INTENT(in   )                 ::   zt, zu
+      REAL(wp), INTENT(inout), DIMENSION(:,:) ::   pT_s, pq_s
+      REAL(wp), INTENT(in   ), DIMENSION(:,:) ::   pt_zt, pq_zt, pU_zu
+      LOGICAL , INTENT(in   )                 ::   l_use_cs, l_use_wl
+      REAL(wp), INTENT(  out), DIMENSION(:,:) ::   pCd, pCh, pCe, pt_zu, pq_zu, pUbzu
+      REAL(wp), INTENT(in   ), OPTIONAL, DIMENSION(:,:) ::   pQsw, prad_lw, pslp
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   pdT_cs, pdT_wl, pHz_wl
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10
+      CALL ab_turb_generic( 4, kt, zt, zu, pT_s, pt_zt, pq_s, pq_zt, pU_zu, l_use_cs, l_use_wl, pCd, pCh, pCe, pt_zu, pq_zu, pUbzu, &
+         &                  Qsw=pQsw, rad_lw=prad_lw, slp=pslp, pdT_cs=pdT_cs, pdT_wl=pdT_wl, pHz_wl=pHz_wl,                          &
+         &                  CdN=pCdN, ChN=pChN, CeN=pCeN, xz0=pz0, xu_star=pu_star, xL=pL, xUN10=pUN10 )
+   END SUBROUTINE TURB_ECMWF
+END MODULE mod_blk_ecmwf
+
+
+MODULE mod_blk_ncar
+   USE mod_const, ONLY: wp
+   USE mod_ab_turb
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_NCAR
+CONTAINS
+   SUBROUTINE TURB_NCAR( zt, zu, sst, t_zt, ssq, q_zt, U_zu,   &
+      &                        Cd, Ch, Ce, t_zu, q_zu, Ubzu,   &
+      &                  CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      REAL(wp), INTENT(in   )                 ::   zt, zu
+      REAL(wp), INTENT(in   ), DIMENSION(:,:) ::   sst, t_zt, ssq, q_zt, U_zu
+      REAL(wp), INTENT(  out), DIMENSION(:,:) ::   Cd, Ch, Ce, t_zu, q_zu, Ubzu
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      REAL(wp), DIMENSION(:,:), ALLOCATABLE :: zTs, zqs   ! sst, ssq are INTENT(in) here; the engine's are INOUT
+      ALLOCATE( zTs(SIZE(sst,1),SIZE(sst,2)), zqs(SIZE(sst,1),SIZE(sst,2)) )
+      zTs = sst ; zqs = ssq
+      CALL ab_turb_generic( 3, 1, zt, zu, zTs, t_zt, zqs, q_zt, U_zu, .FALSE., .FALSE., Cd, Ch, Ce, t_zu, q_zu, Ubzu, &
+         &                  CdN=CdN, ChN=ChN, CeN=CeN, xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10 )
+      DEALLOCATE( zTs, zqs )
+   END SUBROUTINE TURB_NCAR
+END MODULE mod_blk_ncar
+
+
+MODULE mod_blk_andreas
+   USE mod_const, ONLY: wp
+   USE mod_ab_turb
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_ANDREAS
+CONTAINS
+   SUBROUTINE TURB_ANDREAS( zt, zu, psst, pt_zt, pssq, pq_zt, pU_zu, &
+      &                     pCd, pCh, pCe, pt_zu, pq_zu, pUbzu,       &
+      &                    pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10 )
+      REAL(wp), INTENT(in   )                 ::   zt, zu
+      REAL(wp), INTENT(in   ), DIMENSION(:,:) ::   psst, pt_zt, pssq, pq_zt, pU_zu
+      REAL(wp), INTENT(  out), DIMENSION(:,:) ::   pCd, pCh, pCe, pt_zu, pq_zu, pUbzu
+      REAL(wp), INTENT(  out), OPTIONAL, DIMENSION(:,:) ::   pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10
+      REAL(wp), DIMENSION(:,:), ALLOCATABLE :: zTs, zqs
+      ALLOCATE( zTs(SIZE(psst,1),SIZE(psst,2)), zqs(SIZE(psst,1),SIZE(psst,2)) )
+      zTs = psst ; zqs = pssq
+      CALL ab_turb_generic( 5, 1, zt, zu, zTs, pt_zt, zqs, pq_zt, pU_zu, .FALSE., .FALSE., pCd, pCh, pCe, pt_zu, pq_zu, pUbzu, &
+         &                  CdN=pCdN, ChN=pChN, CeN=pCeN, xz0=pz0, xu_star=pu_star, xL=pL, xUN10=pUN10 )
+      DEALLOCATE( zTs, zqs )
+   END SUBROUTINE TURB_ANDREAS
+END MODULE mod_blk_andreas

@@ -137,6 +137,44 @@ typedef struct ab_diag {
 } ab_diag;
 int ab_session_set_diagnostics(ab_session *s, const ab_diag *d, int mem);
 
+/* One call of a TURB_<algo> routine itself, for callers that own the pre-processing and the bulk formula (NEMO's sbcblk,
+ * the reference's station drivers src/tests/test_aerobulk_buoy_series_oce.f90:452-487):
+ *   TURB_COARE3P6( kt, zt, zu, T_s, t_zt, q_s, q_zt, U_zu, l_use_cs, l_use_wl, Cd, Ch, Ce, t_zu, q_zu, Ubzu,
+ *                  Qsw, rad_lw, slp, pdT_cs, isecday_utc, plong, pdT_wl, pHz_wl, CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+ * (mod_blk_coare3p6.f90:123-131; same shape for turb_coare3p0 mod_blk_coare3p0.f90:54-59, turb_ecmwf mod_blk_ecmwf.f90:63-67,
+ * turb_ncar mod_blk_ncar.f90:57-59 and turb_andreas mod_blk_andreas.f90:66-68, the last two without the skin arguments).
+ *   T_s, q_s  : INOUT.  In: bulk SST [K] and its saturation humidity.  Out (use_cs or use_wl): skin temperature and
+ *               0.98 q_sat(T_s, slp); untouched otherwise.
+ *   theta_zt  : POTENTIAL air temperature at zt [K]; q_zt specific humidity [kg/kg]; U_zu scalar wind [m/s]
+ *   Qsw       : NET solar flux (1-albedo) rad_sw; rad_lw; slp: required when use_cs or use_wl, else may be NULL
+ *   Cd..Ubzu  : required outputs.  The OPTIONAL ones (CdN ... Hz_wl) are taken from ab_session_set_diagnostics
+ *               (its first six members are ignored here).
+ *   kt        : 1 initialises the warm-layer state (COARE3P6_INIT mod_blk_coare3p6.f90:250), which then persists in the
+ *               session; solar time / longitude of WL_COARE come from ab_session_set_solar_time.
+ *   nb_iter   : the reference reads the module variable nb_iter (mod_const.f90:33).
+ * Same `mem` / stream rules as ab_session_compute.  The session's algorithm and precision apply; its use_skin flag does not. */
+typedef struct ab_turb_fields {
+    void *T_s;
+    const void *theta_zt;
+    void *q_s;
+    const void *q_zt, *U_zu;
+    const void *Qsw, *rad_lw, *slp;
+    void *Cd, *Ch, *Ce, *t_zu, *q_zu, *Ubzu;
+} ab_turb_fields;
+int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int use_wl, int nb_iter,
+                    const ab_turb_fields *f, int mem, void *stream);
+
+/* The same on process-global state, for the Fortran modules mod_blk_coare3p6 / mod_blk_coare3p0 / mod_blk_ecmwf /
+ * mod_blk_ncar / mod_blk_andreas of aerobulk_amd/fortran/mod_blk_turb.f90 (host fp64 arrays, ni*nj cells): one hidden
+ * session per algorithm, re-created when the shape changes, warm-layer state re-initialised at kt == 1 — the module-level
+ * SAVE arrays of the reference (mod_skin_coare.f90:31-36).  isecday_utc / lon: WL_COARE's solar time (lon may be NULL =
+ * 0 deg everywhere; ignored by ECMWF).  `opt`: host arrays for the OPTIONAL outputs (may be NULL; first six members ignored). */
+int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int nb_iter, int isecday_utc, const double *lon,
+            double *T_s, const double *theta_zt, double *q_s, const double *q_zt, const double *U_zu,
+            const double *Qsw, const double *rad_lw, const double *slp,
+            double *Cd, double *Ch, double *Ce, double *t_zu, double *q_zu, double *Ubzu,
+            const ab_diag *opt, long ni, long nj);
+
 /* Copy the persistent warm-layer state (planes dT_wl, Hz_wl, Qnt_ac, Tau_ac; ECMWF uses the
  * first two) to host doubles — diagnostics pdT_wl/pHz_wl of TURB_COARE3P6, mod_blk_coare3p6.f90:406-407. */
 int ab_session_get_wl_state(ab_session *s, double *state4n);

@@ -481,8 +481,9 @@ static void turb_coare(int v36, double zt, double zu, double sst, double t_zt, d
     int l_zt_equal_zu = (fabs(zu - zt) < 0.01);
     double zm_ztzu = l_zt_equal_zu ? 0. : 1.;    /* 3p0 only :195 */
     double xSST = sst, T_s = sst, q_s = q_s_in;
+    const int l_cs = l_skin & 1, l_wl = l_skin & 2;   /* l_skin: bit0 = l_use_cs, bit1 = l_use_wl */
     if (l_skin) {                                  /* 3p6 :271-276 ; 3p0 :211-214 */
-        T_s = T_s - 0.25;
+        if (l_cs) T_s = T_s - 0.25;
         q_s = rdct_qsat_salt * abo_q_sat(dmax(T_s, 200.), slp);
     }
     double zlog_10 = log(10.), zlog_zt = log(zt), zlog_zu = log(zu);
@@ -540,19 +541,20 @@ static void turb_coare(int v36, double zt, double zu, double sst, double t_zt, d
             t_zu = t_zt - zm_ztzu * zts / vkarmn * ztmp1;
             q_zu = q_zt - zm_ztzu * zqs / vkarmn * ztmp1;
         }
-        if (l_skin) {
+        if (l_cs) {                                 /* cool skin :353-363 */
             double zQns, zTau, zQlat;
-            /* cool skin :353-363 */
             update_qnsol_tau(zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, slp, rad_lw, &zQns, &zTau, &zQlat);
             zdT_cs = cool_skin(Qsw, zQns, zus, xSST, 1, zQlat);
             T_s = xSST + zdT_cs;
-            T_s = T_s + wl[0];
+            if (l_wl) T_s = T_s + wl[0];
             q_s = rdct_qsat_salt * abo_q_sat(dmax(T_s, 200.), slp);
-            /* warm layer :365-376 */
+        }
+        if (l_wl) {                                 /* warm layer :365-376 */
+            double zQns, zTau;
             update_qnsol_tau(zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, slp, rad_lw, &zQns, &zTau, NULL);
             wl_coare(wl, Qsw, zQns, zTau, xSST, plon, isd, nb_iter % jit);
             T_s = xSST + wl[0];
-            T_s = T_s + zdT_cs;
+            if (l_cs) T_s = T_s + zdT_cs;
             q_s = rdct_qsat_salt * abo_q_sat(dmax(T_s, 200.), slp);
         }
         if (!v36 || l_skin || !l_zt_equal_zu) {    /* 3p6 :378-381 conditional; 3p0 :317-318 always */
@@ -574,7 +576,7 @@ static void turb_coare(int v36, double zt, double zu, double sst, double t_zt, d
         o->CeN = dmax(zt1, Cx_min);
     }
     o->z0 = zz0; o->us = zus; o->L = 1. / z1oL_last; o->UN10 = zus / vkarmn * (zlog_10 - zlog_z0);
-    o->dT_cs = zdT_cs; o->dT_wl = l_skin ? wl[0] : 0.; o->Hz_wl = l_skin ? wl[1] : 0.;
+    o->dT_cs = zdT_cs; o->dT_wl = l_wl ? wl[0] : 0.; o->Hz_wl = l_wl ? wl[1] : 0.;
 }
 
 /* ---- ECMWF: mod_blk_ecmwf.f90 ------------------------------------------------------ */
@@ -614,8 +616,9 @@ static void turb_ecmwf(double zt, double zu, double sst, double zt_zt, double q_
     const double charn0_ecmwf = 0.018, zi0 = 1000., Beta0 = 1., alpha_M = 0.11, alpha_H = 0.40, alpha_Q = 0.62;
     double zm_ztzu = (fabs(zu - zt) < 0.01) ? 0. : 1.;
     double zSST = sst, zT_s = sst, zq_s = q_s_in;
+    const int l_cs = l_skin & 1, l_wl = l_skin & 2;   /* bit0 = l_use_cs, bit1 = l_use_wl (:209-216) */
     if (l_skin) {
-        zT_s = zT_s - 0.25;
+        if (l_cs) zT_s = zT_s - 0.25;
         zq_s = rdct_qsat_salt * abo_q_sat(dmax(zT_s, 200.), slp);
     }
     double zlog_10 = log(10.), zlog_zu = log(zu), zlog_ztu = log(zt / zu);
@@ -672,17 +675,20 @@ static void turb_ecmwf(double zt, double zu, double sst, double zt_zt, double q_
         zq_zu = dmax(zq_zt - zm_ztzu * zqs / vkarmn * ztmp1, 0.);
         zFm = zlog_zu - zlog_z0 - zpsi_m_u + zpsi_m_z0;
         zFh = zlog_zu - zlog_z0t - zpsi_h_u + zpsi_h_z0t;
-        if (l_skin) {
+        if (l_cs) {                                 /* :319-329 */
             double zQns, zTau;
             update_qnsol_tau(zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, slp, rad_lw, &zQns, &zTau, NULL);
             zdT_cs = cool_skin(Qsw, zQns, zus, zSST, 0, 0.);
             zT_s = zSST + zdT_cs;
-            zT_s = zT_s + wl[0];
+            if (l_wl) zT_s = zT_s + wl[0];
             zq_s = rdct_qsat_salt * abo_q_sat(dmax(zT_s, 200.), slp);
+        }
+        if (l_wl) {                                 /* :331-340 */
+            double zQns, zTau;
             update_qnsol_tau(zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, slp, rad_lw, &zQns, &zTau, NULL);
             wl_ecmwf(wl, Qsw, zQns, zus, zSST);
             zT_s = zSST + wl[0];
-            zT_s = zT_s + zdT_cs;
+            if (l_cs) zT_s = zT_s + zdT_cs;
             zq_s = rdct_qsat_salt * abo_q_sat(dmax(zT_s, 200.), slp);
         }
         zdt = zt_zu - zT_s;  zdt = fsign(dmax(fabs(zdt), 1.E-09), zdt);
@@ -702,7 +708,7 @@ static void turb_ecmwf(double zt, double zu, double sst, double zt_zt, double q_
         o->CeN = dmax(zt1, Cx_min);
     }
     o->z0 = zz0; o->us = zus; o->L = 1. / z1oL; o->UN10 = zus / vkarmn * (zlog_10 - zlog_z0);
-    o->dT_cs = zdT_cs; o->dT_wl = l_skin ? wl[0] : 0.; o->Hz_wl = l_skin ? wl[1] : 0.;
+    o->dT_cs = zdT_cs; o->dT_wl = l_wl ? wl[0] : 0.; o->Hz_wl = l_wl ? wl[1] : 0.;
 }
 
 /* ---- NCAR: mod_blk_ncar.f90 -------------------------------------------------------- */
@@ -909,7 +915,7 @@ int abo_compute_diag(int algo, int jt, int nt, long n, double zt, double zu, int
 {
     (void)nt;
     if (algo < ABO_COARE3P0 || algo > ABO_ANDREAS) return 2;
-    int l_skin = use_skin && (algo == ABO_COARE3P0 || algo == ABO_COARE3P6 || algo == ABO_ECMWF);
+    int l_skin = (use_skin && (algo == ABO_COARE3P0 || algo == ABO_COARE3P6 || algo == ABO_ECMWF)) ? 3 : 0;  /* cs + wl */
     if (l_skin && (!rad_sw || !rad_lw || !wl_state)) return 2;
     int rc = 0;
     for (long k = 0; k < n; ++k) {
@@ -995,6 +1001,49 @@ int abo_compute(int algo, int jt, int nt, long n, double zt, double zu, int nb_i
 }
 
 /* ---- AEROBULK_INIT host checks: mod_aerobulk.f90:104-153 ---------------------------- */
+/* ---- the TURB_* routines called directly (e.g. mod_blk_coare3p6.f90:123-131), as the reference's station drivers do
+ * (tests/test_aerobulk_buoy_series_oce.f90:452-487): no pre-processing, no bulk formula. */
+int abo_turb(int algo, int kt, long n, double zt, double zu, int nb_iter, int use_cs, int use_wl,
+             double *T_s, const double *theta_zt, double *q_s, const double *q_zt, const double *U_zu,
+             const double *Qsw, const double *rad_lw, const double *slp,
+             double *wl_state, int isecday_utc, const double *lon, double *diag)
+{
+    if (algo < ABO_COARE3P0 || algo > ABO_ANDREAS || !diag) return 2;
+    int l_skin = 0;
+    if (algo == ABO_COARE3P0 || algo == ABO_COARE3P6 || algo == ABO_ECMWF) l_skin = (use_cs ? 1 : 0) | (use_wl ? 2 : 0);
+    else if (use_cs || use_wl) return 2;
+    if (l_skin && (!Qsw || !rad_lw || !slp)) return 2;
+    if ((l_skin & 2) && !wl_state) return 2;
+    for (long k = 0; k < n; ++k) {
+        double wl[4] = {0., 0., 0., 0.};
+        if (l_skin & 2) {
+            if (kt == 1) wl[1] = (algo == ABO_ECMWF) ? 3. : 20.;
+            else for (int s = 0; s < 4; ++s) wl[s] = wl_state[(long)s * n + k];
+        }
+        const double qsw = l_skin ? Qsw[k] : 0., rlw = l_skin ? rad_lw[k] : 0., p = l_skin ? slp[k] : 0.;
+        turb_out o;
+        switch (algo) {
+        case ABO_COARE3P0:
+        case ABO_COARE3P6:
+            turb_coare(algo == ABO_COARE3P6, zt, zu, T_s[k], theta_zt[k], q_s[k], q_zt[k], U_zu[k], l_skin, nb_iter, qsw, rlw, p,
+                       wl, isecday_utc, lon ? lon[k] : 0., &o);
+            break;
+        case ABO_NCAR: turb_ncar(zt, zu, T_s[k], theta_zt[k], q_s[k], q_zt[k], U_zu[k], nb_iter, &o); break;
+        case ABO_ECMWF:
+            turb_ecmwf(zt, zu, T_s[k], theta_zt[k], q_s[k], q_zt[k], U_zu[k], l_skin, nb_iter, qsw, rlw, p, wl, &o);
+            break;
+        default: turb_andreas(zt, zu, T_s[k], theta_zt[k], q_s[k], q_zt[k], U_zu[k], nb_iter, &o); break;
+        }
+        if (l_skin & 2)
+            for (int s = 0; s < 4; ++s) wl_state[(long)s * n + k] = wl[s];
+        if (l_skin) { T_s[k] = o.T_s; q_s[k] = o.q_s; }
+        const double d[16] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
+                              o.dT_cs, o.dT_wl, o.Hz_wl};
+        for (int s = 0; s < 16; ++s) diag[(long)s * n + k] = d[s];
+    }
+    return 0;
+}
+
 static int check_unit(long n, const double *x, const double *x2, int wind_module, const unsigned char *mask,
                       double zmin, double zmax)
 {

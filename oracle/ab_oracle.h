@@ -57,6 +57,15 @@ int abo_compute_diag(int algo, int jt, int nt, long n, double zt, double zu, int
                      double *ql, double *qh, double *tau_x, double *tau_y, double *evap, double *t_s,
                      double *wl_state, int isecday_utc, const double *lon, double *diag);
 
+/* TURB_<algo> called directly (mod_blk_coare3p6.f90:123-131, mod_blk_coare3p0.f90:54, mod_blk_ecmwf.f90:63,
+ * mod_blk_ncar.f90:57, mod_blk_andreas.f90:66): T_s, q_s are INOUT (overwritten with the skin values when use_cs or use_wl),
+ * theta_zt is the POTENTIAL temperature, Qsw the NET solar flux; kt==1 initialises the warm-layer state.
+ * diag: the 16 planes of abo_compute_diag (mandatory outputs first). */
+int abo_turb(int algo, int kt, long n, double zt, double zu, int nb_iter, int use_cs, int use_wl,
+             double *T_s, const double *theta_zt, double *q_s, const double *q_zt, const double *U_zu,
+             const double *Qsw, const double *rad_lw, const double *slp,
+             double *wl_state, int isecday_utc, const double *lon, double *diag);
+
 /* AEROBULK_INIT host checks (mod_aerobulk.f90:24-160): mask, humidity type, unit ranges.
  * Returns 0 ok; negative error codes:
  *  -1 whole domain masked, -2 humidity type unidentified, -3 unit-consistency failure

@@ -60,6 +60,9 @@ def lib():
         L.abo_init_checks.restype = C.c_int
         L.abo_init_checks.argtypes = [C.c_long] + [_dp] * 8 + [C.POINTER(C.c_int), C.POINTER(C.c_long),
                                                                C.POINTER(C.c_int)]
+        L.abo_turb.restype = C.c_int
+        L.abo_turb.argtypes = [C.c_int, C.c_int, C.c_long, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int] + [_dp] * 9 + [
+            C.c_int, _dp, _dp]
         L.abo_synth_fields.restype = None
         L.abo_synth_fields.argtypes = [C.c_int] * 4 + [_dp] * 8
         for name, nargs in [("abo_e_sat", 1), ("abo_q_sat", 2), ("abo_theta_from_z_p0_t_q", 4),
@@ -201,6 +204,61 @@ def run_reference_turb(algo, f, zt, zu, niter, use_skin=False):
             raise RuntimeError("reference TURB driver failed:\n" + pr.stdout[-2000:] + pr.stderr[-2000:])
         d = np.fromfile(fout, dtype=np.float64).reshape(16, n)
     return dict(zip(DIAG_NAMES, d))
+
+
+# ------------------------------------------------------------------ TURB_* level: station time series
+SERIES_IN = ("sst", "theta_zt", "ssq", "q_zt", "U_zu", "Qsw", "rad_lw", "slp")
+SERIES_OUT = DIAG_NAMES + ("T_s", "q_s")
+REF_SERIES_EXE = os.path.join(HERE, "_ref", "ref_series_driver.x")
+
+
+def run_series_driver(exe, algo, use_cs, use_wl, niter, zt, zu, lon, isec, recs, timeout=3600):
+    """Run a build of aerobulk_amd/fortran/turb_series_driver.f90: `exe` = oracle/_ref/ref_series_driver.x (linked with the
+    UNMODIFIED reference modules) or aerobulk_amd/fortran/turb_series_driver.x (linked with the HIP engine).
+    recs: float64 [nt, 8, n] in SERIES_IN order; returns [nt, 18, n] in SERIES_OUT order."""
+    recs = np.ascontiguousarray(recs, dtype=np.float64)
+    nt, _, n = recs.shape
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as fh:
+            np.ascontiguousarray(lon, dtype=np.float64).tofile(fh)
+            np.ascontiguousarray(isec, dtype=np.float64).tofile(fh)
+            recs.tofile(fh)
+        pr = subprocess.run([exe, algo, str(int(use_cs)), str(int(use_wl)), str(int(niter)), repr(float(zt)), repr(float(zu)),
+                             str(n), str(nt), fin, fout], capture_output=True, text=True, timeout=timeout)
+        if pr.returncode != 0 or not os.path.exists(fout) or os.path.getsize(fout) != nt * 18 * n * 8:
+            raise RuntimeError(f"{exe} failed (rc={pr.returncode}):\n" + pr.stdout[-2000:] + pr.stderr[-2000:])
+        return np.fromfile(fout, dtype=np.float64).reshape(nt, 18, n)
+
+
+def run_reference_series(algo, use_cs, use_wl, niter, zt, zu, lon, isec, recs):
+    return run_series_driver(REF_SERIES_EXE, algo, use_cs, use_wl, niter, zt, zu, lon, isec, recs)
+
+
+def oracle_turb_series(algo, use_cs, use_wl, niter, zt, zu, lon, isec, recs):
+    """The same time loop through the C restatement (abo_turb)."""
+    recs = np.ascontiguousarray(recs, dtype=np.float64)
+    nt, _, n = recs.shape
+    out = np.empty((nt, 18, n))
+    wl = np.zeros(4 * n)
+    lon = np.ascontiguousarray(lon, dtype=np.float64)
+    for jt in range(nt):
+        r = recs[jt]
+        T_s, q_s = r[0].copy(), r[2].copy()
+        d = np.empty(16 * n)
+        skin = use_cs or use_wl
+        rc = lib().abo_turb(ALGOS[algo], jt + 1, n, zt, zu, niter, int(use_cs), int(use_wl), _p(T_s), _p(r[1].copy()), _p(q_s),
+                            _p(r[3].copy()), _p(r[4].copy()), _p(r[5].copy()) if skin else None, _p(r[6].copy()) if skin else None,
+                            _p(r[7].copy()) if skin else None, _p(wl), int(isec[jt]), _p(lon), _p(d))
+        if rc:
+            raise RuntimeError(f"abo_turb rc={rc}")
+        out[jt, :16] = d.reshape(16, n)
+        if not use_cs:
+            out[jt, 13] = 0.      # pdT_cs / pdT_wl / pHz_wl stay as the caller initialised them when the scheme is off
+        if not use_wl:
+            out[jt, 14:16] = 0.
+        out[jt, 16], out[jt, 17] = T_s, q_s
+    return out
 
 
 def ref_scalar(symbol, *args):
