@@ -52,6 +52,7 @@ SYMBOLS = {
                 + [C.POINTER(Diag), C.c_long, C.c_long]),
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),
     "ab_session_check": (C.c_int, [vp]),
+    "ab_session_set_regroup": (C.c_int, [vp, C.c_int]),
     "ab_session_set_solar_time": (C.c_int, [vp, C.c_int, vp, C.c_int]),
     "ab_session_get_wl_state": (C.c_int, [vp, dp]),
     "ab_session_last_kernel_ms": (C.c_double, [vp]),

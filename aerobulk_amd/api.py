@@ -155,6 +155,12 @@ class Session:
             _raise(rc)
         return self._diag
 
+    def set_regroup(self, on=True):
+        """Lane regrouping of the flux kernel (ab_session_set_regroup): results do not depend on it."""
+        rc = self._lib.ab_session_set_regroup(self._h, int(bool(on)))
+        if rc:
+            _raise(rc)
+
     def set_solar_time(self, isecday_utc, lon=None):
         p, keep = _ptr(lon, self.dtype, self.n)
         rc = self._lib.ab_session_set_solar_time(self._h, int(isecday_utc), p,

@@ -19,8 +19,12 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"
 # -disable-machine-licm: keep the s_mov of polynomial coefficients next to their use.  Hoisted out of the iteration loop
 # they exhaust the 102 SGPRs and come back as v_readlane/v_mov_b64 VALU traffic (-13 % VALU instructions, profiles/r1_notes.md)
+# -target-feature -fmacf64-inst: without the 2-address v_fmac_f64 the Horner steps a*b + C are selected as the 3-address
+# v_fma_f64 with the coefficient C read straight from an SGPR pair; with it every step pays a v_mov_b64 (VALU) to bring C
+# into the accumulator register (10 % of the VALU instructions of the iteration loop, profiles/r1_notes.md)
 HIPFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-disable-machine-licm"]
+            "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-disable-machine-licm",
+            "-Xclang", "-target-feature", "-Xclang", "-fmacf64-inst"]
 
 
 def _newer(target, sources):

@@ -33,19 +33,10 @@ namespace fm {
 AB_FM double p_rcp(double x) { return __builtin_amdgcn_rcp(x); }      // v_rcp_f64, ~2^-23 relative
 AB_FM double p_rsq(double x) { return __builtin_amdgcn_rsq(x); }      // v_rsq_f64
 AB_FM double p_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// Horner step a*b + C with a compile-time coefficient C: forced to the 3-address VOP3 form with the coefficient in an
-// SGPR pair (2 SALU s_mov).  Left to itself hipcc selects the tied v_fmac_f64 and pays a v_mov_b64 (VALU) per step to
-// put the coefficient into the accumulator register (measured: 10 % of the VALU instructions of the iteration loop).
-AB_FM double p_fmac(double a, double b, double c)
-{
-#ifdef AB_NO_ASM_FMA
-    return __builtin_fma(a, b, c);
-#else
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
-#endif
-}
+// Horner step a*b + C with a table coefficient C.  The build disables the 2-address v_fmac_f64 (build.py), so this is
+// selected as the 3-address v_fma_f64 with C in an SGPR pair.  (An inline-asm v_fma_f64 did the same before, but the
+// hazard recognizer pads every asm block of a dependent chain with an s_nop.)
+AB_FM double p_fmac(double a, double b, double c) { return __builtin_fma(a, b, c); }
 AB_FM double p_mant(double x) { return __builtin_amdgcn_frexp_mant(x); }  // in [0.5,1)
 AB_FM int p_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
 AB_FM double p_ldexp(double x, int e) { return __builtin_amdgcn_ldexp(x, e); }
@@ -69,19 +60,61 @@ AB_FM double p_abs(double x) { return std::fabs(x); }
 AB_FM double p_copysign(double a, double b) { return std::copysign(a, b); }
 #endif
 
-// Polynomial coefficient tables.  On the device they live in constant memory and are fetched with wide scalar loads
-// (s_load_dwordx8/x16: one SMEM instruction per 4-8 coefficients) instead of two s_mov_b32 per coefficient.
+// Polynomial coefficient tables.  On the device they live in constant memory (64-byte aligned, padded to a multiple of 4
+// coefficients) and ab_load<N>() fetches one with wide scalar loads (s_load_dwordx16 / x8: one SMEM instruction per 8 / 4
+// coefficients) instead of two s_mov_b32 per coefficient.
+template <int N> struct ab_coefs {
+    double v[N];
+};
+constexpr int ab_pad4(int n) { return (n + 3) & ~3; }
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST) && !defined(AB_NO_CONST_TABLES)
-#define AB_TAB __constant__
+#define AB_TAB __constant__ __attribute__((aligned(64)))
+typedef const double __attribute__((address_space(4))) *ab_tabp;
+typedef double ab_d4 __attribute__((ext_vector_type(4)));
+typedef double ab_d8 __attribute__((ext_vector_type(8)));
+// The coefficients of ONE polynomial evaluation.  The empty volatile asm makes the table address opaque at the use site,
+// so that the scalar loads stay next to the polynomial that consumes them.  Left alone LLVM hoists every table load out
+// of the iteration loop (the memory is invariant), 64 coefficients = 128 SGPRs do not fit, they are spilled to VGPR lanes
+// and every coefficient use pays two v_readlane_b32 plus hazard s_nops (10 % of the loop's instructions).
+template <int N> AB_FM ab_coefs<N> ab_load(const double *g)
+{
+    ab_tabp p = (ab_tabp)g;
+#ifndef AB_TABLES_HOISTABLE
+    asm volatile("" : "+s"(p));
+#endif
+    ab_coefs<N> r;
+    constexpr int NP = ab_pad4(N);
+#pragma unroll
+    for (int i = 0; i + 8 <= NP; i += 8) {
+        const ab_d8 t = *(const ab_d8 __attribute__((address_space(4))) *)(p + i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i + k < N) r.v[i + k] = t[k];
+    }
+    if (NP % 8) {
+        constexpr int i = NP & ~7;
+        const ab_d4 t = *(const ab_d4 __attribute__((address_space(4))) *)(p + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < N) r.v[i + k] = t[k];
+    }
+    return r;
+}
 #else
 #define AB_TAB static const
+template <int N> AB_FM ab_coefs<N> ab_load(const double *g)
+{
+    ab_coefs<N> r;
+    for (int i = 0; i < N; ++i) r.v[i] = g[i];
+    return r;
+}
 #endif
-AB_TAB double kLogP[7] = {0.666666666666667, 0.39999999999899505, 0.28571428625975487, 0.2222221113479508,
+AB_TAB double kLogP[ab_pad4(7)] = {0.666666666666667, 0.39999999999899505, 0.28571428625975487, 0.2222221113479508,
                           0.18182889125261723, 0.15331721600556042, 0.14616449685043406};
-AB_TAB double kExpP[10] = {0.5000000000000001, 0.16666666666666669, 0.041666666666624164, 0.008333333333330065,
+AB_TAB double kExpP[ab_pad4(10)] = {0.5000000000000001, 0.16666666666666669, 0.041666666666624164, 0.008333333333330065,
                            0.0013888888917196719, 0.00019841269863040545, 2.4801521322368692e-05,
                            2.7557268480310024e-06, 2.7620075879983367e-07, 2.5100375832561234e-08};
-AB_TAB double kAtanP[11] = {-0.3333333333333333, 0.1999999999999552, -0.14285714284666542, 0.11111111015256361,
+AB_TAB double kAtanP[ab_pad4(11)] = {-0.3333333333333333, 0.1999999999999552, -0.14285714284666542, 0.11111111015256361,
                             -0.09090904578123903, 0.07692183190826087, -0.06664511447381948, 0.0585814891280221,
                             -0.0508544973794026, 0.03923165829558719, -0.01917688711906226};
 
@@ -125,9 +158,10 @@ AB_FM double qlog(double x)
     const double f = m - 1.0;
     const double s = qdiv(f, 2.0 + f);
     const double u = s * s;
-    double p = kLogP[6];
+    const ab_coefs<7> c = ab_load<7>(kLogP);
+    double p = c.v[6];
 #pragma unroll
-    for (int i = 5; i >= 0; --i) p = p_fmac(p, u, kLogP[i]);
+    for (int i = 5; i >= 0; --i) p = p_fmac(p, u, c.v[i]);
     const double ef = (double)e;
     const double t = p_fma(s * u, p, ef * 2.3190468138462996e-17);  // s^3 P + e ln2_lo
     return p_fma(ef, 0.6931471805599453, (s + s) + t);
@@ -138,9 +172,10 @@ AB_FM double qlog10(double x) { return qlog(x) * 0.4342944819032518; }
 // exp(r) = 1 + r + r^2 P(r) on |r| <= ln2/2, P degree 9 (truncation 1.6e-17 relative)
 AB_FM double exp_kernel(double r)
 {
-    double p = kExpP[9];
+    const ab_coefs<10> c = ab_load<10>(kExpP);
+    double p = c.v[9];
 #pragma unroll
-    for (int i = 8; i >= 0; --i) p = p_fmac(p, r, kExpP[i]);
+    for (int i = 8; i >= 0; --i) p = p_fmac(p, r, c.v[i]);
     return 1.0 + p_fma(r * r, p, r);
 }
 // exp(x), any finite x (saturates to 0 / inf through ldexp)
@@ -173,9 +208,10 @@ AB_FM double qatan(double x)
     const double blo = big ? 6.123233995736766e-17 : (mid ? 3.061616997868383e-17 : 0.0);
     const double t = qdiv(num, den);
     const double u = t * t;
-    double p = kAtanP[10];
+    const ab_coefs<11> c = ab_load<11>(kAtanP);
+    double p = c.v[10];
 #pragma unroll
-    for (int i = 9; i >= 0; --i) p = p_fmac(p, u, kAtanP[i]);
+    for (int i = 9; i >= 0; --i) p = p_fmac(p, u, c.v[i]);
     const double r = bhi + (p_fma(t * u, p, blo) + t);
     return p_copysign(r, x);
 }
@@ -186,9 +222,10 @@ AB_FM double qatan_ge1(double x)
     const bool big = x > 2.414213562373095;
     const double t = qdiv(big ? -1.0 : x - 1.0, big ? x : x + 1.0);
     const double u = t * t;
-    double p = kAtanP[10];
+    const ab_coefs<11> c = ab_load<11>(kAtanP);
+    double p = c.v[10];
 #pragma unroll
-    for (int i = 9; i >= 0; --i) p = p_fmac(p, u, kAtanP[i]);
+    for (int i = 9; i >= 0; --i) p = p_fmac(p, u, c.v[i]);
     return (big ? 1.5707963267948966 : 0.7853981633974483) + (p_fma(t * u, p, big ? 6.123233995736766e-17 : 3.061616997868383e-17) + t);
 }
 // 1/sqrt(x), x > 0 normal: rsq seed, one Newton step, one residual correction (<= 1 ulp)

@@ -34,6 +34,7 @@ template <class R> struct FluxArgs {
     long n;
     Heights<R> h;
     int nb_iter, hum_type, wl_load, wl_store, isecday, dawn_uniform;
+    int regroup;  // sort the tile's cells into like-behaved waves (see flux_kernel)
 };
 
 // optional per-cell diagnostics of TURB_* (ab_session_set_diagnostics); read only by the DIAG instantiations
@@ -41,71 +42,162 @@ template <class R> struct DiagArgs {
     R *p[16];   // Cd Ch Ce t_zu q_zu Ubzu | CdN ChN CeN z0 u_star L UN10 | dT_cs dT_wl Hz_wl ; nullptr = not wanted
 };
 
+// ---- lane regrouping ---------------------------------------------------------------------------------------------
+// The iteration takes divergent paths per cell: stable / unstable psi functions, warm layer gaining heat / idle.  On
+// spatially incoherent input (the quasi-random benchmark fields are the worst case) every wave holds all kinds of cells and
+// executes every path.  A block therefore owns a TILE of consecutive cells (768 with the skin schemes, 1024 without; 1280 /
+// 1792 in fp32), and works in four phases:
+//   1. owners (thread = cell, natural order, coalesced loads): pre-processing of aerobulk_compute, an fp32 forecast of the
+//      two predicates -> one of 16 buckets, pre-processed inputs parked in LDS (field-major, 48 KB);
+//   2. counting sort of the tile's cell indices by bucket (packed 16-bit histograms, wave scan, no atomics);
+//   3. waves fetch groups of 64 like-behaved cells (dynamic queue, most work first come) and run TURB_* + BULK_FORMULA;
+//      results go back to the cell's LDS slot;
+//   4. owners store the results (coalesced).
+// The arithmetic per cell, hence every output bit, is the same as in natural order (tests/test_gpu_regroup.py); global
+// loads and stores stay coalesced and each field is still read once and written once.
+constexpr int kBuckets = 16;     // 4 warm-layer bins x 4 stability bins
+template <class R, bool SKIN> struct Tile {
+    static constexpr int kFields = SKIN ? 8 : 6;                       // sst theta q_zt u v slp [qsw rlw]
+    // 3 blocks per CU share 160 KB of LDS: <= 53 000 B each for fields + index (2 B) + bucket (1 B) per cell
+    static constexpr int kRounds = 53000 / (kBlock * (kFields * (int)sizeof(R) + 3));   // f64: 3 (skin) / 4 ; f32: 5 / 7
+    static constexpr int kCells = kRounds * kBlock;
+    static constexpr int kGroups = kCells / 64;
+};
+
+// Forecast of (warm layer gains heat, stable) for a cell, with an uncertainty band around each threshold so that the
+// doubtful cells sit together at the bucket borders.  fp32, hardware transcendentals: < 1 % of the work of one cell.
+template <int ALGO, bool SKIN>
+__device__ __forceinline__ int forecast_bucket(float sst, float theta, float q, float uu, float vv, float slp, float qsw,
+                                               float rlw, bool wl_load, float dTprev, float Hzprev)
+{
+    using F = float;
+    using M = Mth<F>;
+    F Ts = SKIN ? sst - 0.25f : sst;
+    if (SKIN && wl_load) Ts += dTprev;
+    const F qs = 0.98f * q_sat<F>(Ts, slp);
+    F dthv = theta * (1.f + 0.608f * q) - Ts * (1.f + 0.608f * qs);   // sign of the bulk Richardson number
+    int wbin = 0;
+    if (SKIN && ALGO != 4) {   // WL_COARE runs its depth solve only where the layer gains heat (mod_skin_coare.f90:171-185)
+        const F w2 = uu * uu + vv * vv;
+        const F wnd = M::sqrt(w2), Ub = vmax(M::sqrt(w2 + 0.25f), 0.5f);
+        const F Cx = dthv > 0.f ? 0.96e-3f : 1.38e-3f;
+        const F t2 = Ts * Ts;
+        const F qns = 1.2f * Ub * Cx * (1005.f * (theta - Ts) + 2.45e6f * (q - qs)) + 0.98f * (rlw - 5.67e-8f * t2 * t2);
+        const F Hz = wl_load ? vmax(vmin(Hzprev, 20.f), 0.1f) : 20.f;
+        const F qabs = wl_absorb<F>(Hz) * qsw + qns;
+        wbin = qabs < -40.f ? 0 : (qabs < 0.f ? 1 : (qabs < 40.f ? 2 : 3));
+        if (wl_load && M::abs(dTprev) >= 1.e-6f && wbin < 2) wbin = 2;
+        if (qabs > 0.f) {      // the warming of this record shifts the stability: estimate of mod_skin_coare.f90:199-224
+            const F alpha = alpha_sw<F>(sst);
+            const F tac = vmax(1.44e-3f * Ub * wnd, 0.002f) * 3600.f;
+            const F qac = qabs * 3600.f;
+            const F hz = vmax(vmin(20.f, M::sqrt(5.422e-1f * M::rcp(alpha)) * tac * M::rsqrt_pos(qac)), 0.1f);
+            F dT = M::sqrt(2.942e-2f * alpha) * 3.687e-6f * qac * M::sqrt(qac) * M::rcp(tac);
+            if (hz < 1.f) dT *= M::rcp(hz);
+            dthv -= dT * (1.f + 11.5f * qs);
+        }
+    }
+    const int sbin = dthv < -0.3f ? 0 : (dthv < 0.f ? 1 : (dthv < 0.3f ? 2 : 3));
+    return wbin * 4 + ((wbin & 1) ? 3 - sbin : sbin);   // snake order: neighbouring buckets differ in one predicate only
+}
+
+// Counting sort of the tile's cells by bucket: thread t owns the PER consecutive cells t*PER.., builds their histogram as
+// sixteen 16-bit counters packed in four 64-bit words, the block scans those (wave shuffle + 4 wave totals through LDS).
+template <int CELLS>
+__device__ __forceinline__ void tile_sort(const unsigned char *s_bkt, unsigned short *s_inv, unsigned long long (*s_wtot)[4], int tid)
+{
+    typedef unsigned long long u64;
+    constexpr int PER = CELLS / kBlock;
+    const int lane = tid & 63, wave = tid >> 6;
+    u64 h[4] = {0, 0, 0, 0};
+    unsigned char b[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        b[i] = s_bkt[tid * PER + i];
+        const u64 inc = 1ull << ((b[i] & 3) * 16);
+        const int w = b[i] >> 2;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) h[x] += (w == x) ? inc : 0ull;
+    }
+    u64 inc4[4] = {h[0], h[1], h[2], h[3]};          // inclusive scan over the 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const u64 t = __shfl_up(inc4[x], d);
+            if (lane >= d) inc4[x] += t;
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) s_wtot[wave][x] = inc4[x];
+    }
+    __syncthreads();
+    u64 pos[4], tot[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        pos[x] = inc4[x] - h[x];
+        tot[x] = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            const u64 t = s_wtot[w][x];
+            tot[x] += t;
+            if (w < wave) pos[x] += t;
+        }
+    }
+    // exclusive prefix over the 16 bucket totals -> first slot of each bucket, packed the same way
+    const u64 ones = 0x0001000100010001ull;
+    u64 carry = 0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const u64 p = tot[x] + (tot[x] << 16) + (tot[x] << 32) + (tot[x] << 48);   // inclusive prefix inside the word
+        pos[x] += p - tot[x] + carry * ones;
+        carry += p >> 48;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int sh = (b[i] & 3) * 16, w = b[i] >> 2;
+        u64 cur = pos[0];
+#pragma unroll
+        for (int x = 1; x < 4; ++x) cur = (w == x) ? pos[x] : cur;
+        s_inv[(cur >> sh) & 0xffffu] = (unsigned short)(tid * PER + i);
+        const u64 inc = 1ull << sh;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) pos[x] += (w == x) ? inc : 0ull;
+    }
+}
+
+// One cell from its pre-processed inputs to the six outputs of aerobulk_compute: TURB_<algo> (mod_aerobulk_compute.f90
+// :129-176), BULK_FORMULA and the stress vector (:184-194).  k: global cell index (warm-layer state, diagnostics, longitude).
 template <class R, int ALGO, bool SKIN, bool DIAG>
-__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
+__device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArgs<R> &dg, const Heights<R> &hh, long k, R sst,
+                                             R theta_zt, R q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
+                                             R &zEvap, R &T_s)
 {
     using M = Mth<R>;
-    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= a.n) return;
-#ifndef AB_NO_VGPR_LAUNDERING
-    // The wave-uniform height constants are used all over the iteration loop.  Left in SGPRs they are spilled to VGPR
-    // lanes (the kernel holds >100 scalar values) and every use pays two v_readlane; there are spare VGPRs, so they are
-    // laundered into vector registers once.
-    Heights<R> hh = a.h;
-    if (AB_LAUNDER_HEIGHTS(SKIN))
-        asm volatile("" : "+v"(hh.zt), "+v"(hh.zu), "+v"(hh.log_zt), "+v"(hh.log_zu), "+v"(hh.log_10), "+v"(hh.log_ztu),
-                          "+v"(hh.log_zu10), "+v"(hh.inv_zu), "+v"(hh.zt_o_zu));
-    // same for the per-lane output / state addresses: formed now (20 VGPRs), so that the 10 base pointers stop
-    // occupying SGPRs for the whole kernel
-    R *pql = a.ql + k, *pqh = a.qh + k, *ptx = a.tau_x + k, *pty = a.tau_y + k;
-    R *pev = a.evap ? a.evap + k : nullptr, *pts = a.t_s ? a.t_s + k : nullptr;
-    R *pw0 = a.wl0 + k, *pw1 = a.wl1 + k, *pw2 = a.wl2 + k, *pw3 = a.wl3 + k;
-    if (AB_LAUNDER_OUT(SKIN)) asm volatile("" : "+v"(pql), "+v"(pqh), "+v"(ptx), "+v"(pty), "+v"(pev), "+v"(pts));
-    if (SKIN && AB_LAUNDER_WL) asm volatile("" : "+v"(pw0), "+v"(pw1), "+v"(pw2), "+v"(pw3));
-#else
-    const Heights<R> &hh = a.h;
-    R *pql = a.ql + k, *pqh = a.qh + k, *ptx = a.tau_x + k, *pty = a.tau_y + k;
-    R *pev = a.evap ? a.evap + k : nullptr, *pts = a.t_s ? a.t_s + k : nullptr;
-    R *pw0 = a.wl0 + k, *pw1 = a.wl1 + k, *pw2 = a.wl2 + k, *pw3 = a.wl3 + k;
-#endif
-
-    // ---- coalesced loads of the input fields
-    const R sst = a.sst[k];
-    const R t_zt = a.t_zt[k];
-    const R hum = a.hum[k];
-    const R uu = a.u[k];
-    const R vv = a.v[k];
-    const R slp = a.slp[k];
-
     CellIn<R> in;
     in.sst = sst;
+    in.theta_zt = theta_zt;
+    in.q_zt = q_zt;
     in.slp = slp;
-    // ---- pre-processing, mod_aerobulk_compute.f90:99-126
-    if (a.hum_type == 0) in.q_zt = hum;                                        // 'sh'
-    else if (a.hum_type == 1) in.q_zt = q_air_dp(hum, vmax(slp, R(50000.)));   // 'dp' :103
-    else in.q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));                  // 'rh' :105
     in.wnd = M::sqrt(uu * uu + vv * vv);                                       // :111
     in.ssq = K<R>::rdct_qsat_salt * q_sat(sst, slp);                           // :114
-    in.theta_zt = theta_from_z_p0_t_q(hh.zt, slp, t_zt, in.q_zt);             // :118
-    in.qsw = R(0.);
-    in.rlw = R(0.);
+    in.qsw = qsw;
+    in.rlw = rlw;
 
     R wl[4] = {R(0.), R(0.), R(0.), R(0.)};
     bool dawn = false;
     if (SKIN) {
-        in.qsw = (R(1.) - K<R>::roce_alb0) * a.rad_sw[k];                      // :135,146,161
-        in.rlw = a.rad_lw[k];
         if (a.wl_load) {
-            wl[0] = *pw0;
-            wl[1] = *pw1;
-            if (ALGO != 4) { wl[2] = *pw2; wl[3] = *pw3; }
+            wl[0] = a.wl0[k];
+            wl[1] = a.wl1[k];
+            if (ALGO != 4) { wl[2] = a.wl2[k]; wl[3] = a.wl3[k]; }
         } else {  // COARE3Px_INIT mod_blk_coare3p6.f90:84-87 ; ECMWF_INIT mod_blk_ecmwf.f90:403-404
             wl[1] = (ALGO == 4) ? R(3.) : R(20.);
         }
         if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>(a.lon[k], a.isecday) : (a.dawn_uniform != 0);
     }
 
-    // ---- TURB_<algo>, mod_aerobulk_compute.f90:129-176
     CellOut<R> o;
     constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
     if (ALGO == 1) turb_coare<R, false, kSkin, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
@@ -120,29 +212,141 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         for (int i = 0; i < 16; ++i)
             if (dg.p[i]) dg.p[i][k] = d[i];
     }
-
     if (SKIN && a.wl_store) {
-        *pw0 = wl[0];
-        *pw1 = wl[1];
-        if (ALGO != 4) { *pw2 = wl[2]; *pw3 = wl[3]; }
+        a.wl0[k] = wl[0];
+        a.wl1[k] = wl[1];
+        if (ALGO != 4) { a.wl2[k] = wl[2]; a.wl3[k] = wl[3]; }
     }
 
-    // ---- BULK_FORMULA + stress vector, :184-194
-    R zTaum, QH, QL, zEvap;
+    R zTaum;
     bulk_formula(hh.zu, o.T_s, o.q_s, o.t_zu, o.q_zu, o.Cd, o.Ch, o.Ce, in.wnd, o.Ubzu, slp, zTaum, QH, QL, zEvap);
     if (zTaum > R(10.)) atomicOr(a.flags, 1);                                  // mod_phymbl.f90:1250-1253
-    R tx = R(0.), ty = R(0.);
+    tx = R(0.);
+    ty = R(0.);
     if (in.wnd > R(1.E-3)) {
         const R s = zTaum / in.wnd;
         tx = s * uu;
         ty = s * vv;
     }
-    *pql = QL;
-    *pqh = QH;
-    *ptx = tx;
-    *pty = ty;
-    if (pev) *pev = zEvap;                                                     // :208
-    if (pts) *pts = o.T_s;                                                     // :206
+    T_s = o.T_s;
+}
+
+template <class R, int ALGO, bool SKIN, bool DIAG>
+__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
+{
+    if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
+        const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+        if (k >= a.n) return;
+        const R slp = a.slp[k], t_zt = a.t_zt[k], hum = a.hum[k];
+        R q_zt;
+        if (a.hum_type == 0) q_zt = hum;
+        else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));
+        else q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));
+        R QL, QH, tx, ty, zEvap, T_s;
+        compute_cell<R, ALGO, SKIN, DIAG>(a, dg, a.h, k, a.sst[k], theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt), q_zt, a.u[k],
+                                          a.v[k], slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
+        a.ql[k] = QL;
+        a.qh[k] = QH;
+        a.tau_x[k] = tx;
+        a.tau_y[k] = ty;
+        if (a.evap) a.evap[k] = zEvap;
+        if (a.t_s) a.t_s[k] = T_s;
+        return;
+    }
+    using T = Tile<R, SKIN>;
+    __shared__ R s_f[T::kFields][T::kCells];
+    __shared__ unsigned short s_inv[T::kCells];
+    __shared__ unsigned char s_bkt[T::kCells];
+    __shared__ unsigned long long s_wtot[kBlock / 64][4];
+    __shared__ int s_next;
+    const int tid = threadIdx.x;
+    const long tile0 = (long)blockIdx.x * T::kCells;
+
+    // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126
+    if (tid == 0) s_next = 0;
+#pragma unroll 1
+    for (int r = 0; r < T::kRounds; ++r) {
+        const int j = r * kBlock + tid;
+        const long k = tile0 + j;
+        int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
+        if (k < a.n) {
+            const R sst = a.sst[k], t_zt = a.t_zt[k], hum = a.hum[k], uu = a.u[k], vv = a.v[k], slp = a.slp[k];
+            R q_zt;
+            if (a.hum_type == 0) q_zt = hum;                                        // 'sh'
+            else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));   // 'dp' :103
+            else q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));                  // 'rh' :105
+            const R theta = theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt);           // :118
+            s_f[0][j] = sst; s_f[1][j] = theta; s_f[2][j] = q_zt; s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
+            R qsw = R(0.), rlw = R(0.);
+            if (SKIN) {
+                qsw = (R(1.) - K<R>::roce_alb0) * a.rad_sw[k];                      // :135,146,161
+                rlw = a.rad_lw[k];
+                s_f[SKIN ? 6 : 0][j] = qsw; s_f[SKIN ? 7 : 0][j] = rlw;
+            }
+            if (a.regroup) {
+                const bool wll = SKIN && a.wl_load;
+                bkt = forecast_bucket<ALGO, SKIN>((float)sst, (float)theta, (float)q_zt, (float)uu, (float)vv, (float)slp,
+                                                  (float)qsw, (float)rlw, wll, wll ? (float)a.wl0[k] : 0.f,
+                                                  (wll && ALGO != 4) ? (float)a.wl1[k] : 20.f);
+            } else {
+                bkt = 0;
+            }
+        }
+        s_bkt[j] = (unsigned char)bkt;
+    }
+    __syncthreads();
+    // ---- phase 2: who computes which cell
+    if (a.regroup) {
+        tile_sort<T::kCells>(s_bkt, s_inv, s_wtot, tid);
+    } else {
+#pragma unroll
+        for (int r = 0; r < T::kRounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
+    }
+    __syncthreads();
+
+    // ---- phase 3: groups of 64 sorted cells, fetched from a queue
+    const int lane = tid & 63;
+    Heights<R> hh = a.h;
+#ifndef AB_NO_VGPR_LAUNDERING
+    // The wave-uniform height constants are used all over the iteration loop.  Left in SGPRs they are spilled to VGPR
+    // lanes (the kernel holds >100 scalar values) and every use pays two v_readlane; there are spare VGPRs, so they are
+    // laundered into vector registers once.
+    if (AB_LAUNDER_HEIGHTS(SKIN))
+        asm volatile("" : "+v"(hh.zt), "+v"(hh.zu), "+v"(hh.log_zt), "+v"(hh.log_zu), "+v"(hh.log_10), "+v"(hh.log_ztu),
+                          "+v"(hh.log_zu10), "+v"(hh.inv_zu), "+v"(hh.zt_o_zu));
+#endif
+#pragma unroll 1
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&s_next, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= T::kGroups) break;
+        const int j = s_inv[g * 64 + lane];
+        const long k = tile0 + j;
+        if (k >= a.n) continue;
+
+        R QL, QH, tx, ty, zEvap, T_s;
+        compute_cell<R, ALGO, SKIN, DIAG>(a, dg, hh, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
+                                          SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
+                                          ty, zEvap, T_s);
+        // the cell's LDS slot is read by this lane only: reuse it for the results
+        s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = T_s;
+    }
+    __syncthreads();
+
+    // ---- phase 4: owners store (coalesced)
+#pragma unroll 1
+    for (int r = 0; r < T::kRounds; ++r) {
+        const int j = r * kBlock + tid;
+        const long k = tile0 + j;
+        if (k >= a.n) break;
+        a.ql[k] = s_f[0][j];
+        a.qh[k] = s_f[1][j];
+        a.tau_x[k] = s_f[2][j];
+        a.tau_y[k] = s_f[3][j];
+        if (a.evap) a.evap[k] = s_f[4][j];                                         // :208
+        if (a.t_s) a.t_s[k] = s_f[5][j];                                           // :206
+    }
 }
 
 template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
@@ -163,7 +367,9 @@ template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCal
     a.nb_iter = c.nb_iter; a.hum_type = c.hum_type; a.wl_load = c.wl_load; a.wl_store = c.wl_store;
     a.isecday = c.isecday;
     a.dawn_uniform = dawn_at_lon0(c.isecday);
-    const long nblk = (c.n + kBlock - 1) / kBlock;
+    a.regroup = c.regroup ? 1 : 0;
+    const long tile = (ALGO == 3) ? kBlock : Tile<R, SKIN>::kCells;
+    const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;
     if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);

@@ -25,6 +25,7 @@ struct FluxCall {
     int wl_load;    // jt > 1: read state ; else initial values
     int wl_store;   // jt < nt: write state back
     int isecday;    // UTC seconds of day for WL_COARE (12 in aerobulk_compute)
+    int regroup;    // 1: regroup the cells of a tile into like-behaved waves (default), 0: natural order
 };
 
 hipError_t launch_flux(const FluxCall &c, hipStream_t stream);

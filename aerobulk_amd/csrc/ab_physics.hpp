@@ -64,16 +64,17 @@ template <class R> struct K {  // constants, mod_const.f90:38-114
 // near-minimax polynomial in x = (T-288.5)/23.5 (60-digit Chebyshev fit of the formula above, tools/gen_poly.py;
 // |dA| <= 9.2e-17, i.e. below the rounding of the direct evaluation); outside that range (polar air, masked cells)
 // the formula itself is evaluated.
-__constant__ double kGoffA[15] = {1.2415921763001385, 0.6554537644583072, -0.06042150514551698, 0.0052061867921480934,
+AB_TAB double kGoffA[fm::ab_pad4(15)] = {1.2415921763001385, 0.6554537644583072, -0.06042150514551698, 0.0052061867921480934,
                                   -0.0004389902243182716, 4.0181440214509234e-05, -4.299303765658193e-06,
                                   5.668664093041563e-07, -8.717077199072555e-08, 1.3977187155429886e-08,
                                   -2.167668513463531e-09, 3.147964597951566e-10, -4.254827005592513e-11,
                                   5.6079820609247194e-12, -6.519141017660851e-13};
 __device__ __forceinline__ double goff_poly(double x)
 {
-    double p = kGoffA[14];
+    const fm::ab_coefs<15> c = fm::ab_load<15>(kGoffA);
+    double p = c.v[14];
 #pragma unroll
-    for (int i = 13; i >= 0; --i) p = fm::p_fmac(p, x, kGoffA[i]);
+    for (int i = 13; i >= 0; --i) p = fm::p_fmac(p, x, c.v[i]);
     return p;
 }
 __device__ __forceinline__ float goff_poly(float x)
@@ -84,14 +85,15 @@ __device__ __forceinline__ float goff_poly(float x)
     return p;
 }
 // Horner evaluation of a constant-memory coefficient table (coefficients fetched with scalar loads)
-template <int N> __device__ __forceinline__ double horner_tab(const double (&tab)[N], double x)
+template <int N> __device__ __forceinline__ double horner_tab(const double *tab, double x)
 {
-    double p = tab[N - 1];
+    const fm::ab_coefs<N> c = fm::ab_load<N>(tab);
+    double p = c.v[N - 1];
 #pragma unroll
-    for (int i = N - 2; i >= 0; --i) p = fm::p_fmac(p, x, tab[i]);
+    for (int i = N - 2; i >= 0; --i) p = fm::p_fmac(p, x, c.v[i]);
     return p;
 }
-template <int N> __device__ __forceinline__ float horner_tab(const double (&tab)[N], float x)
+template <int N> __device__ __forceinline__ float horner_tab(const double *tab, float x)
 {
     float p = (float)tab[N - 1];
 #pragma unroll
@@ -374,7 +376,7 @@ template <class R> __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, R 
 //    psi_c = 3 LOG(c) + G(w) = .9999 L + G(w),   G(w) = 1.5 LOG((w*w+w+1)/3) - 1.7320508 (pi/2 - ATAN(1.7320508 w/(w+2))) + 1.813799447
 // G is analytic on [0,1]; it is evaluated by its degree-20 near-minimax polynomial in x = 2w-1 (tools/gen_poly.py, fitted
 // to the reference's formula WITH its truncated literals; |dG| <= 3.2e-16) instead of a second log and an atan.
-__constant__ double kPsicG[21] = {-1.1378018661248832, 1.2857142823699836, -0.15306122324762675, -0.0029154522038313062,
+AB_TAB double kPsicG[fm::ab_pad4(21)] = {-1.1378018661248832, 1.2857142823699836, -0.15306122324762675, -0.0029154522038313062,
                                   0.012182424010797529, -0.005319212199747766, 0.001372727329966169, -0.00012957955060170255,
                                   -8.228815772429666e-05, 5.619522847612674e-05, -1.9496010425207854e-05, 3.5584071875334317e-06,
                                   4.569112576860545e-07, -6.688538104698402e-07, 2.9920447417445153e-07, -7.973350238907205e-08,
@@ -385,7 +387,7 @@ template <class R> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
     using M = Mth<R>;
     const R L = M::log(y);
     const R w = M::exp(R(-.3333) * L);
-    return R(.9999) * L + horner_tab(kPsicG, R(2.) * w - R(1.));
+    return R(.9999) * L + horner_tab<21>(kPsicG, R(2.) * w - R(1.));
 }
 // psi_m_coare_sclr :217-254 and psi_h_coare_sclr :305-344 at the same zeta
 template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)

@@ -52,6 +52,7 @@ struct ab_session {
     int hum_type = AB_HUM_SH;
     int last_jt = 0;
     int isecday = 12;                 // mod_aerobulk_compute.f90:136,146
+    int regroup = 1;                  // lane regrouping of flux_kernel (ab_session_set_regroup)
     void *d_lon = nullptr;            // optional longitude field (device, session-owned copy)
     void *wl[4] = {nullptr, nullptr, nullptr, nullptr};
     int *d_flags = nullptr;
@@ -130,6 +131,7 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     ab_session *s = new ab_session;
     s->algo = algo; s->ni = ni; s->nj = nj; s->n = ni * nj; s->nt = nt; s->use_skin = use_skin ? 1 : 0;
     s->f32 = (precision == AB_F32); s->esz = s->f32 ? 4 : 8; s->device = device;
+    if (const char *e = getenv("AEROBULK_AMD_REGROUP")) s->regroup = atoi(e) != 0;   // A/B measurements
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
     chk(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -291,6 +293,13 @@ int ab_session_set_diagnostics(ab_session *s, const ab_diag *d, int mem)
         s->diag_on = s->diag_on || (ptrs[i] != nullptr);
     }
     s->diag_mem = mem;
+    return AB_OK;
+}
+
+int ab_session_set_regroup(ab_session *s, int on)
+{
+    if (!s) return fail(AB_ERR_ARG, "NULL session");
+    s->regroup = on ? 1 : 0;
     return AB_OK;
 }
 
@@ -481,6 +490,7 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     c.wl_load = (s->use_skin && jt > 1 && s->wl[0]) ? 1 : 0;      // kt == nit000 initialises, mod_blk_coare3p6.f90:250
     c.wl_store = (s->use_skin && jt < s->nt && s->wl[0]) ? 1 : 0;  // freed at kt == nitend, :411
     c.isecday = s->isecday;
+    c.regroup = s->regroup;
 
     if (pipelined) {
         AB_HIP(compute_host_pipelined(s, c, host_in, hout));

@@ -117,6 +117,13 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter,
                        int mem, void *stream);
 int ab_session_check(ab_session *s);
 
+/* Lane regrouping of the flux kernel (default on).  A thread block owns a tile of ~1000 consecutive cells, parks their
+ * pre-processed inputs in LDS and sorts them so that each 64-lane wave works on cells that take the same branches (stable /
+ * unstable stratification, warm layer gaining heat / idle): on spatially incoherent input this removes most of the SIMT
+ * divergence.  Results are bit-identical with it on or off; off = natural order inside the tile.
+ * Environment override for A/B measurements: AEROBULK_AMD_REGROUP=0. */
+int ab_session_set_regroup(ab_session *s, int on);
+
 /* Warm-layer solar-time inputs for the next ab_session_compute calls.  aerobulk_compute
  * hard-wires isecday_utc=12 and longitude 0 (mod_aerobulk_compute.f90:126,136,146), which is
  * the default; TURB_COARE3Px callers with real time/longitude (tests/test_aerobulk_buoy_series_oce.f90

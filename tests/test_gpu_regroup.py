@@ -1,0 +1,56 @@
+"""Lane regrouping of the flux kernel (include/aerobulk_amd.h: ab_session_set_regroup): which lane computes which cell must
+not change a single output bit — compared with the natural order, for every tile size, ragged sizes and WL state carry-over."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+IN6 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")
+
+
+def _run(algo, skin, f, n, nt=1, on=True, precision="f64"):
+    import aerobulk_amd as ab
+    outs = []
+    with ab.Session(algo, n, 1, nt, skin, precision=precision) as s:
+        s.set_regroup(on)
+        for jt in range(1, nt + 1):
+            outs.append(s.compute(jt, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, rad_sw=f["rad_sw"] if skin else None,
+                                  rad_lw=f["rad_lw"] if skin else None))
+    return outs
+
+
+@pytest.mark.parametrize("algo,skin", [("coare3p6", True), ("coare3p6", False), ("coare3p0", True), ("ecmwf", True), ("ecmwf", False),
+                                       ("ncar", False), ("andreas", False)])
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_regrouped_bits_equal_natural_order(oracle, algo, skin, precision):
+    ni, nj = 1013, 37                      # 37481 cells: ragged last tile for every tile size
+    f = oracle.synth_fields(ni, nj)
+    n = ni * nj
+    ref = _run(algo, skin, f, n, on=False, precision=precision)[0]
+    got = _run(algo, skin, f, n, precision=precision)[0]
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{algo} {k}")
+        assert np.isfinite(got[k]).all()
+
+
+def test_regrouped_multi_record_warm_layer_state(oracle):
+    ni, nj = 700, 23
+    f = oracle.synth_fields(ni, nj)
+    f["u_zu"] = f["u_zu"] * 0.2            # light winds: the warm layer builds up over the records
+    f["v_zu"] = f["v_zu"] * 0.2
+    n = ni * nj
+    ref = _run("coare3p6", True, f, n, nt=4, on=False)
+    got = _run("coare3p6", True, f, n, nt=4)
+    assert np.abs(ref[3]["T_s"] - f["sst"]).max() > 1.0
+    for a, b in zip(got, ref):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_regrouped_tiny_and_large_grids(oracle):
+    for ni, nj in ((7, 1), (300, 1), (4320, 400)):      # fewer cells than one wave / one tile / 1.7 M cells
+        f = oracle.synth_fields(ni, nj)
+        n = ni * nj
+        ref = _run("ecmwf", True, f, n, on=False)[0]
+        got = _run("ecmwf", True, f, n)[0]
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{ni}x{nj} {k}")

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", default="0,4,8")
     ap.add_argument("--precision", default="f64")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--regroup", type=int, default=1)
     a = ap.parse_args()
     ni, nj = (int(x) for x in a.grid.split("x"))
     f = ab.synth_fields_device(ni, nj, precision=a.precision)
@@ -27,6 +28,7 @@ def main():
     for algo in a.algos.split(","):
         for skin in ((False, True) if algo in ("coare3p0", "coare3p6", "ecmwf") else (False,)):
             with ab.Session(algo, ni, nj, 1, skin, precision=a.precision) as s:
+                s.set_regroup(a.regroup)
                 ms = []
                 for it in iters:
                     best = 1e9
