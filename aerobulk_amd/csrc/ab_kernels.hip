@@ -58,8 +58,10 @@ template <class R> struct DiagArgs {
 constexpr int kBuckets = 16;     // 4 warm-layer bins x 4 stability bins
 template <class R, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // sst theta q_zt u v slp [qsw rlw]
-    // 3 blocks per CU share 160 KB of LDS: <= 53 000 B each for fields + index (2 B) + bucket (1 B) per cell
-    static constexpr int kRounds = 53000 / (kBlock * (kFields * (int)sizeof(R) + 3));   // f64: 3 (skin) / 4 ; f32: 5 / 7
+    // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) + bucket (1 B) per cell
+    static constexpr int kWaves = sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU;                 // fp32 fits 128 VGPRs (+10 %)
+    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256;
+    static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 3 (skin) / 4 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;
 };
@@ -232,7 +234,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
 }
 
 template <class R, int ALGO, bool SKIN, bool DIAG>
-__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
+__global__ void __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU)) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
 {
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
