@@ -592,10 +592,15 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
         }
         if (WL) {
-            R zQns, zTau, zQlat;
-            update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
-                             zQlat);                                   // :367-368
-            wl_coare(wl, wc, in.qsw, zQns, zTau, (nb_iter % jit) == 0);  // :370  iwait = MOD(nb_iter,jit)
+            // WL_COARE is called with iwait = MOD(nb_iter,jit) (:370) and writes its state (dT_wl, Hz_wl, Qnt_ac, Tau_ac)
+            // only when iwait == 0 (mod_skin_coare.f90:239-248); everything else in it is local.  For the other
+            // iterations (jit = 2,3,4 of 5) the call and the UPDATE_QNSOL_TAU feeding it have no effect: skipped.
+            if ((nb_iter % jit) == 0) {
+                R zQns, zTau, zQlat;
+                update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
+                                 zQlat);                               // :367-368
+                wl_coare(wl, wc, in.qsw, zQns, zTau, true);            // :370
+            }
             T_s = xSST + wl[0];
             if (CS) T_s = T_s + zdT_cs;                                // :373-374
             q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
