@@ -589,7 +589,8 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             zdT_cs = cool_skin<R, true>(in.qsw, zQns, zus, zalpha, zQlat);  // :358
             T_s = xSST + zdT_cs;
             if (WL) T_s = T_s + wl[0];                                 // :360-361
-            q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
+            // with the warm layer on, this q_s is only read by the UPDATE_QNSOL_TAU of a live WL_COARE call (below)
+            if (!WL || (nb_iter % jit) == 0) q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
         }
         if (WL) {
             // WL_COARE is called with iwait = MOD(nb_iter,jit) (:370) and writes its state (dT_wl, Hz_wl, Qnt_ac, Tau_ac)
