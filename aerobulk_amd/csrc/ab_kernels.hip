@@ -1,26 +1,25 @@
 // ab_kernels.hip — HIP kernels of the bulk air-sea flux engine, written for gfx950 (MI355X).
 //
-// flux_kernel<R,ALGO,SKIN>: the whole of aerobulk_compute() (mod_aerobulk_compute.f90:22-213)
+// flux_kernel<R,ALGO,SKIN,DIAG>: the whole of aerobulk_compute() (mod_aerobulk_compute.f90:22-213)
 // fused into ONE pointwise kernel: humidity conversion, scalar wind, q_sat(SST), theta(zt),
 // TURB_<algo> with its nb_iter Monin-Obukhov iterations and optional cool-skin/warm-layer,
-// BULK_FORMULA and the stress vector.  One lane = one cell; a wave reads 64 consecutive cells of
+// BULK_FORMULA and the stress vector.  One lane = one cell at a time; a wave reads 64 consecutive cells of
 // each field with one coalesced 8-byte-per-lane load (512 B per wave-instruction) and writes the
 // outputs the same way; none of the reference's 15 (Ni,Nj) temporaries exists.  The kernel is
-// bound by fp64 VALU throughput, not HBM, so there is no LDS staging: the
-// ≈100 B/cell stream is hidden under thousands of VALU cycles per cell by wave-level parallelism.
+// bound by fp64 VALU throughput, not HBM.  LDS stages the input tile of a block so that
+// the cells can be dealt to the waves by kind (lane regrouping, below): same arithmetic per cell, less
+// SIMT divergence.
 #include "ab_kernels.hpp"
 #include "ab_physics.hpp"
 #include "ab_launch.hpp"
 
 namespace ab {
 
-// Which wave-uniform values are laundered into VGPRs (see flux_kernel), measured on the MI355X (profiles/r1_notes.md):
-// heights -2 % (skin) / -5 % (no skin); output addresses -4 % (no skin) and -1 % (skin) PROVIDED the kernel stays at
-// 3 waves/SIMD (<= 168 VGPRs, enforced by __launch_bounds__ below): at 170 VGPRs (2 waves/SIMD) the skin kernel loses 9 %.
+// The wave-uniform height constants are laundered into VGPRs (see flux_kernel): -2 % (skin) / -5 % (no skin) measured on
+// the MI355X (profiles/r1_notes.md), PROVIDED the kernel stays at 3 waves/SIMD (<= 168 VGPRs, __launch_bounds__ below):
+// at 2 waves/SIMD the skin kernel loses 9 %.
 #ifndef AB_LAUNDER_HEIGHTS
 #define AB_LAUNDER_HEIGHTS(skin) true
-#define AB_LAUNDER_OUT(skin) true
-#define AB_LAUNDER_WL false
 #endif
 #ifndef AB_WAVES_PER_EU
 #define AB_WAVES_PER_EU 3    // <= 168 VGPRs: scalar-load / SALU latencies want the third wave (no scratch needed)
