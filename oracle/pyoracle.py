@@ -189,6 +189,55 @@ def run_reference(algo, records, zt, zu, niter, use_skin=False, with_rad=None, t
             return pickle.load(fh)
 
 
+_CHILD_SLAB = r"""
+import ctypes as C, sys, time, numpy as np
+so_ref, so_orc, algo, skin, niter, ni, nj, j0, njl = sys.argv[1:10]
+skin, niter, ni, nj, j0, njl = int(skin), int(niter), int(ni), int(nj), int(j0), int(njl)
+O = C.CDLL(so_orc); L = C.CDLL(so_ref)
+dp = C.POINTER(C.c_double)
+p = lambda a: a.ctypes.data_as(dp)
+ci = lambda v: C.byref(C.c_int(v)); cd = lambda v: C.byref(C.c_double(v))
+n = ni * njl
+f = [np.empty(n) for _ in range(8)]
+O.abo_synth_fields.restype = None
+O.abo_synth_fields(C.c_int(ni), C.c_int(nj), C.c_int(j0), C.c_int(njl), *[p(a) for a in f])
+o = [np.empty(n) for _ in range(6)]
+a = algo.encode()
+t0 = time.perf_counter()
+if skin:
+    L.aerobulk_cxx_skin(ci(1), ci(1), C.c_char_p(a), cd(2.0), cd(10.0), *[p(x) for x in f[:6]], *[p(x) for x in o[:5]],
+                        ci(niter), ci(1), p(f[6]), p(f[7]), p(o[5]), ci(len(a)), ci(n))
+else:
+    L.aerobulk_cxx_no_skin(ci(1), ci(1), C.c_char_p(a), cd(2.0), cd(10.0), *[p(x) for x in f[:6]], *[p(x) for x in o[:5]],
+                           ci(niter), ci(len(a)), ci(n))
+print("SECS", time.perf_counter() - t0, float(o[0].sum()))
+"""
+
+
+def run_reference_all_cores(algo, use_skin, niter, ni, nj, nproc):
+    """The reference is single-threaded and non-reentrant: to load every host core, `nproc` independent processes each run
+    aerobulk_model(jt=1,Nt=1) on their own j-block of the ni x nj synthetic grid, at the same time.  Returns the list of
+    seconds each spent inside the call (stdout of the reference is discarded)."""
+    per = -(-nj // nproc)
+    procs = []
+    for r in range(nproc):
+        j0 = r * per
+        njl = max(min(per, nj - j0), 0)
+        if njl == 0:
+            continue
+        procs.append(subprocess.Popen([sys.executable, "-c", _CHILD_SLAB, REF_SO, ORACLE_SO, algo, "1" if use_skin else "0",
+                                       str(int(niter)), str(ni), str(nj), str(j0), str(njl)], stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL, text=True))
+    secs = []
+    for pr in procs:
+        out = pr.communicate(timeout=3600)[0]
+        m = [l for l in out.splitlines() if l.startswith("SECS")]
+        if not m:
+            raise RuntimeError("reference child failed:\n" + out[-1000:])
+        secs.append(float(m[-1].split()[1]))
+    return secs
+
+
 def run_reference_turb(algo, f, zt, zu, niter, use_skin=False):
     """TURB_<algo> of the UNMODIFIED reference with all optional diagnostics (oracle/ref_turb_driver.f90, specific humidity,
     one record).  `f` = dict of flat float64 fields; returns dict of DIAG_NAMES arrays."""
