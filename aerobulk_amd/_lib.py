@@ -33,6 +33,13 @@ class TurbFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in NAMES]
 
 
+class IceFields(C.Structure):
+    """ab_ice_fields: arguments of a TURB_ICE_* routine."""
+    NAMES = ("Ts_i", "theta_zt", "qs_i", "q_zt", "U_zu", "frice", "Cd", "Ch", "Ce", "t_zu", "q_zu", "Ub",
+             "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10")
+    _fields_ = [(n, C.c_void_p) for n in NAMES]
+
+
 # every symbol include/aerobulk_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ab_algo_from_string": (C.c_int, [C.c_char_p, C.c_int]),
@@ -50,6 +57,8 @@ SYMBOLS = {
     "ab_session_turb": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(TurbFields), C.c_int, vp]),
     "ab_turb": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, dp] + [dp] * 8 + [dp] * 6
                 + [C.POINTER(Diag), C.c_long, C.c_long]),
+    "ab_turb_ice": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(IceFields), C.c_long, C.c_int, C.c_int, vp]),
+    "ab_ice_algo_from_string": (C.c_int, [C.c_char_p]),
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),
     "ab_session_check": (C.c_int, [vp]),
     "ab_session_set_regroup": (C.c_int, [vp, C.c_int]),

@@ -324,3 +324,42 @@ def synth_fields_device(Ni, Nj, j0=0, nj_local=None, precision="f64", device="cu
     if rc:
         _raise(rc)
     return f
+
+
+ICE_ALGOS = {"nemo": 1, "an05": 2, "lu12": 3, "lg15": 4}
+ICE_OUT = ("Cd", "Ch", "Ce", "t_zu", "q_zu", "Ub", "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10")
+
+
+def turb_ice(calgo, zt, zu, Ts_i, theta_zt, qs_i, q_zt, U_zu, frice=None, nb_iter=5, optional=ICE_OUT[6:], precision="f64"):
+    """TURB_ICE_NEMO / AN05 / LU12 / LG15 (src/ice/mod_blk_ice_*.f90) on flat arrays: numpy (host) or torch (device).
+    Returns the dict of the six mandatory outputs plus the requested OPTIONAL ones."""
+    lib = _lib.load()
+    if calgo not in ICE_ALGOS:
+        raise AerobulkError(3, f"sea-ice algorithm {calgo} is unknown")
+    dtype = np.float64 if precision == "f64" else np.float32
+    dev = _is_torch(Ts_i)
+    n = int(Ts_i.numel() if dev else np.asarray(Ts_i).size)
+    f = _lib.IceFields()
+    keep = []
+    for k, a in (("Ts_i", Ts_i), ("theta_zt", theta_zt), ("qs_i", qs_i), ("q_zt", q_zt), ("U_zu", U_zu), ("frice", frice)):
+        p, kp = _ptr(a, dtype, n)
+        keep.append(kp)
+        setattr(f, k, p)
+    names = ICE_OUT[:6] + tuple(k for k in ICE_OUT[6:] if k in optional)
+    if dev:
+        import torch
+        out = {k: torch.empty(n, dtype=Ts_i.dtype, device=Ts_i.device) for k in names}
+        stream = torch.cuda.current_stream().cuda_stream
+    else:
+        out = {k: np.empty(n, dtype=dtype) for k in names}
+        stream = 0
+    for k, a in out.items():
+        setattr(f, k, _ptr(a, dtype, n)[0])
+    rc = lib.ab_turb_ice(ICE_ALGOS[calgo], float(zt), float(zu), int(nb_iter), C.byref(f), n, AB_F64 if precision == "f64" else AB_F32,
+                         AB_MEM_DEVICE if dev else AB_MEM_HOST, C.c_void_p(stream or 0))
+    if rc:
+        _raise(rc)
+    if dev:
+        import torch
+        torch.cuda.synchronize()
+    return out

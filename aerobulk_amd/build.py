@@ -40,7 +40,7 @@ def _run(cmd, **kw):
 
 
 def build_engine(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_runtime.hip", "ab_cxx.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_ice_kernels.hip", "ab_runtime.hip", "ab_cxx.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [
         os.path.join(ROOT, "include", "aerobulk_amd.h"), os.path.join(ROOT, "include", "aerobulk.hpp"), os.path.abspath(__file__)]
     if not force and not _newer(LIB, deps):
@@ -80,6 +80,14 @@ def build_fortran_host(force=False):
         _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-I", fdir, "-c", tsrc, "-o", os.path.join(fdir, "mod_blk_turb.o")])
         _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, tdrv, os.path.join(fdir, "mod_blk_turb.o"),
               os.path.join(fdir, "mod_aerobulk.o"), "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", texe])
+    # sea-ice modules (mod_blk_ice_nemo ...) + their driver
+    isrc = os.path.join(fdir, "mod_blk_ice.f90")
+    idrv = os.path.join(fdir, "turb_ice_driver.f90")
+    iexe = os.path.join(fdir, "turb_ice_driver.x")
+    if force or _newer(iexe, [src, isrc, idrv, LIB]):
+        _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-I", fdir, "-c", isrc, "-o", os.path.join(fdir, "mod_blk_ice.o")])
+        _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, idrv, os.path.join(fdir, "mod_blk_ice.o"),
+              os.path.join(fdir, "mod_aerobulk.o"), "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", iexe])
     return exe
 
 

@@ -45,6 +45,17 @@ struct TurbCall {
 };
 hipError_t launch_turb(const TurbCall &c, hipStream_t stream);
 
+// One call of a sea-ice TURB_ICE_<algo> routine (src/ice/mod_blk_ice_*.f90).
+struct IceCall {
+    const void *Ts_i, *theta_zt, *qs_i, *q_zt, *U_zu, *frice;   // frice: lu12 (per cell), lg15 (its LAST element only)
+    void *out[13];                                              // Cd Ch Ce t_zu q_zu Ub (required) | CdN ChN CeN z0 u_star L UN10
+    long n;
+    double zt, zu;
+    int algo;        // enum ab_ice_algo
+    int f32, nb_iter;
+};
+hipError_t launch_turb_ice(const IceCall &c, hipStream_t stream);
+
 // AEROBULK_INIT statistics (mod_aerobulk.f90:104-153): per-block partial reductions.
 //  fields order: 0 sst,1 t_air,2 slp,3 u,4 v,5 wnd,6 hum,7 rad_sw,8 rad_lw
 //  partials layout per block: [count, then for each of 9 fields: sum, min, max] = 28 doubles

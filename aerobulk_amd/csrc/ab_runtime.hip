@@ -754,6 +754,68 @@ int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int 
     return ab_session_turb(s, kt, zt, zu, use_cs, use_wl, nb_iter, &f, AB_MEM_HOST, nullptr);
 }
 
+// ---- sea ice: stateless; host callers are staged through a grow-only scratch
+int ab_ice_algo_from_string(const char *calgo)
+{
+    static const char *names[5] = {"", "nemo", "an05", "lu12", "lg15"};
+    if (!calgo) return 0;
+    for (int i = 1; i <= 4; ++i)
+        if (strcmp(calgo, names[i]) == 0) return i;
+    return 0;
+}
+
+int ab_turb_ice(int ice_algo, double zt, double zu, int nb_iter, const ab_ice_fields *f, long n, int precision, int mem,
+                void *stream)
+{
+    if (!f) return fail(AB_ERR_ARG, "ab_turb_ice: NULL fields");
+    if (ice_algo < AB_ICE_NEMO || ice_algo > AB_ICE_LG15) return fail(AB_ERR_ALGO, "sea-ice algorithm id %d is unknown!!!", ice_algo);
+    if (n <= 0 || nb_iter < 0) return fail(AB_ERR_ARG, "ab_turb_ice: bad n / nb_iter");
+    if (precision != AB_F64 && precision != AB_F32) return fail(AB_ERR_ARG, "bad precision %d", precision);
+    if (!f->Ts_i || !f->theta_zt || !f->qs_i || !f->q_zt || !f->U_zu) return fail(AB_ERR_ARG, "ab_turb_ice: NULL input field");
+    if (!f->Cd || !f->Ch || !f->Ce || !f->t_zu || !f->q_zu || !f->Ub) return fail(AB_ERR_ARG, "ab_turb_ice: NULL output field");
+    if ((ice_algo == AB_ICE_LU12 || ice_algo == AB_ICE_LG15) && !f->frice)
+        return fail(AB_ERR_ARG, "TURB_ICE_%s needs the ice concentration `frice`", ice_algo == AB_ICE_LU12 ? "LU12" : "LG15");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(AB_ERR_HIP, "no HIP device visible: this engine has no CPU fallback");
+    const size_t esz = precision == AB_F32 ? 4 : 8, bytes = esz * (size_t)n;
+    const void *hin[6] = {f->Ts_i, f->theta_zt, f->qs_i, f->q_zt, f->U_zu,
+                          (ice_algo == AB_ICE_LU12 || ice_algo == AB_ICE_LG15) ? f->frice : nullptr};
+    void *hout[13] = {f->Cd, f->Ch, f->Ce, f->t_zu, f->q_zu, f->Ub, f->CdN, f->ChN, f->CeN, f->z0, f->u_star, f->L, f->UN10};
+    ab::IceCall c;
+    memset(&c, 0, sizeof c);
+    c.n = n; c.zt = zt; c.zu = zu; c.algo = ice_algo; c.f32 = precision == AB_F32; c.nb_iter = nb_iter;
+    if (mem == AB_MEM_DEVICE) {
+        c.Ts_i = hin[0]; c.theta_zt = hin[1]; c.qs_i = hin[2]; c.q_zt = hin[3]; c.U_zu = hin[4]; c.frice = hin[5];
+        for (int i = 0; i < 13; ++i) c.out[i] = hout[i];
+        AB_HIP(ab::launch_turb_ice(c, (hipStream_t)stream));
+        return AB_OK;
+    }
+    static void *scratch = nullptr;        // 19 planes, grow-only, one host caller at a time (like the reference)
+    static size_t scratch_bytes = 0;
+    if (scratch_bytes < 19 * bytes) {
+        if (scratch) (void)hipFree(scratch);
+        scratch = nullptr; scratch_bytes = 0;
+        AB_HIP(hipMalloc(&scratch, 19 * bytes));
+        scratch_bytes = 19 * bytes;
+    }
+    char *base = (char *)scratch;
+    const void *din[6];
+    for (int i = 0; i < 6; ++i) {
+        din[i] = nullptr;
+        if (!hin[i]) continue;
+        AB_HIP(hipMemcpyAsync(base + i * bytes, hin[i], bytes, hipMemcpyHostToDevice, nullptr));
+        din[i] = base + i * bytes;
+    }
+    c.Ts_i = din[0]; c.theta_zt = din[1]; c.qs_i = din[2]; c.q_zt = din[3]; c.U_zu = din[4]; c.frice = din[5];
+    for (int i = 0; i < 13; ++i) c.out[i] = hout[i] ? base + (6 + i) * bytes : nullptr;
+    AB_HIP(ab::launch_turb_ice(c, nullptr));
+    for (int i = 0; i < 13; ++i)
+        if (hout[i]) AB_HIP(hipMemcpyAsync(hout[i], c.out[i], bytes, hipMemcpyDeviceToHost, nullptr));
+    AB_HIP(hipStreamSynchronize(nullptr));
+    return AB_OK;
+}
+
 static void stop_like_fortran(int rc)
 {
     // ctl_stop, mod_const.f90:255-276: banner + message on stdout, then STOP

@@ -1,0 +1,188 @@
+! mod_blk_ice.f90 -- Fortran hosts of the sea-ice bulk algorithms of the MI355X-native engine.
+!
+! Drop-in for callers of the reference's src/ice modules:
+!    mod_blk_ice_nemo : TURB_ICE_NEMO   (reference: src/ice/mod_blk_ice_nemo.f90:36-38)
+!    mod_blk_ice_an05 : TURB_ICE_AN05   (src/ice/mod_blk_ice_an05.f90:41-43)
+!    mod_blk_ice_lu12 : TURB_ICE_LU12   (src/ice/mod_blk_ice_lu12.f90:69-71)
+!    mod_blk_ice_lg15 : TURB_ICE_LG15   (src/ice/mod_blk_ice_lg15.f90:68-70)
+! Same module / routine / dummy-argument names, INTENTs and OPTIONALs; everything goes through ISO_C_BINDING to
+! `ab_turb_ice` (include/aerobulk_amd.h), i.e. to ice_kernel (aerobulk_amd/csrc/ab_ice_kernels.hip).  `nb_iter` is read from
+! mod_const like the reference does.  Compile after mod_aerobulk.f90 (mod_const), with -fdefault-real-8.
+
+MODULE mod_ab_ice
+   USE, INTRINSIC :: ISO_C_BINDING
+   USE mod_const, ONLY: wp, nb_iter
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: ab_ice_generic
+
+   !! mirror of `ab_ice_fields` (include/aerobulk_amd.h)
+   TYPE, BIND(C) :: ab_ice_fields
+      TYPE(C_PTR) :: Ts_i, theta_zt, qs_i, q_zt, U_zu, frice
+      TYPE(C_PTR) :: Cd, Ch, Ce, t_zu, q_zu, Ub
+      TYPE(C_PTR) :: CdN, ChN, CeN, z0, u_star, L, UN10
+   END TYPE ab_ice_fields
+
+   INTERFACE
+      FUNCTION ab_turb_ice( ice_algo, zt, zu, niter, f, n, iprecision, mem, stream ) BIND(C, NAME='ab_turb_ice') RESULT(istat)
+         IMPORT :: C_INT, C_LONG, C_DOUBLE, C_PTR, ab_ice_fields
+         INTEGER(C_INT),  VALUE :: ice_algo, niter, iprecision, mem
+         REAL(C_DOUBLE),  VALUE :: zt, zu
+         TYPE(ab_ice_fields), INTENT(in) :: f
+         INTEGER(C_LONG), VALUE :: n
+         TYPE(C_PTR),     VALUE :: stream
+         INTEGER(C_INT) :: istat
+      END FUNCTION ab_turb_ice
+      FUNCTION ab_last_error() BIND(C, NAME='ab_last_error') RESULT(cptr)
+         IMPORT :: C_PTR
+         TYPE(C_PTR) :: cptr
+      END FUNCTION ab_last_error
+      FUNCTION c_strlen(s) BIND(C, NAME='strlen') RESULT(n)
+         IMPORT :: C_PTR, C_SIZE_T
+         TYPE(C_PTR), VALUE :: s
+         INTEGER(C_SIZE_T) :: n
+      END FUNCTION c_strlen
+   END INTERFACE
+
+CONTAINS
+
+   SUBROUTINE stop_with_library_message()
+      TYPE(C_PTR) :: cp
+      CHARACTER(KIND=C_CHAR), DIMENSION(:), POINTER :: cs
+      INTEGER :: n, i
+      CHARACTER(len=1024) :: cmsg
+      cp = ab_last_error()
+      cmsg = ''
+      IF( C_ASSOCIATED(cp) ) THEN
+         n = MIN( INT(c_strlen(cp)), 1024 )
+         CALL C_F_POINTER( cp, cs, (/ n /) )
+         DO i = 1, n
+            cmsg(i:i) = cs(i)
+         END DO
+      END IF
+      WRITE(6,'(" *** E R R O R :  ")')
+      WRITE(6,*) TRIM(cmsg)
+      WRITE(6,*) ''
+      STOP
+   END SUBROUTINE stop_with_library_message
+
+   SUBROUTINE ab_ice_generic( ialgo, zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, Cd, Ch, Ce, t_zu, q_zu, Ub, &
+      &                       frice, CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      INTEGER,                  INTENT(in)  :: ialgo
+      REAL(wp),                 INTENT(in)  :: zt, zu
+      REAL(wp), DIMENSION(:,:), INTENT(in)  :: Ts_i, t_zt, qs_i, q_zt, U_zu
+      REAL(wp), DIMENSION(:,:), INTENT(out) :: Cd, Ch, Ce, t_zu, q_zu, Ub
+      REAL(wp), DIMENSION(:,:), INTENT(in),  OPTIONAL :: frice
+      REAL(wp), DIMENSION(:,:), INTENT(out), OPTIONAL :: CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      !! explicit-shape dummies: the compiler hands over contiguous storage
+      CALL ice_contig( SIZE(Ts_i), Ts_i, t_zt, qs_i, q_zt, U_zu, Cd, Ch, Ce, t_zu, q_zu, Ub, frice, &
+         &             CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+   CONTAINS
+      SUBROUTINE ice_contig( n, a1, a2, a3, a4, a5, o1, o2, o3, o4, o5, o6, r1, d1, d2, d3, d4, d5, d6, d7 )
+         INTEGER, INTENT(in) :: n
+         REAL(wp), DIMENSION(n), INTENT(in),  TARGET :: a1, a2, a3, a4, a5
+         REAL(wp), DIMENSION(n), INTENT(out), TARGET :: o1, o2, o3, o4, o5, o6
+         REAL(wp), DIMENSION(n), INTENT(in),  TARGET, OPTIONAL :: r1
+         REAL(wp), DIMENSION(n), INTENT(out), TARGET, OPTIONAL :: d1, d2, d3, d4, d5, d6, d7
+         TYPE(ab_ice_fields) :: f
+         INTEGER(C_INT) :: istat
+         f%Ts_i = C_LOC(a1) ; f%theta_zt = C_LOC(a2) ; f%qs_i = C_LOC(a3) ; f%q_zt = C_LOC(a4) ; f%U_zu = C_LOC(a5)
+         f%Cd = C_LOC(o1) ; f%Ch = C_LOC(o2) ; f%Ce = C_LOC(o3) ; f%t_zu = C_LOC(o4) ; f%q_zu = C_LOC(o5) ; f%Ub = C_LOC(o6)
+         f%frice = C_NULL_PTR
+         f%CdN = C_NULL_PTR ; f%ChN = C_NULL_PTR ; f%CeN = C_NULL_PTR ; f%z0 = C_NULL_PTR
+         f%u_star = C_NULL_PTR ; f%L = C_NULL_PTR ; f%UN10 = C_NULL_PTR
+         IF( PRESENT(r1) ) f%frice  = C_LOC(r1)
+         IF( PRESENT(d1) ) f%CdN    = C_LOC(d1)
+         IF( PRESENT(d2) ) f%ChN    = C_LOC(d2)
+         IF( PRESENT(d3) ) f%CeN    = C_LOC(d3)
+         IF( PRESENT(d4) ) f%z0     = C_LOC(d4)
+         IF( PRESENT(d5) ) f%u_star = C_LOC(d5)
+         IF( PRESENT(d6) ) f%L      = C_LOC(d6)
+         IF( PRESENT(d7) ) f%UN10   = C_LOC(d7)
+         istat = ab_turb_ice( INT(ialgo,C_INT), REAL(zt,C_DOUBLE), REAL(zu,C_DOUBLE), INT(nb_iter,C_INT), f, INT(n,C_LONG), &
+            &                 0_C_INT, 0_C_INT, C_NULL_PTR )      ! AB_F64, AB_MEM_HOST
+         IF( istat /= 0 ) CALL stop_with_library_message()
+      END SUBROUTINE ice_contig
+   END SUBROUTINE ab_ice_generic
+
+END MODULE mod_ab_ice
+
+
+MODULE mod_blk_ice_nemo
+   USE mod_const, ONLY: wp
+   USE mod_ab_ice
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_ICE_NEMO
+CONTAINS
+   SUBROUTINE TURB_ICE_NEMO( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu,         &
+      &                      Cd, Ch, Ce, t_zu, q_zu, Ub,                       &
+      &                      CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      REAL(wp), INTENT(in )                 :: zt, zu
+      REAL(wp), INTENT(in ), DIMENSION(:,:) :: Ts_i, t_zt, qs_i, q_zt, U_zu
+      REAL(wp), INTENT(out), DIMENSION(:,:) :: Cd, Ch, Ce, t_zu, q_zu, Ub
+      REAL(wp), INTENT(out), OPTIONAL, DIMENSION(:,:) :: CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      CALL ab_ice_generic( 1, zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, Cd, Ch, Ce, t_zu, q_zu, Ub, &
+         &                 CdN=CdN, ChN=ChN, CeN=CeN, xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10 )
+   END SUBROUTINE TURB_ICE_NEMO
+END MODULE mod_blk_ice_nemo
+
+
+MODULE mod_blk_ice_an05
+   USE mod_const, ONLY: wp
+   USE mod_ab_ice
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_ICE_AN05
+CONTAINS
+   SUBROUTINE TURB_ICE_AN05( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu,         &
+      &                      Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu,                   &
+      &                      CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      REAL(wp), INTENT(in )                 :: zt, zu
+      REAL(wp), INTENT(in ), DIMENSION(:,:) :: Ts_i, t_zt, qs_i, q_zt, U_zu
+      REAL(wp), INTENT(out), DIMENSION(:,:) :: Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu
+      REAL(wp), INTENT(out), OPTIONAL, DIMENSION(:,:) :: CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      CALL ab_ice_generic( 2, zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu, &
+         &                 CdN=CdN, ChN=ChN, CeN=CeN, xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10 )
+   END SUBROUTINE TURB_ICE_AN05
+END MODULE mod_blk_ice_an05
+
+
+MODULE mod_blk_ice_lu12
+   USE mod_const, ONLY: wp
+   USE mod_ab_ice
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_ICE_LU12
+CONTAINS
+   SUBROUTINE TURB_ICE_LU12( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, frice, &
+      &                      Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu,      &
+      &                      CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      REAL(wp), INTENT(in )                 :: zt, zu
+      REAL(wp), INTENT(in ), DIMENSION(:,:) :: Ts_i, t_zt, qs_i, q_zt, U_zu, frice
+      REAL(wp), INTENT(out), DIMENSION(:,:) :: Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu
+      REAL(wp), INTENT(out), OPTIONAL, DIMENSION(:,:) :: CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      CALL ab_ice_generic( 3, zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu, frice=frice, &
+         &                 CdN=CdN, ChN=ChN, CeN=CeN, xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10 )
+   END SUBROUTINE TURB_ICE_LU12
+END MODULE mod_blk_ice_lu12
+
+
+MODULE mod_blk_ice_lg15
+   USE mod_const, ONLY: wp
+   USE mod_ab_ice
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_ICE_LG15
+CONTAINS
+   SUBROUTINE TURB_ICE_LG15( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, frice, &
+      &                      Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu,      &
+      &                      CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      REAL(wp), INTENT(in )                 :: zt, zu
+      REAL(wp), INTENT(in ), DIMENSION(:,:) :: Ts_i, t_zt, qs_i, q_zt, U_zu, frice
+      REAL(wp), INTENT(out), DIMENSION(:,:) :: Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu
+      REAL(wp), INTENT(out), OPTIONAL, DIMENSION(:,:) :: CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      CALL ab_ice_generic( 4, zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu, frice=frice, &
+         &                 CdN=CdN, ChN=ChN, CeN=CeN, xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10 )
+   END SUBROUTINE TURB_ICE_LG15
+END MODULE mod_blk_ice_lg15

@@ -182,6 +182,25 @@ int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int 
             double *Cd, double *Ch, double *Ce, double *t_zu, double *q_zu, double *Ubzu,
             const ab_diag *opt, long ni, long nj);
 
+/* Sea-ice bulk algorithms (reference: src/ice/): TURB_ICE_NEMO mod_blk_ice_nemo.f90:36-38, TURB_ICE_AN05
+ * mod_blk_ice_an05.f90:41-43, TURB_ICE_LU12 mod_blk_ice_lu12.f90:69-71, TURB_ICE_LG15 mod_blk_ice_lg15.f90:68-70, e.g.
+ *   TURB_ICE_LG15( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, frice, Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu,
+ *                  CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+ * Stateless (no session): n cells, arrays of `precision` (enum ab_precision) in `mem`; AB_MEM_DEVICE enqueues on `stream`.
+ *   Ts_i, qs_i : ice surface temperature [K] and saturation humidity over ice; theta_zt POTENTIAL air temperature at zt
+ *   frice      : ice concentration, required by LU12 and LG15 (NULL otherwise).  NB LG15 reproduces the reference, whose
+ *                CdN_f_LG15_light (mod_cdn_form_ice.f90:304) gives every cell the form drag of the LAST cell of the array
+ *   Cd..Ub     : required outputs; CdN..UN10 optional (NULL = not wanted) */
+enum ab_ice_algo { AB_ICE_NEMO = 1, AB_ICE_AN05 = 2, AB_ICE_LU12 = 3, AB_ICE_LG15 = 4 };
+typedef struct ab_ice_fields {
+    const void *Ts_i, *theta_zt, *qs_i, *q_zt, *U_zu, *frice;
+    void *Cd, *Ch, *Ce, *t_zu, *q_zu, *Ub;
+    void *CdN, *ChN, *CeN, *z0, *u_star, *L, *UN10;
+} ab_ice_fields;
+int ab_turb_ice(int ice_algo, double zt, double zu, int nb_iter, const ab_ice_fields *f, long n, int precision, int mem,
+                void *stream);
+int ab_ice_algo_from_string(const char *calgo);
+
 /* Copy the persistent warm-layer state (planes dT_wl, Hz_wl, Qnt_ac, Tau_ac; ECMWF uses the
  * first two) to host doubles — diagnostics pdT_wl/pHz_wl of TURB_COARE3P6, mod_blk_coare3p6.f90:406-407. */
 int ab_session_get_wl_state(ab_session *s, double *state4n);

@@ -1044,6 +1044,247 @@ int abo_turb(int algo, int kt, long n, double zt, double zu, int nb_iter, int us
     return 0;
 }
 
+
+/* ======================================================================================
+ * Sea-ice bulk algorithms: src/ice/mod_blk_ice_nemo.f90, mod_blk_ice_an05.f90,
+ * mod_blk_ice_lu12.f90, mod_blk_ice_lg15.f90, mod_cdn_form_ice.f90 (per-cell literal restatement)
+ * ====================================================================================== */
+static const double wspd_thrshld_ice = 0.2;   /* mod_const.f90:120 */
+static const double rCd_ice = 1.4e-3;         /* mod_const.f90:118 */
+static const double rz0_i_s_0 = 0.69e-3;      /* mod_blk_ice_lg15.f90:56, mod_blk_ice_lu12.f90:57 */
+static const double rz0_i_f_0 = 4.54e-4;      /* mod_blk_ice_lg15.f90:57 */
+static const double ralpha_0 = 0.2;           /* mod_blk_ice_lg15.f90:54 */
+static const double rce10_i_0 = 3.46e-3;      /* mod_cdn_form_ice.f90:34 */
+static const double rbeta_0_miz = 1.4;        /* mod_cdn_form_ice.f90:25 */
+
+/* rough_leng_m, mod_blk_ice_an05.f90:232-255 */
+static double an05_rough_leng_m(double pus, double pnua)
+{
+    double zus = dmax(pus, 1.E-9);
+    double zz = (zus - 0.18) / 0.1;
+    return 0.135 * pnua / zus + 0.035 * zus * zus / grav * (5. * exp(-zz * zz) + 1.);
+}
+/* rough_leng_tq, mod_blk_ice_an05.f90:257-312 */
+static void an05_rough_leng_tq(double pz0, double pus, double pnua, double *z0t, double *z0q)
+{
+    double zz0 = pz0;
+    double zus = dmax(pus, 1.E-9);
+    double zre = dmax(zus * zz0 / pnua, 0.);
+    double zsmoot = 0.5 + fsign(0.5, (0.135 - zre));
+    double ztrans = 0.5 + fsign(0.5, (2.49999 - zre)) - zsmoot;
+    double zrough = 0.5 + fsign(0.5, (zre - 2.5));
+    double zlog = log(zre);
+    double zlog2 = zlog * zlog;
+    double zb0 = zsmoot * 1.25 + ztrans * 0.149 + zrough * 0.317;
+    double zb1 = -ztrans * 0.550 - zrough * 0.565;
+    double zb2 = -zrough * 0.183;
+    *z0t = zz0 * exp(zb0 + zb1 * zlog + zb2 * zlog2);
+    zb0 = zsmoot * 1.61 + ztrans * 0.351 + zrough * 0.396;
+    zb1 = -ztrans * 0.628 - zrough * 0.512;
+    zb2 = -zrough * 0.180;
+    *z0q = zz0 * exp(zb0 + zb1 * zlog + zb2 * zlog2);
+}
+/* psi_m_ice / psi_h_ice, mod_blk_ice_an05.f90:316-405 */
+double abo_psi_m_ice(double zta)
+{
+    double zx = pow(fabs(1. - 16. * zta), .25);
+    double zpsi_u = log((1. + zx * zx) / 2.) + 2. * log((1. + zx) / 2.) - 2. * atan(zx) + 0.5 * rpi;
+    double zpsi_s = -(0.7 * zta + 0.75 * (zta - 14.3) * exp(-0.35 * zta) + 10.7);
+    double zstab = 0.5 + fsign(0.5, zta);
+    return (1. - zstab) * zpsi_u + zstab * zpsi_s;
+}
+double abo_psi_h_ice(double zta)
+{
+    double zx = pow(fabs(1. - 16. * zta), .25);
+    double zpsi_u = 2. * log((1. + zx * zx) / 2.);
+    double zpsi_s = -(0.7 * zta + 0.75 * (zta - 14.3) * exp(-0.35 * zta) + 10.7);
+    double zstab = 0.5 + fsign(0.5, zta);
+    return (1. - zstab) * zpsi_u + zstab * zpsi_s;
+}
+/* f_m_louis_sclr / f_h_louis_sclr, mod_phymbl.f90:1419-1479 (rc_louis = 5 :150) */
+static double f_louis(double pzu, double pRib, double pCxn, double pz0, double ra)
+{
+    const double rc2_louis = 25.;
+    double zstab = 0.5 + fsign(0.5, pRib);
+    double ztu = pRib / (1. + 3. * rc2_louis * pCxn * sqrt(fabs(-pRib * (pzu / pz0 + 1.))));
+    double zts = pRib / sqrt(fabs(1. + pRib));
+    return (1. - zstab) * (1. - ra * ztu) + zstab * 1. / (1. + ra * zts);
+}
+static double f_m_louis(double pzu, double pRib, double pCdn, double pz0) { return f_louis(pzu, pRib, pCdn, pz0, 10.); }
+static double f_h_louis(double pzu, double pRib, double pChn, double pz0) { return f_louis(pzu, pRib, pChn, pz0, 15.); }
+/* Cd_from_z0 (no psi), mod_phymbl.f90:1396-1414 ; z0_from_Cd (no psi) :1349 */
+static double cd_from_z0(double pzu, double pz0) { double c = 1. / log(pzu / pz0); return vkarmn2 * c * c; }
+static double z0_from_cd(double pzu, double pCd) { return pzu * exp(-vkarmn / sqrt(pCd)); }
+
+typedef struct { double Cd, Ch, Ce, t_zu, q_zu, Ub, CdN, ChN, CeN, z0, us, L, UN10; } ice_out;
+
+/* shared by NEMO and LU12: constant-in-stability coefficients, optional outputs of mod_blk_ice_nemo.f90:138-145 */
+static void ice_const_cx(double zu, double Ts_i, double t_zt, double qs_i, double q_zt, double U_zu, double cd, ice_out *o)
+{
+    double Ub = dmax(U_zu, wspd_thrshld_ice);
+    double t_zu = dmax(t_zt, 100.), q_zu = dmax(q_zt, 0.1e-6);
+    double dt_zu = t_zu - Ts_i;  dt_zu = fsign(dmax(fabs(dt_zu), 1.E-6), dt_zu);
+    double dq_zu = q_zu - qs_i;  dq_zu = fsign(dmax(fabs(dq_zu), 1.E-9), dq_zu);
+    o->Cd = cd; o->Ch = cd; o->Ce = cd; o->t_zu = t_zu; o->q_zu = q_zu; o->Ub = Ub;
+    o->CdN = cd; o->ChN = cd; o->CeN = cd;
+    o->z0 = z0_from_cd(zu, cd);
+    o->us = sqrt(cd) * Ub;
+    o->L = 1. / abo_one_on_l(t_zu, q_zu, sqrt(cd) * Ub, cd / sqrt(cd) * dt_zu, cd / sqrt(cd) * dq_zu);
+    o->UN10 = sqrt(cd) * Ub / vkarmn * log(10. / z0_from_cd(zu, cd));
+}
+
+/* turb_ice_an05, mod_blk_ice_an05.f90:41-228 */
+static void turb_ice_an05(double zt, double zu, double Ts_i, double t_zt, double qs_i, double q_zt, double U_zu, int nb_iter,
+                          ice_out *o)
+{
+    int l_zt_equal_zu = (fabs(zu - zt) < 0.01);
+    double Ubzu = dmax(U_zu, wspd_thrshld_ice);
+    double t_zu = dmax(t_zt, 100.), q_zu = dmax(q_zt, 0.1e-6);
+    double dt_zu = t_zu - Ts_i;  dt_zu = fsign(dmax(fabs(dt_zu), 1.E-6), dt_zu);
+    double dq_zu = q_zu - qs_i;  dq_zu = fsign(dmax(fabs(dq_zu), 1.E-9), dq_zu);
+    double znu_a = abo_visc_air(t_zu);
+    double z0 = 8.0E-4;
+    double u_star = 0.035 * Ubzu * log(10. / z0) / log(zu / z0);
+    z0 = an05_rough_leng_m(u_star, znu_a);
+    for (int jit = 1; jit <= 2; ++jit) {
+        u_star = dmax(Ubzu * vkarmn / (log(zu) - log(z0)), 1.E-9);
+        z0 = an05_rough_leng_m(u_star, znu_a);
+    }
+    double z0t, z0q;
+    an05_rough_leng_tq(z0, u_star, znu_a, &z0t, &z0q);
+    double t_star = dt_zu * vkarmn / (log(zu / z0t));
+    double q_star = dq_zu * vkarmn / (log(zu / z0q));
+    for (int jit = 1; jit <= nb_iter; ++jit) {
+        double ztmp0 = abo_one_on_l(t_zu, q_zu, u_star, t_star, q_star);
+        ztmp0 = fsign(dmin(fabs(ztmp0), 200.), ztmp0);
+        double zeta_u = zu * ztmp0;
+        zeta_u = fsign(dmin(fabs(zeta_u), 50.0), zeta_u);
+        double zeta_t = 0.;
+        if (!l_zt_equal_zu) {
+            zeta_t = zt * ztmp0;
+            zeta_t = fsign(dmin(fabs(zeta_t), 50.0), zeta_t);
+        }
+        z0 = an05_rough_leng_m(u_star, znu_a);
+        an05_rough_leng_tq(z0, u_star, znu_a, &z0t, &z0q);
+        ztmp0 = abo_psi_h_ice(zeta_u);
+        t_star = dt_zu * vkarmn / (log(zu) - log(z0t) - ztmp0);
+        q_star = dq_zu * vkarmn / (log(zu) - log(z0q) - ztmp0);
+        u_star = dmax(Ubzu * vkarmn / (log(zu) - log(z0) - abo_psi_m_ice(zeta_u)), 1.E-9);
+        if (!l_zt_equal_zu) {
+            double ztmp1 = log(zt / zu) + ztmp0 - abo_psi_h_ice(zeta_t);
+            t_zu = t_zt - t_star / vkarmn * ztmp1;
+            q_zu = q_zt - q_star / vkarmn * ztmp1;
+            dt_zu = t_zu - Ts_i;  dt_zu = fsign(dmax(fabs(dt_zu), 1.E-6), dt_zu);
+            dq_zu = q_zu - qs_i;  dq_zu = fsign(dmax(fabs(dq_zu), 1.E-9), dq_zu);
+        }
+    }
+    double ztmp0 = u_star / Ubzu;
+    o->Cd = ztmp0 * ztmp0;
+    o->Ch = ztmp0 * t_star / dt_zu;
+    o->Ce = ztmp0 * q_star / dq_zu;
+    o->t_zu = t_zu; o->q_zu = q_zu; o->Ub = Ubzu;
+    ztmp0 = 1. / log(zu / z0);
+    o->CdN = vkarmn2 * ztmp0 * ztmp0;
+    o->ChN = vkarmn2 * ztmp0 / log(zu / z0t);
+    o->CeN = vkarmn2 * ztmp0 / log(zu / z0q);
+    o->z0 = z0; o->us = u_star;
+    o->L = 1. / abo_one_on_l(t_zu, q_zu, u_star, t_star, q_star);
+    o->UN10 = u_star / vkarmn * log(10. / z0);
+}
+
+/* turb_ice_lg15, mod_blk_ice_lg15.f90:68-307.  frice_last: CdN_f_LG15_light (mod_cdn_form_ice.f90:272-307) assigns its WHOLE
+ * result array inside its cell loop, so every cell ends up with the form drag of the LAST cell of the array. */
+static void turb_ice_lg15(double zt, double zu, double Ts_i, double t_zt, double qs_i, double q_zt, double U_zu,
+                          double frice_last, int nb_iter, ice_out *o)
+{
+    int l_zt_equal_zu = (fabs(zu - zt) < 0.01);
+    double Ubzu = dmax(U_zu, wspd_thrshld_ice);
+    double t_zu = dmax(t_zt, 100.), q_zu = dmax(q_zt, 0.1e-6);
+    double dt_zu = t_zu - Ts_i;  dt_zu = fsign(dmax(fabs(dt_zu), 1.E-6), dt_zu);
+    double dq_zu = q_zu - qs_i;  dq_zu = fsign(dmax(fabs(dq_zu), 1.E-9), dq_zu);
+    double zz0_s = rz0_i_s_0;
+    double zCdN_s = cd_from_z0(zu, zz0_s);
+    double zChN_s = vkarmn2 / (log(zu / zz0_s) * log(zu / (ralpha_0 * zz0_s)));
+    double zz0_f = rz0_i_f_0;
+    double zCdN_f, zChN_f;
+    {
+        double ztmp = 1. / zz0_f;
+        double zrlog = log(10. * ztmp) / log(zu * ztmp);
+        zCdN_f = rce10_i_0 * zrlog * zrlog * frice_last * pow(1. - frice_last, rbeta_0_miz);
+        zChN_f = zCdN_f / (1. + log(1. / ralpha_0) / vkarmn * sqrt(zCdN_f));
+    }
+    double Cd_i = zCdN_s + zCdN_f;
+    double Ch_i = zChN_s + zChN_f;
+    double RiB = abo_ri_bulk(zt, Ts_i, t_zt, qs_i, q_zt, Ubzu);
+    for (int jit = 1; jit <= nb_iter; ++jit) {
+        double xtmp1, xtmp2;
+        if (!l_zt_equal_zu) {
+            xtmp1 = zCdN_s + zCdN_f;
+            xtmp2 = zz0_s + zz0_f;
+            xtmp1 = log(zt / zu) + f_h_louis(zu, RiB, xtmp1, xtmp2) - f_h_louis(zt, RiB, xtmp1, xtmp2);
+            xtmp2 = dmax(Ubzu + (sqrt(Cd_i) * Ubzu) * xtmp1, wspd_thrshld_ice);
+            xtmp2 = dmin(xtmp2, Ubzu);
+        } else {
+            xtmp2 = Ubzu;
+        }
+        RiB = abo_ri_bulk(zt, Ts_i, t_zt, qs_i, q_zt, xtmp2);
+        Cd_i = zCdN_s * f_m_louis(zu, RiB, zCdN_s, zz0_s);
+        Ch_i = zChN_s * f_h_louis(zu, RiB, zCdN_s, zz0_s);
+        Cd_i = Cd_i + zCdN_f * f_m_louis(zu, RiB, zCdN_f, zz0_f);
+        Ch_i = Ch_i + zChN_f * f_h_louis(zu, RiB, zCdN_f, zz0_f);
+        if (!l_zt_equal_zu) {
+            xtmp1 = zCdN_s + zCdN_f;
+            xtmp2 = zz0_s + zz0_f;
+            xtmp1 = log(zt / zu) + f_h_louis(zu, RiB, xtmp1, xtmp2) - f_h_louis(zt, RiB, xtmp1, xtmp2);
+            xtmp2 = 1. / sqrt(Cd_i);
+            t_zu = t_zt - (Ch_i * dt_zu * xtmp2) / vkarmn * xtmp1;
+            q_zu = q_zt - (Ch_i * dq_zu * xtmp2) / vkarmn * xtmp1;
+            q_zu = dmax(0., q_zu);
+            dt_zu = t_zu - Ts_i;
+            dq_zu = q_zu - qs_i;
+            dt_zu = fsign(dmax(fabs(dt_zu), 1.E-6), dt_zu);
+            dq_zu = fsign(dmax(fabs(dq_zu), 1.E-9), dq_zu);
+        }
+    }
+    double Ce_i = Ch_i;
+    o->Cd = Cd_i; o->Ch = Ch_i; o->Ce = Ce_i; o->t_zu = t_zu; o->q_zu = q_zu; o->Ub = Ubzu;
+    o->CdN = zCdN_s + zCdN_f; o->ChN = zChN_s + zChN_f; o->CeN = zChN_s + zChN_f;
+    o->z0 = z0_from_cd(zu, zCdN_s + zCdN_f);
+    o->us = sqrt(Cd_i) * Ubzu;
+    {
+        double x = sqrt(Cd_i);
+        o->L = 1. / abo_one_on_l(t_zu, q_zu, x * Ubzu, Ch_i * dt_zu / x, Ce_i * dq_zu / x);
+    }
+    o->UN10 = sqrt(Cd_i) * Ubzu / vkarmn * log(10. / z0_from_cd(zu, zCdN_s + zCdN_f));
+}
+
+/* TURB_ICE_<algo> over n cells.  ice_algo: 1 nemo, 2 an05, 3 lu12, 4 lg15.  frice (ice concentration) is read by lu12
+ * (per cell, mod_cdn_form_ice.f90:147-191 with rMu_0 = rNu_0 = 1, rBeta_0 = 1.4) and lg15 (last cell only, see above).
+ * diag: 13 planes Cd Ch Ce t_zu q_zu Ub CdN ChN CeN z0 u_star L UN10. */
+int abo_turb_ice(int ice_algo, long n, double zt, double zu, int nb_iter, const double *Ts_i, const double *t_zt,
+                 const double *qs_i, const double *q_zt, const double *U_zu, const double *frice, double *diag)
+{
+    if (ice_algo < 1 || ice_algo > 4 || !diag) return 2;
+    if ((ice_algo == 3 || ice_algo == 4) && !frice) return 2;
+    for (long k = 0; k < n; ++k) {
+        ice_out o;
+        switch (ice_algo) {
+        case 1: ice_const_cx(zu, Ts_i[k], t_zt[k], qs_i[k], q_zt[k], U_zu[k], rCd_ice, &o); break;
+        case 2: turb_ice_an05(zt, zu, Ts_i[k], t_zt[k], qs_i[k], q_zt[k], U_zu[k], nb_iter, &o); break;
+        case 3: {
+            const double rCe_0 = 2.23E-3, zcoef = 1. + 1. / (10. * rbeta_0_miz);  /* rNu_0 + 1/(10 rBeta_0): Fortran is case-blind, rBeta_0 IS rbeta_0 = 1.4 (:25) */
+            double cdf = rCe_0 * pow(frice[k], 1. - 1.) * pow(1. - frice[k], zcoef);   /* CdN10_f_LU13 */
+            ice_const_cx(zu, Ts_i[k], t_zt[k], qs_i[k], q_zt[k], U_zu[k], cd_from_z0(zu, rz0_i_s_0) + cdf, &o);
+            break;
+        }
+        default: turb_ice_lg15(zt, zu, Ts_i[k], t_zt[k], qs_i[k], q_zt[k], U_zu[k], frice[n - 1], nb_iter, &o); break;
+        }
+        const double d[13] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ub, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10};
+        for (int s = 0; s < 13; ++s) diag[(long)s * n + k] = d[s];
+    }
+    return 0;
+}
+
 static int check_unit(long n, const double *x, const double *x2, int wind_module, const unsigned char *mask,
                       double zmin, double zmax)
 {

@@ -66,6 +66,15 @@ int abo_turb(int algo, int kt, long n, double zt, double zu, int nb_iter, int us
              const double *Qsw, const double *rad_lw, const double *slp,
              double *wl_state, int isecday_utc, const double *lon, double *diag);
 
+/* Sea-ice bulk algorithms (src/ice/): TURB_ICE_NEMO (1), TURB_ICE_AN05 (2), TURB_ICE_LU12 (3), TURB_ICE_LG15 (4), e.g.
+ * mod_blk_ice_an05.f90:41-43.  Inputs as the TURB_* routines (Ts_i ice surface temperature, qs_i its saturation humidity,
+ * t_zt POTENTIAL temperature); frice = ice concentration (lu12, lg15; may be NULL otherwise).
+ * diag: 13 planes of n doubles: Cd Ch Ce t_zu q_zu Ub CdN ChN CeN z0 u_star L UN10. */
+int abo_turb_ice(int ice_algo, long n, double zt, double zu, int nb_iter, const double *Ts_i, const double *t_zt,
+                 const double *qs_i, const double *q_zt, const double *U_zu, const double *frice, double *diag);
+double abo_psi_m_ice(double zeta);
+double abo_psi_h_ice(double zeta);
+
 /* AEROBULK_INIT host checks (mod_aerobulk.f90:24-160): mask, humidity type, unit ranges.
  * Returns 0 ok; negative error codes:
  *  -1 whole domain masked, -2 humidity type unidentified, -3 unit-consistency failure

@@ -63,6 +63,11 @@ def lib():
         L.abo_turb.restype = C.c_int
         L.abo_turb.argtypes = [C.c_int, C.c_int, C.c_long, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int] + [_dp] * 9 + [
             C.c_int, _dp, _dp]
+        L.abo_turb_ice.restype = C.c_int
+        L.abo_turb_ice.argtypes = [C.c_int, C.c_long, C.c_double, C.c_double, C.c_int] + [_dp] * 7
+        for name in ("abo_psi_m_ice", "abo_psi_h_ice"):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double]
         L.abo_synth_fields.restype = None
         L.abo_synth_fields.argtypes = [C.c_int] * 4 + [_dp] * 8
         for name, nargs in [("abo_e_sat", 1), ("abo_q_sat", 2), ("abo_theta_from_z_p0_t_q", 4),
@@ -308,6 +313,37 @@ def oracle_turb_series(algo, use_cs, use_wl, niter, zt, zu, lon, isec, recs):
             out[jt, 14:16] = 0.
         out[jt, 16], out[jt, 17] = T_s, q_s
     return out
+
+
+# ------------------------------------------------------------------ sea ice (src/ice/)
+ICE_ALGOS = {"nemo": 1, "an05": 2, "lu12": 3, "lg15": 4}
+ICE_IN = ("Ts_i", "theta_zt", "qs_i", "q_zt", "U_zu", "frice")
+ICE_OUT = DIAG_NAMES[:13]
+REF_ICE_EXE = os.path.join(HERE, "_ref", "ref_ice_driver.x")
+
+
+def run_ice_driver(exe, algo, niter, zt, zu, f, timeout=3600):
+    """Run a build of aerobulk_amd/fortran/turb_ice_driver.f90 (`exe` = oracle/_ref/ref_ice_driver.x: unmodified reference
+    modules; aerobulk_amd/fortran/turb_ice_driver.x: HIP engine).  f: dict of ICE_IN arrays; returns dict of ICE_OUT."""
+    n = f["Ts_i"].size
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        np.concatenate([np.ascontiguousarray(f[k], dtype=np.float64) for k in ICE_IN]).tofile(fin)
+        pr = subprocess.run([exe, algo, str(int(niter)), repr(float(zt)), repr(float(zu)), str(n), fin, fout],
+                            capture_output=True, text=True, timeout=timeout)
+        if pr.returncode != 0 or not os.path.exists(fout) or os.path.getsize(fout) != 13 * n * 8:
+            raise RuntimeError(f"{exe} failed (rc={pr.returncode}):\n" + pr.stdout[-2000:] + pr.stderr[-2000:])
+        return dict(zip(ICE_OUT, np.fromfile(fout, dtype=np.float64).reshape(13, n)))
+
+
+def oracle_turb_ice(algo, niter, zt, zu, f):
+    n = f["Ts_i"].size
+    d = np.empty(13 * n)
+    a = [np.ascontiguousarray(f[k], dtype=np.float64) for k in ICE_IN]
+    rc = lib().abo_turb_ice(ICE_ALGOS[algo], n, zt, zu, niter, *[_p(x) for x in a], _p(d))
+    if rc:
+        raise RuntimeError(f"abo_turb_ice rc={rc}")
+    return dict(zip(ICE_OUT, d.reshape(13, n)))
 
 
 def ref_scalar(symbol, *args):
