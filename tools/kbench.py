@@ -25,6 +25,10 @@ def main():
     ni, nj = (int(x) for x in a.grid.split("x"))
     f = ab.synth_fields_device(ni, nj, precision=a.precision)
     iters = [int(x) for x in a.iters.split(",")]
+    with ab.Session("coare3p6", ni, nj, 1, False, precision=a.precision) as s:   # clocks ramp up during the first ~100 ms of work
+        for _ in range(60):
+            s.compute(1, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, check=False)
+        s.last_kernel_ms()
     for algo in a.algos.split(","):
         for skin in ((False, True) if algo in ("coare3p0", "coare3p6", "ecmwf") else (False,)):
             with ab.Session(algo, ni, nj, 1, skin, precision=a.precision) as s:
