@@ -200,6 +200,11 @@ def main():
                     glob[:, (rj0 + r0) * ni:(rj0 + r0 + rows) * ni] = gather_lists[c][r][:, :rows * ni]
         return glob
 
+    # pre-roll, part of the setup: the GPU raises its clocks during the first ~100 ms of sustained work (the first
+    # configuration measured after start-up runs 5-8 % slow otherwise, profiles/r1_notes.md); then the W warm-up steps
+    for _ in range(40):          # the same count on every rank (step() contains the gather)
+        step()
+    sync()
     for _ in range(a.warmup):
         step()
     sync()
