@@ -57,6 +57,7 @@ SYMBOLS = {
     "ab_session_turb": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(TurbFields), C.c_int, vp]),
     "ab_turb": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, dp] + [dp] * 8 + [dp] * 6
                 + [C.POINTER(Diag), C.c_long, C.c_long]),
+    "ab_turb_neutral_10m": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, vp]),
     "ab_turb_ice": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(IceFields), C.c_long, C.c_int, C.c_int, vp]),
     "ab_ice_algo_from_string": (C.c_int, [C.c_char_p]),
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),

@@ -363,3 +363,27 @@ def turb_ice(calgo, zt, zu, Ts_i, theta_zt, qs_i, q_zt, U_zu, frice=None, nb_ite
         import torch
         torch.cuda.synchronize()
     return out
+
+
+def turb_neutral_10m(calgo, U_N10, nb_iter=5, precision="f64"):
+    """TURB_NEUTRAL_10M (mod_blk_neutral_10m.f90:33): dict CdN10, ChN10, CeN10, z0 from the neutral 10 m wind (numpy or torch)."""
+    lib = _lib.load()
+    dtype = np.float64 if precision == "f64" else np.float32
+    dev = _is_torch(U_N10)
+    n = int(U_N10.numel() if dev else np.asarray(U_N10).size)
+    pu, keep = _ptr(U_N10, dtype, n)
+    if dev:
+        import torch
+        out = {k: torch.empty(n, dtype=U_N10.dtype, device=U_N10.device) for k in ("CdN10", "ChN10", "CeN10", "z0")}
+        stream = torch.cuda.current_stream().cuda_stream
+    else:
+        out = {k: np.empty(n, dtype=dtype) for k in ("CdN10", "ChN10", "CeN10", "z0")}
+        stream = 0
+    rc = lib.ab_turb_neutral_10m(ALGOS.get(calgo, 0), int(nb_iter), pu, *[_ptr(a, dtype, n)[0] for a in out.values()], n,
+                                 AB_F64 if precision == "f64" else AB_F32, AB_MEM_DEVICE if dev else AB_MEM_HOST, C.c_void_p(stream or 0))
+    if rc:
+        _raise(rc)
+    if dev:
+        import torch
+        torch.cuda.synchronize()
+    return out

@@ -80,6 +80,11 @@ def build_fortran_host(force=False):
         _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-I", fdir, "-c", tsrc, "-o", os.path.join(fdir, "mod_blk_turb.o")])
         _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, tdrv, os.path.join(fdir, "mod_blk_turb.o"),
               os.path.join(fdir, "mod_aerobulk.o"), "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", texe])
+    ndrv = os.path.join(fdir, "neutral10_driver.f90")
+    nexe = os.path.join(fdir, "neutral10_driver.x")
+    if force or _newer(nexe, [src, tsrc, ndrv, LIB]):
+        _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, ndrv, os.path.join(fdir, "mod_blk_turb.o"),
+              os.path.join(fdir, "mod_aerobulk.o"), "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", nexe])
     # sea-ice modules (mod_blk_ice_nemo ...) + their driver
     isrc = os.path.join(fdir, "mod_blk_ice.f90")
     idrv = os.path.join(fdir, "turb_ice_driver.f90")

@@ -45,6 +45,10 @@ struct TurbCall {
 };
 hipError_t launch_turb(const TurbCall &c, hipStream_t stream);
 
+// turb_neutral_10m (mod_blk_neutral_10m.f90:33): neutral 10 m coefficients from the neutral 10 m wind
+hipError_t launch_neutral10(int algo, int nb_iter, const void *U_N10, void *CdN10, void *ChN10, void *CeN10, void *z0, long n,
+                            int f32, hipStream_t stream);
+
 // One call of a sea-ice TURB_ICE_<algo> routine (src/ice/mod_blk_ice_*.f90).
 struct IceCall {
     const void *Ts_i, *theta_zt, *qs_i, *q_zt, *U_zu, *frice;   // frice: lu12 (per cell), lg15 (its LAST element only)

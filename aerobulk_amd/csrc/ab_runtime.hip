@@ -754,6 +754,33 @@ int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int 
     return ab_session_turb(s, kt, zt, zu, use_cs, use_wl, nb_iter, &f, AB_MEM_HOST, nullptr);
 }
 
+int ab_turb_neutral_10m(int algo, int nb_iter, const void *U_N10, void *CdN10, void *ChN10, void *CeN10, void *z0, long n,
+                        int precision, int mem, void *stream)
+{
+    if (algo < AB_ALGO_COARE3P0 || algo > AB_ALGO_ECMWF)   // andreas: "YET TO BE CODED" + STOP in the reference (:190-191)
+        return fail(AB_ERR_ALGO, "ERROR: algorithm %s is not supported yet!", ab_algo_name(algo));
+    if (!U_N10 || !CdN10 || !ChN10 || !CeN10 || !z0 || n <= 0 || nb_iter < 0) return fail(AB_ERR_ARG, "ab_turb_neutral_10m: bad argument");
+    if (precision != AB_F64 && precision != AB_F32) return fail(AB_ERR_ARG, "bad precision %d", precision);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(AB_ERR_HIP, "no HIP device visible: this engine has no CPU fallback");
+    const size_t bytes = (precision == AB_F32 ? 4 : 8) * (size_t)n;
+    if (mem == AB_MEM_DEVICE) {
+        AB_HIP(ab::launch_neutral10(algo, nb_iter, U_N10, CdN10, ChN10, CeN10, z0, n, precision == AB_F32, (hipStream_t)stream));
+        return AB_OK;
+    }
+    void *d = nullptr;
+    AB_HIP(hipMalloc(&d, 5 * bytes));
+    char *b = (char *)d;
+    hipError_t e = hipMemcpy(b, U_N10, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = ab::launch_neutral10(algo, nb_iter, b, b + bytes, b + 2 * bytes, b + 3 * bytes, b + 4 * bytes, n, precision == AB_F32, nullptr);
+    void *outs[4] = {CdN10, ChN10, CeN10, z0};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipMemcpy(outs[i], b + (1 + i) * bytes, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    AB_HIP(e);
+    return AB_OK;
+}
+
 // ---- sea ice: stateless; host callers are staged through a grow-only scratch
 int ab_ice_algo_from_string(const char *calgo)
 {

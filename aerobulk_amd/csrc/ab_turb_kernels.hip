@@ -115,6 +115,77 @@ template <class R> static hipError_t launch_r(const TurbCall &c, hipStream_t s)
     }
 }
 
+// ---- turb_neutral_10m, mod_blk_neutral_10m.f90:33-209: CdN10, ChN10, CeN10, z0 from the neutral wind at 10 m.
+// coare3p0 / coare3p6 / ecmwf: nb_iter passes of z0 = charn u*^2/g + 0.11 nu/u*, CdN10 = (kappa/ln(10/z0))^2 (:86-122); ncar:
+// closed form (:166-180).  HBM-streaming: 8 B in, 32 B out per cell.
+template <class R, int ALGO>
+__global__ void __launch_bounds__(kBlock) neutral10_kernel(const R *U_N10, R *CdN10, R *ChN10, R *CeN10, R *pz0, long n, int nb_iter)
+{
+    using M = Mth<R>;
+    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const R rnu0_air = R(1.5E-5), log_zu = R(2.302585092994046);
+    R cd, ch, ce, z0;
+    if (ALGO == 3) {
+        const R Ub = vmax(U_N10[k], R(0.5));
+        cd = cd_n10_ncar(Ub);
+        const R sq = M::sqrt(cd);
+        ch = vmax(R(1.e-3) * sq * R(32.7), K<R>::Cx_min);      // pstab = 0 (:174)
+        ce = vmax(R(1.e-3) * (R(34.6) * sq), K<R>::Cx_min);
+        z0 = vmin(vmax(R(10.) * M::exp(-M::div(K<R>::vkarmn, sq)), R(0.0001)), R(0.1));
+    } else {
+        const R Ub = vmax(U_N10[k], R(0.1));
+        cd = R(8.575E-5) * Ub + R(0.657E-3);
+        const R charn = ALGO == 2 ? charn_coare3p6(Ub) : (ALGO == 1 ? charn_coare3p0(Ub) : R(0.018));
+        R u_star = R(0.), lz0 = R(0.), dl = R(1.);
+        z0 = R(0.);
+#pragma unroll 1
+        for (int jit = 1; jit <= nb_iter; ++jit) {
+            u_star = Ub * M::sqrt(cd);
+            z0 = charn * u_star * u_star * R(1. / 9.8) + M::div(R(0.11) * rnu0_air, u_star);
+            lz0 = M::log(z0);
+            dl = log_zu - lz0;
+            cd = M::div(K<R>::vkarmn2, dl * dl);
+        }
+        R lz0t, lz0q;
+        if (ALGO == 4) {
+            const R lt = M::log(M::div(rnu0_air, u_star));
+            lz0t = R(-0.916290731874155) + lt;      // ln 0.40
+            lz0q = R(-0.4780358009429998) + lt;     // ln 0.62
+        } else {
+            const R lrr = lz0 + M::log(M::div(u_star, rnu0_air));   // ln(z0 u*/nu)
+            lz0t = ALGO == 2 ? vmin(R(-8.740336742730447), R(-9.755067547417855) - R(0.72) * lrr)
+                             : vmin(R(-9.115030192171858), R(-9.808177372731803) - R(0.6) * lrr);
+            lz0q = lz0t;
+        }
+        ch = M::div(K<R>::vkarmn2, dl * (log_zu - lz0t));
+        ce = M::div(K<R>::vkarmn2, dl * (log_zu - lz0q));
+    }
+    CdN10[k] = cd; ChN10[k] = ch; CeN10[k] = ce; pz0[k] = z0;
+}
+
+template <class R> static hipError_t launch_n10(int algo, int nb_iter, const void *U, void *cd, void *ch, void *ce, void *z0, long n,
+                                                hipStream_t st)
+{
+    const long nblk = (n + kBlock - 1) / kBlock;
+    if (nblk <= 0) return hipSuccess;
+    const dim3 g((unsigned)nblk), b(kBlock);
+    switch (algo) {
+    case 1: hipLaunchKernelGGL((neutral10_kernel<R, 1>), g, b, 0, st, (const R *)U, (R *)cd, (R *)ch, (R *)ce, (R *)z0, n, nb_iter); break;
+    case 2: hipLaunchKernelGGL((neutral10_kernel<R, 2>), g, b, 0, st, (const R *)U, (R *)cd, (R *)ch, (R *)ce, (R *)z0, n, nb_iter); break;
+    case 3: hipLaunchKernelGGL((neutral10_kernel<R, 3>), g, b, 0, st, (const R *)U, (R *)cd, (R *)ch, (R *)ce, (R *)z0, n, nb_iter); break;
+    case 4: hipLaunchKernelGGL((neutral10_kernel<R, 4>), g, b, 0, st, (const R *)U, (R *)cd, (R *)ch, (R *)ce, (R *)z0, n, nb_iter); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_neutral10(int algo, int nb_iter, const void *U_N10, void *CdN10, void *ChN10, void *CeN10, void *z0, long n,
+                            int f32, hipStream_t stream)
+{
+    return f32 ? launch_n10<float>(algo, nb_iter, U_N10, CdN10, ChN10, CeN10, z0, n, stream)
+               : launch_n10<double>(algo, nb_iter, U_N10, CdN10, ChN10, CeN10, z0, n, stream);
+}
+
 hipError_t launch_turb(const TurbCall &c, hipStream_t stream)
 {
     return c.f32 ? launch_r<float>(c, stream) : launch_r<double>(c, stream);

@@ -278,3 +278,52 @@ CONTAINS
       DEALLOCATE( zTs, zqs )
    END SUBROUTINE TURB_ANDREAS
 END MODULE mod_blk_andreas
+
+
+MODULE mod_blk_neutral_10m
+   !! TURB_NEUTRAL_10M( calgo, U_N10, CdN10, ChN10, CeN10, pz0 ) -- reference: src/mod_blk_neutral_10m.f90:33
+   USE, INTRINSIC :: ISO_C_BINDING
+   USE mod_const, ONLY: wp, nb_iter
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_NEUTRAL_10M
+   INTERFACE
+      FUNCTION ab_turb_neutral_10m( algo, niter, U_N10, CdN10, ChN10, CeN10, z0, n, iprecision, mem, stream ) &
+         &     BIND(C, NAME='ab_turb_neutral_10m') RESULT(istat)
+         IMPORT :: C_INT, C_LONG, C_PTR
+         INTEGER(C_INT),  VALUE :: algo, niter, iprecision, mem
+         TYPE(C_PTR),     VALUE :: U_N10, CdN10, ChN10, CeN10, z0, stream
+         INTEGER(C_LONG), VALUE :: n
+         INTEGER(C_INT) :: istat
+      END FUNCTION ab_turb_neutral_10m
+   END INTERFACE
+CONTAINS
+   SUBROUTINE TURB_NEUTRAL_10M( calgo, U_N10, CdN10, ChN10, CeN10, pz0 )
+      CHARACTER(len=*),         INTENT(in)  :: calgo
+      REAL(wp), DIMENSION(:,:), INTENT(in ) :: U_N10
+      REAL(wp), DIMENSION(:,:), INTENT(out) :: CdN10, ChN10, CeN10, pz0
+      INTEGER :: ialgo
+      SELECT CASE( TRIM(calgo) )
+      CASE('coare3p0') ; ialgo = 1
+      CASE('coare3p6') ; ialgo = 2
+      CASE('ncar')     ; ialgo = 3
+      CASE('ecmwf')    ; ialgo = 4
+      CASE DEFAULT
+         PRINT *, 'ERROR: algorithm '//TRIM(calgo)//' is not supported yet!'   ! mod_blk_neutral_10m.f90:195-197 (and :190 for andreas)
+         PRINT *, ''
+         STOP
+      END SELECT
+      PRINT *, ' *** Algo = ', TRIM(calgo)
+      CALL n10_contig( SIZE(U_N10), U_N10, CdN10, ChN10, CeN10, pz0 )
+   CONTAINS
+      SUBROUTINE n10_contig( n, a, o1, o2, o3, o4 )
+         INTEGER, INTENT(in) :: n
+         REAL(wp), DIMENSION(n), INTENT(in),  TARGET :: a
+         REAL(wp), DIMENSION(n), INTENT(out), TARGET :: o1, o2, o3, o4
+         INTEGER(C_INT) :: istat
+         istat = ab_turb_neutral_10m( INT(ialgo,C_INT), INT(nb_iter,C_INT), C_LOC(a), C_LOC(o1), C_LOC(o2), C_LOC(o3), C_LOC(o4), &
+            &                         INT(n,C_LONG), 0_C_INT, 0_C_INT, C_NULL_PTR )
+         IF( istat /= 0 ) STOP 'TURB_NEUTRAL_10M: engine error'
+      END SUBROUTINE n10_contig
+   END SUBROUTINE TURB_NEUTRAL_10M
+END MODULE mod_blk_neutral_10m

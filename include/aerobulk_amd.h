@@ -182,6 +182,12 @@ int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int 
             double *Cd, double *Ch, double *Ce, double *t_zu, double *q_zu, double *Ubzu,
             const ab_diag *opt, long ni, long nj);
 
+/* TURB_NEUTRAL_10M( calgo, U_N10, CdN10, ChN10, CeN10, pz0 ) (mod_blk_neutral_10m.f90:33): neutral 10 m transfer coefficients
+ * and roughness length from the neutral 10 m wind.  algo = AB_ALGO_COARE3P0 | COARE3P6 | ECMWF | NCAR (the reference STOPs for
+ * andreas: AB_ERR_ALGO).  Stateless; n cells of `precision` in `mem`. */
+int ab_turb_neutral_10m(int algo, int nb_iter, const void *U_N10, void *CdN10, void *ChN10, void *CeN10, void *z0, long n,
+                        int precision, int mem, void *stream);
+
 /* Sea-ice bulk algorithms (reference: src/ice/): TURB_ICE_NEMO mod_blk_ice_nemo.f90:36-38, TURB_ICE_AN05
  * mod_blk_ice_an05.f90:41-43, TURB_ICE_LU12 mod_blk_ice_lu12.f90:69-71, TURB_ICE_LG15 mod_blk_ice_lg15.f90:68-70, e.g.
  *   TURB_ICE_LG15( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, frice, Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu,

@@ -1285,6 +1285,57 @@ int abo_turb_ice(int ice_algo, long n, double zt, double zu, int nb_iter, const 
     return 0;
 }
 
+/* ---- turb_neutral_10m, mod_blk_neutral_10m.f90:33-209: neutral 10 m coefficients from the neutral 10 m wind.
+ * algo: coare3p0, coare3p6, ecmwf (nb_iter fixed-point passes on the Charnock + smooth-flow roughness), ncar (closed form);
+ * the reference STOPs for andreas ("YET TO BE CODED").  Outputs CdN10 ChN10 CeN10 z0. */
+int abo_turb_neutral_10m(int algo, long n, int nb_iter, const double *U_N10, double *CdN10, double *ChN10, double *CeN10,
+                         double *pz0)
+{
+    const double zu = 10., rnu0_air = 1.5E-5;   /* mod_blk_neutral_10m.f90:28, mod_const.f90:89 */
+    if (algo == ABO_ANDREAS || algo < ABO_COARE3P0 || algo > ABO_ANDREAS) return 2;
+    for (long k = 0; k < n; ++k) {
+        if (algo == ABO_NCAR) {
+            double Ub = dmax(U_N10[k], 0.5);
+            double cd = abo_cd_n10_ncar(Ub);
+            double sq = sqrt(cd);
+            CdN10[k] = cd;
+            ChN10[k] = dmax(1.e-3 * sq * (18. * (Ub * 0.) + 32.7 * (1. - Ub * 0.)), Cx_min);   /* pstab = Ub*0. :174 */
+            CeN10[k] = dmax(1.e-3 * (34.6 * sq), Cx_min);
+            pz0[k] = dmin(dmax(10. * exp(-vkarmn / sqrt(cd)), 0.0001), 0.1);
+            continue;
+        }
+        double Ub = dmax(U_N10[k], 0.1);
+        double cd = 8.575E-5 * Ub + 0.657E-3;
+        double u_star = 0., z0 = 0., ztmp0 = 0.;
+        for (int jit = 1; jit <= nb_iter; ++jit) {
+            u_star = Ub * sqrt(cd);
+            double charn = algo == ABO_COARE3P6 ? abo_charn_coare3p6(Ub) : (algo == ABO_COARE3P0 ? abo_charn_coare3p0(Ub) : 0.018);
+            z0 = charn * u_star * u_star / grav + 0.11 * rnu0_air / u_star;
+            ztmp0 = log(zu / z0);
+            cd = vkarmn2 / (ztmp0 * ztmp0);
+        }
+        double z0t, z0q;
+        if (algo == ABO_COARE3P0) {
+            double rr = z0 * u_star / rnu0_air;
+            z0t = dmin(1.1E-4, 5.5E-5 * pow(rr, -0.6));
+            z0q = z0t;
+        } else if (algo == ABO_COARE3P6) {
+            double rr = z0 * u_star / rnu0_air;
+            z0t = dmin(1.6e-4, 5.8E-5 * pow(rr, -0.72));
+            z0q = z0t;
+        } else {
+            double t = rnu0_air / u_star;
+            z0t = 0.40 * t;
+            z0q = 0.62 * t;
+        }
+        CdN10[k] = cd;
+        ChN10[k] = vkarmn2 / (ztmp0 * log(zu / z0t));
+        CeN10[k] = vkarmn2 / (ztmp0 * log(zu / z0q));
+        pz0[k] = z0;
+    }
+    return 0;
+}
+
 static int check_unit(long n, const double *x, const double *x2, int wind_module, const unsigned char *mask,
                       double zmin, double zmax)
 {

@@ -75,6 +75,11 @@ int abo_turb_ice(int ice_algo, long n, double zt, double zu, int nb_iter, const 
 double abo_psi_m_ice(double zeta);
 double abo_psi_h_ice(double zeta);
 
+/* turb_neutral_10m (mod_blk_neutral_10m.f90:33): neutral 10 m coefficients and roughness length from the neutral 10 m wind;
+ * algo = coare3p0 | coare3p6 | ecmwf | ncar (the reference STOPs for andreas). */
+int abo_turb_neutral_10m(int algo, long n, int nb_iter, const double *U_N10, double *CdN10, double *ChN10, double *CeN10,
+                         double *pz0);
+
 /* AEROBULK_INIT host checks (mod_aerobulk.f90:24-160): mask, humidity type, unit ranges.
  * Returns 0 ok; negative error codes:
  *  -1 whole domain masked, -2 humidity type unidentified, -3 unit-consistency failure

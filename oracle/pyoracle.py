@@ -68,6 +68,8 @@ def lib():
         for name in ("abo_psi_m_ice", "abo_psi_h_ice"):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double]
+        L.abo_turb_neutral_10m.restype = C.c_int
+        L.abo_turb_neutral_10m.argtypes = [C.c_int, C.c_long, C.c_int] + [_dp] * 5
         L.abo_synth_fields.restype = None
         L.abo_synth_fields.argtypes = [C.c_int] * 4 + [_dp] * 8
         for name, nargs in [("abo_e_sat", 1), ("abo_q_sat", 2), ("abo_theta_from_z_p0_t_q", 4),
@@ -344,6 +346,32 @@ def oracle_turb_ice(algo, niter, zt, zu, f):
     if rc:
         raise RuntimeError(f"abo_turb_ice rc={rc}")
     return dict(zip(ICE_OUT, d.reshape(13, n)))
+
+
+# ------------------------------------------------------------------ TURB_NEUTRAL_10M
+N10_OUT = ("CdN10", "ChN10", "CeN10", "z0")
+REF_N10_EXE = os.path.join(HERE, "_ref", "ref_neutral10_driver.x")
+
+
+def run_neutral10_driver(exe, algo, niter, U, timeout=600):
+    """A build of aerobulk_amd/fortran/neutral10_driver.f90 (reference modules or HIP engine); returns dict of N10_OUT."""
+    U = np.ascontiguousarray(U, dtype=np.float64)
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        U.tofile(fin)
+        pr = subprocess.run([exe, algo, str(int(niter)), str(U.size), fin, fout], capture_output=True, text=True, timeout=timeout)
+        if pr.returncode != 0 or not os.path.exists(fout) or os.path.getsize(fout) != 4 * U.size * 8:
+            raise RuntimeError(f"{exe} failed (rc={pr.returncode}):\n" + pr.stdout[-2000:] + pr.stderr[-2000:])
+        return dict(zip(N10_OUT, np.fromfile(fout, dtype=np.float64).reshape(4, U.size)))
+
+
+def oracle_neutral10(algo, niter, U):
+    U = np.ascontiguousarray(U, dtype=np.float64)
+    o = {k: np.empty(U.size) for k in N10_OUT}
+    rc = lib().abo_turb_neutral_10m(ALGOS[algo], U.size, niter, _p(U), *[_p(o[k]) for k in N10_OUT])
+    if rc:
+        raise RuntimeError(f"abo_turb_neutral_10m rc={rc}")
+    return o
 
 
 def ref_scalar(symbol, *args):
