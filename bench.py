@@ -99,6 +99,8 @@ def main():
                          "path can be exercised on a box with fewer GPUs than ranks")
     ap.add_argument("--verify", action="store_true", help="N>1: rank 0 recomputes the whole grid alone and checks the gathered "
                                                         "fields are bit-identical (outside the timed region)")
+    ap.add_argument("--gather-ts", action="store_true", help="N>1: also gather the skin temperature T_s (the north_star gather is "
+                                                           "the output tau / Q_L / Q_H / E arrays: 5 fields; T_s stays on its GPU)")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row sub-blocks per rank (gather of one overlaps compute of the next)")
     a = ap.parse_args()
 
@@ -139,13 +141,14 @@ def main():
     n_cpad = ni * cr
     nout = 6 if skin else 5
     names = ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")[:nout]
+    ngat = nout if a.gather_ts else 5            # fields that travel to rank 0
 
     # synthetic inputs generated straight into HBM; outputs packed [chunk, field, cell] for ONE gather per chunk
     f = ab.synth_fields_device(ni, nj, j0, max(njl, 1), precision=a.precision, device=dev, with_rad=True)
     outbuf = torch.zeros((chunks, nout, n_cpad), dtype=tdt, device=dev)
     gather_lists = None
     if world > 1 and rank == 0 and not a.no_gather:
-        gather_lists = [[torch.empty((nout, n_cpad), dtype=tdt, device=dev) for _ in range(world)] for _ in range(chunks)]
+        gather_lists = [[torch.empty((ngat, n_cpad), dtype=tdt, device=dev) for _ in range(world)] for _ in range(chunks)]
 
     work = []  # (session, inputs, rad, out) per non-empty chunk
     for c in range(chunks):
@@ -171,9 +174,9 @@ def main():
                 sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
             if world > 1 and not a.no_gather:
                 if a.backend == "nccl":
-                    pending.append(dist.gather(outbuf[c], gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
+                    pending.append(dist.gather(outbuf[c, :ngat], gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
                 else:  # test-only path: gloo gathers host tensors
-                    host = outbuf[c].cpu()
+                    host = outbuf[c, :ngat].cpu()
                     gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                     dist.gather(host, gl, dst=0)
                     if rank == 0:
@@ -190,7 +193,7 @@ def main():
 
     def assemble():
         """rank 0: global fields [nout, ni*nj] from the gathered chunk buffers (rank-major j-blocks, chunk-major inside)."""
-        glob = torch.empty((nout, ni * nj), dtype=tdt, device=dev)
+        glob = torch.empty((ngat, ni * nj), dtype=tdt, device=dev)
         for r in range(world):
             rj0, rnjl, _ = shard_rows(nj, world, r)
             for c in range(chunks):
@@ -243,7 +246,7 @@ def main():
             s1.set_humidity("sh")
             one = s1.compute(1, zt, zu, *[ff[k] for k in IN6], Niter=a.niter, rad_sw=ff["rad_sw"] if skin else None,
                              rad_lw=ff["rad_lw"] if skin else None, want_T_s=skin)
-        bad = [k for i, k in enumerate(names) if not torch.equal(glob[i], one[k])]
+        bad = [k for i, k in enumerate(names[:ngat]) if not torch.equal(glob[i], one[k])]
         verify_msg = "gathered == single-GPU (bit-identical)" if not bad else f"MISMATCH in {bad}"
         if bad:
             raise SystemExit("verify failed: " + verify_msg)
@@ -265,7 +268,7 @@ def main():
                                    f"zt=2 zu=10, one time record (jt=1=Nt), inputs/outputs resident in HBM",
                        "grid": [ni, nj], "algo": a.algo, "skin": skin, "nb_iter": a.niter,
                        "sharding": f"j-block x{world}" + ("" if world == 1 or a.no_gather else
-                                                            f" + RCCL gather of outputs to rank 0, {chunks} overlapped row chunks per rank")},
+                                                            f" + RCCL gather of {', '.join(names[:ngat])} to rank 0, {chunks} overlapped row chunks per rank")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None,
