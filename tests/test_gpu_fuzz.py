@@ -1,0 +1,47 @@
+"""Randomised parity: inputs drawn over the whole range AEROBULK_INIT accepts (mod_const.f90:138-146), including calm, very
+stable and very unstable cells, winds of 50 m/s, zt = zu and odd heights; HIP (regrouped tiles) against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity
+
+pytestmark = pytest.mark.gpu
+OUT = (("QL", "ql"), ("QH", "qh"), ("Tau_x", "tau_x"), ("Tau_y", "tau_y"), ("Evap", "evap"), ("T_s", "t_s"))
+
+
+def _fields(seed, n):
+    r = np.random.default_rng(seed)
+    sst = r.uniform(271.5, 305.0, n)
+    t = sst + r.uniform(-12.0, 10.0, n)
+    t[:: 97] = sst[:: 97]                                 # exactly neutral in temperature
+    slp = r.uniform(92000.0, 105000.0, n)
+    es = 611.2 * np.exp(17.62 * (t - 273.15) / (t - 30.03))
+    q = r.uniform(0.2, 1.0, n) * 0.622 * es / (slp - 0.378 * es)
+    w = r.uniform(0.0, 1.0, n) ** 2 * 40.0
+    w[:: 53] = 0.0                                        # dead calm
+    ang = r.uniform(0, 2 * np.pi, n)
+    return dict(sst=sst, t_zt=t, hum_zt=q, u_zu=w * np.cos(ang), v_zu=w * np.sin(ang), slp=slp,
+                rad_sw=np.where(r.uniform(size=n) < 0.3, 0.0, r.uniform(0.0, 1100.0, n)), rad_lw=r.uniform(150.0, 480.0, n))
+
+
+@pytest.mark.parametrize("seed", [11, 23])
+@pytest.mark.parametrize("algo,skin,zt,zu,niter", [("coare3p6", True, 2.0, 10.0, 5), ("coare3p6", False, 10.0, 10.0, 8),
+                                                    ("coare3p0", True, 3.5, 17.0, 4), ("ecmwf", True, 2.0, 10.0, 6),
+                                                    ("ecmwf", False, 2.0, 10.0, 5), ("ncar", False, 2.0, 10.0, 5),
+                                                    ("andreas", False, 8.0, 12.0, 7)])
+def test_random_inputs_match_oracle(oracle, seed, algo, skin, zt, zu, niter):
+    import aerobulk_amd as ab
+    n = 40000 + 13 * seed                                  # ragged: not a multiple of any tile size
+    f = _fields(seed, n)
+    ins = [f[k] for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")]
+    ref = oracle.OracleSession(algo, n, 1, skin).compute(1, zt, zu, niter, *ins, rad_sw=f["rad_sw"] if skin else None,
+                                                         rad_lw=f["rad_lw"] if skin else None)
+    try:
+        with ab.Session(algo, n, 1, 1, skin) as s:
+            got = s.compute(1, zt, zu, *ins, Niter=niter, rad_sw=f["rad_sw"] if skin else None, rad_lw=f["rad_lw"] if skin else None)
+    except ab.AerobulkError as e:                         # 40 m/s over a very unstable cell may exceed 10 N/m2: both must agree
+        assert e.status == 8 and ref["rc"] == 1, (e, ref["rc"])
+        return
+    assert ref["rc"] == 0
+    keys = OUT if skin else OUT[:5]
+    assert_parity({kr: got[k] for k, kr in keys}, ref, [kr for _, kr in keys], label=f"fuzz {algo} skin={skin} seed={seed}")
