@@ -34,6 +34,7 @@ template <class R> struct FluxArgs {
     Heights<R> h;
     int nb_iter, hum_type, wl_load, wl_store, isecday, dawn_uniform;
     int regroup;  // sort the tile's cells into like-behaved waves (see flux_kernel)
+    int rounds;   // tile = rounds*256 cells (<= Tile<R,SKIN>::kRounds)
 };
 
 // optional per-cell diagnostics of TURB_* (ab_session_set_diagnostics); read only by the DIAG instantiations
@@ -108,20 +109,24 @@ __device__ __forceinline__ int forecast_bucket(float sst, float theta, float q, 
 // Counting sort of the tile's cells by bucket: thread t owns the PER consecutive cells t*PER.., builds their histogram as
 // sixteen 16-bit counters packed in four 64-bit words, the block scans those (wave shuffle + 4 wave totals through LDS).
 template <int CELLS>
-__device__ __forceinline__ void tile_sort(const unsigned char *s_bkt, unsigned short *s_inv, unsigned long long (*s_wtot)[4], int tid)
+__device__ __forceinline__ void tile_sort(const unsigned char *s_bkt, unsigned short *s_inv, unsigned long long (*s_wtot)[4], int tid,
+                                          int per)
 {
     typedef unsigned long long u64;
-    constexpr int PER = CELLS / kBlock;
+    constexpr int PER = CELLS / kBlock;   // most cells a thread can own; `per` (<= PER) are in use (small grids: smaller tiles)
     const int lane = tid & 63, wave = tid >> 6;
     u64 h[4] = {0, 0, 0, 0};
     unsigned char b[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        b[i] = s_bkt[tid * PER + i];
-        const u64 inc = 1ull << ((b[i] & 3) * 16);
-        const int w = b[i] >> 2;
+        b[i] = 0;
+        if (i < per) {
+            b[i] = s_bkt[tid * per + i];
+            const u64 inc = 1ull << ((b[i] & 3) * 16);
+            const int w = b[i] >> 2;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) h[x] += (w == x) ? inc : 0ull;
+            for (int x = 0; x < 4; ++x) h[x] += (w == x) ? inc : 0ull;
+        }
     }
     u64 inc4[4] = {h[0], h[1], h[2], h[3]};          // inclusive scan over the 64 lanes
 #pragma unroll
@@ -160,14 +165,16 @@ __device__ __forceinline__ void tile_sort(const unsigned char *s_bkt, unsigned s
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int sh = (b[i] & 3) * 16, w = b[i] >> 2;
-        u64 cur = pos[0];
+        if (i < per) {
+            const int sh = (b[i] & 3) * 16, w = b[i] >> 2;
+            u64 cur = pos[0];
 #pragma unroll
-        for (int x = 1; x < 4; ++x) cur = (w == x) ? pos[x] : cur;
-        s_inv[(cur >> sh) & 0xffffu] = (unsigned short)(tid * PER + i);
-        const u64 inc = 1ull << sh;
+            for (int x = 1; x < 4; ++x) cur = (w == x) ? pos[x] : cur;
+            s_inv[(cur >> sh) & 0xffffu] = (unsigned short)(tid * per + i);
+            const u64 inc = 1ull << sh;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) pos[x] += (w == x) ? inc : 0ull;
+            for (int x = 0; x < 4; ++x) pos[x] += (w == x) ? inc : 0ull;
+        }
     }
 }
 
@@ -264,12 +271,13 @@ __global__ void __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU)
     __shared__ unsigned long long s_wtot[kBlock / 64][4];
     __shared__ int s_next;
     const int tid = threadIdx.x;
-    const long tile0 = (long)blockIdx.x * T::kCells;
+    const int rounds = a.rounds;                          // <= T::kRounds; fewer on small grids so that every CU gets blocks
+    const long tile0 = (long)blockIdx.x * ((long)rounds * kBlock);
 
     // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126
     if (tid == 0) s_next = 0;
 #pragma unroll 1
-    for (int r = 0; r < T::kRounds; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         const int j = r * kBlock + tid;
         const long k = tile0 + j;
         int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
@@ -301,10 +309,9 @@ __global__ void __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU)
     __syncthreads();
     // ---- phase 2: who computes which cell
     if (a.regroup) {
-        tile_sort<T::kCells>(s_bkt, s_inv, s_wtot, tid);
+        tile_sort<T::kCells>(s_bkt, s_inv, s_wtot, tid, rounds);
     } else {
-#pragma unroll
-        for (int r = 0; r < T::kRounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
+        for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
     }
     __syncthreads();
 
@@ -324,7 +331,7 @@ __global__ void __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU)
         int g = 0;
         if (lane == 0) g = atomicAdd(&s_next, 1);
         g = __builtin_amdgcn_readfirstlane(g);
-        if (g >= T::kGroups) break;
+        if (g >= rounds * (kBlock / 64)) break;
         const int j = s_inv[g * 64 + lane];
         const long k = tile0 + j;
         if (k >= a.n) continue;
@@ -340,7 +347,7 @@ __global__ void __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU)
 
     // ---- phase 4: owners store (coalesced)
 #pragma unroll 1
-    for (int r = 0; r < T::kRounds; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         const int j = r * kBlock + tid;
         const long k = tile0 + j;
         if (k >= a.n) break;
@@ -351,6 +358,19 @@ __global__ void __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU)
         if (a.evap) a.evap[k] = s_f[4][j];                                         // :208
         if (a.t_s) a.t_s[k] = s_f[5][j];                                           // :206
     }
+}
+
+// blocks the chip holds at once: 3 per CU (one wave of each block per SIMD)
+static long resident_block_slots()
+{
+    static long slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        slots = (long)cus * AB_WAVES_PER_EU;
+    }
+    return slots;
 }
 
 template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
@@ -372,7 +392,12 @@ template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCal
     a.isecday = c.isecday;
     a.dawn_uniform = dawn_at_lon0(c.isecday);
     a.regroup = c.regroup ? 1 : 0;
-    const long tile = (ALGO == 3) ? kBlock : Tile<R, SKIN>::kCells;
+    // full tiles when the grid fills the chip several times over; smaller ones on small grids so that every CU gets work
+    // (a 360x180 grid is 85 full tiles for 256 CUs, but 254 one-round tiles)
+    long rounds = c.n / ((long)kBlock * resident_block_slots());
+    rounds = rounds < 1 ? 1 : (rounds > Tile<R, SKIN>::kRounds ? Tile<R, SKIN>::kRounds : rounds);
+    a.rounds = (int)rounds;
+    const long tile = (ALGO == 3) ? kBlock : rounds * kBlock;
     const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;
     if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);

@@ -193,3 +193,38 @@ def test_pipelined_host_path_equals_device_path(oracle, torch_mod):
         wh, wd = sh.wl_state(), sd.wl_state()
         for k in wh:
             np.testing.assert_array_equal(wh[k], wd[k], err_msg=k)
+
+
+def test_time_loop_can_be_captured_in_a_hip_graph():
+    """AB_MEM_DEVICE calls only enqueue work on the caller's stream (kernel + two event records): a GPU-resident model can
+    capture its whole jt loop, warm-layer carry-over included, in a hipGraph (small grids are launch-bound otherwise)."""
+    import torch
+    import aerobulk_amd as ab
+    ni, nj, nt = 360, 180, 6
+    f = ab.synth_fields_device(ni, nj)
+    ins = [f[k] for k in ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp")]
+    with ab.Session("coare3p6", ni, nj, nt, True) as s:
+        s.set_humidity("sh")
+        outs = [{k: torch.empty(ni * nj, dtype=torch.float64, device="cuda") for k in ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")}
+                for _ in range(nt)]
+
+        def loop():
+            for jt in range(1, nt + 1):
+                s.compute(jt, 2.0, 10.0, *ins, Niter=5, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"], out=outs[jt - 1], check=False)
+        loop()
+        torch.cuda.synchronize()
+        ref = [{k: v.clone() for k, v in o.items()} for o in outs]
+        assert not torch.equal(ref[0]["T_s"], ref[-1]["T_s"])          # the warm layer evolves over the records
+        g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(g, stream=st):
+                loop()
+        for o in outs:
+            for v in o.values():
+                v.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(ref, outs):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+        s.check()
