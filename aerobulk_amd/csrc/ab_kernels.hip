@@ -34,7 +34,7 @@ template <class R> struct FluxArgs {
     Heights<R> h;
     int nb_iter, hum_type, wl_load, wl_store, isecday, dawn_uniform;
     int regroup;  // sort the tile's cells into like-behaved waves (see flux_kernel)
-    int rounds;   // tile = rounds*256 cells (<= Tile<R,SKIN>::kRounds)
+    int rounds;   // tile = rounds*256 cells (<= Tile<R,ALGO,SKIN>::kRounds)
 };
 
 // optional per-cell diagnostics of TURB_* (ab_session_set_diagnostics); read only by the DIAG instantiations
@@ -56,10 +56,13 @@ template <class R> struct DiagArgs {
 // The arithmetic per cell, hence every output bit, is the same as in natural order (tests/test_gpu_regroup.py); global
 // loads and stores stay coalesced and each field is still read once and written once.
 constexpr int kBuckets = 16;     // 4 stability bins x 4 warm-layer bins
-template <class R, bool SKIN> struct Tile {
+// resident blocks per CU (= waves per SIMD): 3 in fp64 (<= 168 VGPRs), 4 where the kernel fits 128 VGPRs without spilling --
+// every fp32 kernel (+10 %) and ECMWF + skin in fp64 (111 VGPRs, +4 %); COARE + skin spills at 128 and gains nothing
+template <class R, int ALGO, bool SKIN> constexpr int waves_per_simd() { return (sizeof(R) == 4 || (ALGO == 4 && SKIN)) ? 4 : AB_WAVES_PER_EU; }
+template <class R, int ALGO, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // sst theta q_zt u v slp [qsw rlw]
     // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) + bucket (1 B) per cell
-    static constexpr int kWaves = sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU;                 // fp32 fits 128 VGPRs (+10 %)
+    static constexpr int kWaves = waves_per_simd<R, ALGO, SKIN>();
     static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 3 (skin) / 4 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
@@ -243,7 +246,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
 }
 
 template <class R, int ALGO, bool SKIN, bool DIAG>
-__global__ void __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU)) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
+__global__ void __launch_bounds__(kBlock, (waves_per_simd<R, ALGO, SKIN>())) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
 {
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : AB_WAVES_PER_EU)
         if (a.t_s) a.t_s[k] = T_s;
         return;
     }
-    using T = Tile<R, SKIN>;
+    using T = Tile<R, ALGO, SKIN>;
     __shared__ R s_f[T::kFields][T::kCells];
     __shared__ unsigned short s_inv[T::kCells];
     __shared__ unsigned char s_bkt[T::kCells];
@@ -394,8 +397,8 @@ template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCal
     a.regroup = c.regroup ? 1 : 0;
     // full tiles when the grid fills the chip several times over; smaller ones on small grids so that every CU gets work
     // (a 360x180 grid is 85 full tiles for 256 CUs, but 254 one-round tiles)
-    long rounds = c.n / ((long)kBlock * resident_block_slots());
-    rounds = rounds < 1 ? 1 : (rounds > Tile<R, SKIN>::kRounds ? Tile<R, SKIN>::kRounds : rounds);
+    long rounds = c.n / ((long)kBlock * resident_block_slots() / AB_WAVES_PER_EU * waves_per_simd<R, ALGO, SKIN>());
+    rounds = rounds < 1 ? 1 : (rounds > Tile<R, ALGO, SKIN>::kRounds ? Tile<R, ALGO, SKIN>::kRounds : rounds);
     a.rounds = (int)rounds;
     const long tile = (ALGO == 3) ? kBlock : rounds * kBlock;
     const long nblk = (c.n + tile - 1) / tile;
