@@ -15,14 +15,11 @@
 
 namespace ab {
 
-// The wave-uniform height constants are laundered into VGPRs (see flux_kernel): -2 % (skin) / -5 % (no skin) measured on
-// the MI355X (profiles/r1_notes.md), PROVIDED the kernel stays at 3 waves/SIMD (<= 168 VGPRs, __launch_bounds__ below):
-// at 2 waves/SIMD the skin kernel loses 9 %.
-#ifndef AB_LAUNDER_HEIGHTS
-#define AB_LAUNDER_HEIGHTS(skin) true
-#endif
+// Resident blocks per CU = waves per SIMD.  Every flux kernel fits 128 VGPRs without scratch, so four blocks of 256 lanes
+// share a CU (and its 160 KB of LDS): measured 1.5-4 % faster than three blocks with larger tiles and the height constants
+// parked in VGPRs (profiles/r1_notes.md).
 #ifndef AB_WAVES_PER_EU
-#define AB_WAVES_PER_EU 3    // <= 168 VGPRs: scalar-load / SALU latencies want the third wave (no scratch needed)
+#define AB_WAVES_PER_EU 4
 #endif
 
 template <class R> struct FluxArgs {
@@ -45,10 +42,10 @@ template <class R> struct DiagArgs {
 // ---- lane regrouping ---------------------------------------------------------------------------------------------
 // The iteration takes divergent paths per cell: stable / unstable psi functions, warm layer gaining heat / idle.  On
 // spatially incoherent input (the quasi-random benchmark fields are the worst case) every wave holds all kinds of cells and
-// executes every path.  A block therefore owns a TILE of consecutive cells (768 with the skin schemes, 1024 without; 1280 /
-// 1792 in fp32), and works in four phases:
+// executes every path.  A block therefore owns a TILE of consecutive cells (512 with the skin schemes, 768 without; 1024 /
+// 1280 in fp32), and works in four phases:
 //   1. owners (thread = cell, natural order, coalesced loads): pre-processing of aerobulk_compute, an fp32 forecast of the
-//      two predicates -> one of 16 buckets, pre-processed inputs parked in LDS (field-major, 48 KB);
+//      two predicates -> one of 16 buckets, pre-processed inputs parked in LDS (field-major, <= 39 KB);
 //   2. counting sort of the tile's cell indices by bucket (packed 16-bit histograms, wave scan, no atomics);
 //   3. waves fetch groups of 64 like-behaved cells (dynamic queue, most work first come) and run TURB_* + BULK_FORMULA;
 //      results go back to the cell's LDS slot;
@@ -56,15 +53,12 @@ template <class R> struct DiagArgs {
 // The arithmetic per cell, hence every output bit, is the same as in natural order (tests/test_gpu_regroup.py); global
 // loads and stores stay coalesced and each field is still read once and written once.
 constexpr int kBuckets = 16;     // 4 stability bins x 4 warm-layer bins
-// resident blocks per CU (= waves per SIMD): 3 in fp64 (<= 168 VGPRs), 4 where the kernel fits 128 VGPRs without spilling --
-// every fp32 kernel (+10 %) and ECMWF + skin in fp64 (111 VGPRs, +4 %); COARE + skin spills at 128 and gains nothing
-template <class R, int ALGO, bool SKIN> constexpr int waves_per_simd() { return (sizeof(R) == 4 || (ALGO == 4 && SKIN)) ? 4 : AB_WAVES_PER_EU; }
 template <class R, int ALGO, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // sst theta q_zt u v slp [qsw rlw]
     // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) + bucket (1 B) per cell
-    static constexpr int kWaves = waves_per_simd<R, ALGO, SKIN>();
+    static constexpr int kWaves = AB_WAVES_PER_EU;
     static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256;
-    static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 3 (skin) / 4 ; f32: 4 / 5
+    static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;
 };
@@ -246,7 +240,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
 }
 
 template <class R, int ALGO, bool SKIN, bool DIAG>
-__global__ void __launch_bounds__(kBlock, (waves_per_simd<R, ALGO, SKIN>())) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
+__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
 {
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -320,15 +314,7 @@ __global__ void __launch_bounds__(kBlock, (waves_per_simd<R, ALGO, SKIN>())) flu
 
     // ---- phase 3: groups of 64 sorted cells, fetched from a queue
     const int lane = tid & 63;
-    Heights<R> hh = a.h;
-#ifndef AB_NO_VGPR_LAUNDERING
-    // The wave-uniform height constants are used all over the iteration loop.  Left in SGPRs they are spilled to VGPR
-    // lanes (the kernel holds >100 scalar values) and every use pays two v_readlane; there are spare VGPRs, so they are
-    // laundered into vector registers once.
-    if (AB_LAUNDER_HEIGHTS(SKIN))
-        asm volatile("" : "+v"(hh.zt), "+v"(hh.zu), "+v"(hh.log_zt), "+v"(hh.log_zu), "+v"(hh.log_10), "+v"(hh.log_ztu),
-                          "+v"(hh.log_zu10), "+v"(hh.inv_zu), "+v"(hh.zt_o_zu));
-#endif
+    const Heights<R> &hh = a.h;
 #pragma unroll 1
     for (;;) {
         int g = 0;
@@ -363,7 +349,7 @@ __global__ void __launch_bounds__(kBlock, (waves_per_simd<R, ALGO, SKIN>())) flu
     }
 }
 
-// blocks the chip holds at once: 3 per CU (one wave of each block per SIMD)
+// blocks the chip holds at once: AB_WAVES_PER_EU per CU (one wave of each block per SIMD)
 static long resident_block_slots()
 {
     static long slots = 0;
@@ -397,7 +383,7 @@ template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCal
     a.regroup = c.regroup ? 1 : 0;
     // full tiles when the grid fills the chip several times over; smaller ones on small grids so that every CU gets work
     // (a 360x180 grid is 85 full tiles for 256 CUs, but 254 one-round tiles)
-    long rounds = c.n / ((long)kBlock * resident_block_slots() / AB_WAVES_PER_EU * waves_per_simd<R, ALGO, SKIN>());
+    long rounds = c.n / ((long)kBlock * resident_block_slots());
     rounds = rounds < 1 ? 1 : (rounds > Tile<R, ALGO, SKIN>::kRounds ? Tile<R, ALGO, SKIN>::kRounds : rounds);
     a.rounds = (int)rounds;
     const long tile = (ALGO == 3) ? kBlock : rounds * kBlock;
