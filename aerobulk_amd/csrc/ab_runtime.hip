@@ -820,11 +820,19 @@ int ab_turb_ice(int ice_algo, double zt, double zu, int nb_iter, const ab_ice_fi
     }
     static void *scratch = nullptr;        // 19 planes, grow-only, one host caller at a time (like the reference)
     static size_t scratch_bytes = 0;
-    if (scratch_bytes < 19 * bytes) {
-        if (scratch) (void)hipFree(scratch);
+    static int scratch_dev = -1;
+    int dev = 0;
+    AB_HIP(hipGetDevice(&dev));
+    if (scratch_bytes < 19 * bytes || dev != scratch_dev) {
+        if (scratch) {
+            if (scratch_dev >= 0) (void)hipSetDevice(scratch_dev);
+            (void)hipFree(scratch);
+            (void)hipSetDevice(dev);
+        }
         scratch = nullptr; scratch_bytes = 0;
         AB_HIP(hipMalloc(&scratch, 19 * bytes));
         scratch_bytes = 19 * bytes;
+        scratch_dev = dev;
     }
     char *base = (char *)scratch;
     const void *din[6];
