@@ -117,7 +117,7 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter,
                        int mem, void *stream);
 int ab_session_check(ab_session *s);
 
-/* Lane regrouping of the flux kernel (default on).  A thread block owns a tile of ~1000 consecutive cells, parks their
+/* Lane regrouping of the flux kernel (default on).  A thread block owns a tile of 512-1280 consecutive cells, parks their
  * pre-processed inputs in LDS and sorts them so that each 64-lane wave works on cells that take the same branches (stable /
  * unstable stratification, warm layer gaining heat / idle): on spatially incoherent input this removes most of the SIMT
  * divergence.  Results are bit-identical with it on or off; off = natural order inside the tile.
