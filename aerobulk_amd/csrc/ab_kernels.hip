@@ -493,6 +493,14 @@ hipError_t launch_init_stats(const void *sst, const void *t_air, const void *hum
 }
 
 // ------------------------------------------------------------------------------------------------
+// a product the compiler may not contract into an fma with the sum that follows (ROCm's __dmul_rn is a plain `*`)
+__device__ __forceinline__ double dadd(double a, double b) { return a + b; }
+__device__ __forceinline__ double mul_rn(double a, double b)
+{
+    double t = a * b;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 // Synthetic inputs of SURVEY.md §8d.  Always evaluated in fp64, stored in R.
 template <class R>
 __global__ void __launch_bounds__(kBlock) synth_kernel(R *sst, R *t_zt, R *q_zt, R *u, R *v, R *slp, R *rsw, R *rlw,
@@ -506,23 +514,25 @@ __global__ void __launch_bounds__(kBlock) synth_kernel(R *sst, R *t_zt, R *q_zt,
     const double B[7] = {0.7548776662466927, 0.3247179572447460, 0.6710436067037893, 0.7320508075688772,
                          0.6457513110645906, 0.6055512754639891, 0.3588989435406740};
     const double C[7] = {0., 0.1, 0.2, 0.3, 0.4, 0.5, 0.6};
+    // every product rounded on its own (mul_rn), never contracted into an fma: bit-identical to the host generator of the
+    // oracle (gcc -ffp-contract=off), which frac() of numbers up to ~6000 would not survive otherwise
     double r[7];
 #pragma unroll
     for (int m = 0; m < 7; ++m) {
-        const double x = i * A[m] + j * B[m] + C[m];
-        r[m] = x - floor(x);
+        const double x = dadd(dadd(mul_rn(i, A[m]), mul_rn(j, B[m])), C[m]);
+        r[m] = dadd(x, -floor(x));
     }
-    const double s = 274.15 + 29. * r[0];
-    const double t = s - 6. + 9. * r[1];
-    const double p = 98000. + 5000. * r[2];
+    const double s = dadd(274.15, mul_rn(29., r[0]));
+    const double t = dadd(dadd(s, -6.), mul_rn(9., r[1]));
+    const double p = dadd(98000., mul_rn(5000., r[2]));
     sst[k] = (R)s;
     t_zt[k] = (R)t;
     slp[k] = (R)p;
-    q_zt[k] = (R)((0.55 + 0.4 * r[3]) * q_sat<double>(t, p));
-    u[k] = (R)(-14. + 28. * r[4]);
-    v[k] = (R)(-14. + 28. * r[5]);
-    if (rsw) rsw[k] = (R)(900. * r[6]);
-    if (rlw) rlw[k] = (R)(250. + 200. * r[0]);
+    q_zt[k] = (R)(dadd(0.55, mul_rn(0.4, r[3])) * q_sat<double>(t, p));   // q_sat: device math, within an ulp or two of libm
+    u[k] = (R)dadd(-14., mul_rn(28., r[4]));
+    v[k] = (R)dadd(-14., mul_rn(28., r[5]));
+    if (rsw) rsw[k] = (R)mul_rn(900., r[6]);
+    if (rlw) rlw[k] = (R)dadd(250., mul_rn(200., r[0]));
 }
 
 hipError_t launch_synth(void *sst, void *t_zt, void *q_zt, void *u, void *v, void *slp, void *rad_sw, void *rad_lw,

@@ -228,3 +228,15 @@ def test_time_loop_can_be_captured_in_a_hip_graph():
             for k in a:
                 assert torch.equal(a[k], b[k]), k
         s.check()
+
+
+def test_device_generator_reproduces_the_host_generator_bits(oracle):
+    """ab_synth_fields_device (bench inputs) == abo_synth_fields, bit for bit, except the humidity whose q_sat
+    goes through the device math library."""
+    import aerobulk_amd as ab
+    ni, nj = 4320, 40
+    fd = ab.synth_fields_device(ni, nj)
+    fh = oracle.synth_fields(ni, nj)
+    for kd, kh in (("sst", "sst"), ("t_zt", "t_zt"), ("U_zu", "u_zu"), ("V_zu", "v_zu"), ("slp", "slp"), ("rad_sw", "rad_sw"), ("rad_lw", "rad_lw")):
+        np.testing.assert_array_equal(fd[kd].cpu().numpy(), fh[kh], err_msg=kd)
+    np.testing.assert_allclose(fd["hum_zt"].cpu().numpy(), fh["hum_zt"], rtol=1e-14, atol=0)   # e_sat surrogate: <= 6e-15
