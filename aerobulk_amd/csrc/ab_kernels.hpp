@@ -42,6 +42,7 @@ struct TurbCall {
     int algo;
     int skin;        // bit 0: l_use_cs, bit 1: l_use_wl
     int f32, nb_iter, wl_load, wl_store, isecday;
+    int regroup;     // as FluxCall::regroup
 };
 hipError_t launch_turb(const TurbCall &c, hipStream_t stream);
 

@@ -576,6 +576,7 @@ int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int
     c.wl_load = (use_wl && kt > 1) ? 1 : 0;
     c.wl_store = use_wl ? 1 : 0;
     c.isecday = s->isecday;
+    c.regroup = s->regroup;
     AB_HIP(hipEventRecord(s->ev0, st));
     AB_HIP(ab::launch_turb(c, st));
     AB_HIP(hipEventRecord(s->ev1, st));

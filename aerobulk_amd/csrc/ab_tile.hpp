@@ -1,0 +1,159 @@
+// ab_tile.hpp — tile machinery shared by flux_kernel (ab_kernels.hip) and turb_kernel (ab_turb_kernels.hip): LDS budget of
+// a block, forecast of a cell's divergent predicates, counting sort of a tile's cells by bucket, tile size on small grids.
+// The method is described at flux_kernel.  Internal; include after ab_physics.hpp and ab_launch.hpp.
+#pragma once
+
+namespace ab {
+
+// Resident blocks per CU = waves per SIMD.  Every flux kernel fits 128 VGPRs without scratch, so four blocks of 256 lanes
+// share a CU (and its 160 KB of LDS): measured 1.5-4 % faster than three blocks with larger tiles and the height constants
+// parked in VGPRs (profiles/r1_notes.md).
+#ifndef AB_WAVES_PER_EU
+#define AB_WAVES_PER_EU 4
+#endif
+
+constexpr int kBuckets = 16;     // 4 stability bins x 4 warm-layer bins
+template <class R, int ALGO, bool SKIN> struct Tile {
+    static constexpr int kFields = SKIN ? 8 : 6;                       // flux: sst theta q_zt u v slp [qsw rlw] ; turb: 8 / 6 too
+    // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) + bucket (1 B) per cell
+    static constexpr int kWaves = AB_WAVES_PER_EU;
+    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256;
+    static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
+    static constexpr int kCells = kRounds * kBlock;
+    static constexpr int kGroups = kCells / 64;
+};
+
+// Forecast of (warm layer gains heat, stable) for a cell, with an uncertainty band around each threshold so that the
+// doubtful cells sit together at the bucket borders.  fp32, hardware transcendentals: < 1 % of the work of one cell.
+template <int ALGO, bool SKIN>
+__device__ __forceinline__ int forecast_bucket(float sst, float theta, float q, float uu, float vv, float slp, float qsw,
+                                               float rlw, bool wl_load, float dTprev, float Hzprev)
+{
+    using F = float;
+    using M = Mth<F>;
+    F Ts = SKIN ? sst - 0.25f : sst;
+    if (SKIN && wl_load) Ts += dTprev;
+    const F qs = 0.98f * q_sat<F>(Ts, slp);
+    F dthv = theta * (1.f + 0.608f * q) - Ts * (1.f + 0.608f * qs);   // sign of the bulk Richardson number
+    int wbin = 0;
+    if (SKIN && ALGO != 4) {   // WL_COARE runs its depth solve only where the layer gains heat (mod_skin_coare.f90:171-185)
+        const F w2 = uu * uu + vv * vv;
+        const F wnd = M::sqrt(w2), Ub = vmax(M::sqrt(w2 + 0.25f), 0.5f);
+        const F Cx = dthv > 0.f ? 0.96e-3f : 1.38e-3f;
+        const F t2 = Ts * Ts;
+        const F qns = 1.2f * Ub * Cx * (1005.f * (theta - Ts) + 2.45e6f * (q - qs)) + 0.98f * (rlw - 5.67e-8f * t2 * t2);
+        const F Hz = wl_load ? vmax(vmin(Hzprev, 20.f), 0.1f) : 20.f;
+        const F qabs = wl_absorb<F>(Hz) * qsw + qns;
+        wbin = qabs < -40.f ? 0 : (qabs < 0.f ? 1 : (qabs < 40.f ? 2 : 3));
+        if (wl_load && M::abs(dTprev) >= 1.e-6f && wbin < 2) wbin = 2;
+        if (qabs > 0.f) {      // the warming of this record shifts the stability: estimate of mod_skin_coare.f90:199-224
+            const F alpha = alpha_sw<F>(sst);
+            const F tac = vmax(1.44e-3f * Ub * wnd, 0.002f) * 3600.f;
+            const F qac = qabs * 3600.f;
+            const F hz = vmax(vmin(20.f, M::sqrt(5.422e-1f * M::rcp(alpha)) * tac * M::rsqrt_pos(qac)), 0.1f);
+            F dT = M::sqrt(2.942e-2f * alpha) * 3.687e-6f * qac * M::sqrt(qac) * M::rcp(tac);
+            if (hz < 1.f) dT *= M::rcp(hz);
+            dthv -= dT * (1.f + 11.5f * qs);
+        }
+    }
+    const int sbin = dthv < -0.3f ? 0 : (dthv < 0.f ? 1 : (dthv < 0.3f ? 2 : 3));
+    // stability is the major key (it matters in every iteration, the warm layer only in those that commit); snake order:
+    // neighbouring buckets differ in one predicate only.  Measured: -4.6 % against warm layer major; band widths
+    // 0.15-0.6 K / 40-80 W/m2 and 8 x 2 bins are all within 2 % (profiles/r1_notes.md)
+    return sbin * 4 + ((sbin & 1) ? 3 - wbin : wbin);
+}
+
+// Counting sort of the tile's cells by bucket: thread t owns the PER consecutive cells t*PER.., builds their histogram as
+// sixteen 16-bit counters packed in four 64-bit words, the block scans those (wave shuffle + 4 wave totals through LDS).
+template <int CELLS>
+__device__ __forceinline__ void tile_sort(const unsigned char *s_bkt, unsigned short *s_inv, unsigned long long (*s_wtot)[4], int tid,
+                                          int per)
+{
+    typedef unsigned long long u64;
+    constexpr int PER = CELLS / kBlock;   // most cells a thread can own; `per` (<= PER) are in use (small grids: smaller tiles)
+    const int lane = tid & 63, wave = tid >> 6;
+    u64 h[4] = {0, 0, 0, 0};
+    unsigned char b[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        b[i] = 0;
+        if (i < per) {
+            b[i] = s_bkt[tid * per + i];
+            const u64 inc = 1ull << ((b[i] & 3) * 16);
+            const int w = b[i] >> 2;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) h[x] += (w == x) ? inc : 0ull;
+        }
+    }
+    u64 inc4[4] = {h[0], h[1], h[2], h[3]};          // inclusive scan over the 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const u64 t = __shfl_up(inc4[x], d);
+            if (lane >= d) inc4[x] += t;
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) s_wtot[wave][x] = inc4[x];
+    }
+    __syncthreads();
+    u64 pos[4], tot[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        pos[x] = inc4[x] - h[x];
+        tot[x] = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            const u64 t = s_wtot[w][x];
+            tot[x] += t;
+            if (w < wave) pos[x] += t;
+        }
+    }
+    // exclusive prefix over the 16 bucket totals -> first slot of each bucket, packed the same way
+    const u64 ones = 0x0001000100010001ull;
+    u64 carry = 0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const u64 p = tot[x] + (tot[x] << 16) + (tot[x] << 32) + (tot[x] << 48);   // inclusive prefix inside the word
+        pos[x] += p - tot[x] + carry * ones;
+        carry += p >> 48;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (i < per) {
+            const int sh = (b[i] & 3) * 16, w = b[i] >> 2;
+            u64 cur = pos[0];
+#pragma unroll
+            for (int x = 1; x < 4; ++x) cur = (w == x) ? pos[x] : cur;
+            s_inv[(cur >> sh) & 0xffffu] = (unsigned short)(tid * per + i);
+            const u64 inc = 1ull << sh;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) pos[x] += (w == x) ? inc : 0ull;
+        }
+    }
+}
+
+// blocks the chip holds at once: AB_WAVES_PER_EU per CU (one wave of each block per SIMD)
+static inline long resident_block_slots()
+{
+    static long slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        slots = (long)cus * AB_WAVES_PER_EU;
+    }
+    return slots;
+}
+
+// full tiles when the grid fills the chip several times over; smaller ones on small grids so that every CU gets work
+// (a 360x180 grid is 127 two-round tiles for 256 CUs, but 254 one-round tiles)
+static inline int tile_rounds(long n, int max_rounds)
+{
+    long rounds = n / ((long)kBlock * resident_block_slots());
+    return (int)(rounds < 1 ? 1 : (rounds > max_rounds ? max_rounds : rounds));
+}
+
+}  // namespace ab

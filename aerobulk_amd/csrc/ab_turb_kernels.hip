@@ -5,11 +5,11 @@
 // transfer coefficients, air temperature / humidity adjusted to zu, bulk wind, the OPTIONAL diagnostics, and T_s / q_s
 // updated in place by the cool-skin (bit 0 of SKIN) and / or warm-layer (bit 1) scheme.  This is the entry the reference's
 // station drivers use (tests/test_aerobulk_buoy_series_oce.f90:452-487), with the real solar time of WL_COARE.
-// Same per-cell physics (ab_physics.hpp) and the same one-lane-per-cell streaming layout as flux_kernel (ab_kernels.hip);
-// the lean flux kernels are not touched by this file.
+// Same per-cell physics (ab_physics.hpp) and the same LDS-staged, regrouped tiles as flux_kernel (ab_kernels.hip, ab_tile.hpp).
 #include "ab_kernels.hpp"
 #include "ab_physics.hpp"
 #include "ab_launch.hpp"
+#include "ab_tile.hpp"
 
 namespace ab {
 
@@ -21,24 +21,15 @@ template <class R> struct TurbArgs {
     long n;
     Heights<R> h;
     int nb_iter, wl_load, wl_store, isecday, dawn_uniform;
+    int regroup, rounds;
 };
 
+// One cell of a TURB_* call: returns the eight values that go back to the caller's arrays (Cd Ch Ce t_zu q_zu Ubzu T_s q_s);
+// the OPTIONAL outputs and the warm-layer state are written straight to global memory at cell k.
 template <class R, int ALGO, int SKIN>
-__global__ void __launch_bounds__(kBlock) turb_kernel(const TurbArgs<R> a)
+__device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, long k, const CellIn<R> &in, R (&res)[8])
 {
-    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= a.n) return;
     constexpr bool WL = (SKIN & kSkinWL) != 0;
-    CellIn<R> in;
-    in.sst = a.T_s[k];
-    in.theta_zt = a.theta_zt[k];
-    in.ssq = a.q_s[k];
-    in.q_zt = a.q_zt[k];
-    in.wnd = a.U_zu[k];
-    in.slp = SKIN ? a.slp[k] : R(101000.);
-    in.qsw = SKIN ? a.qsw[k] : R(0.);
-    in.rlw = SKIN ? a.rad_lw[k] : R(0.);
-
     R wl[4] = {R(0.), R(0.), R(0.), R(0.)};
     bool dawn = false;
     if (WL) {
@@ -51,27 +42,115 @@ __global__ void __launch_bounds__(kBlock) turb_kernel(const TurbArgs<R> a)
         }
         if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>(a.lon[k], a.isecday) : (a.dawn_uniform != 0);
     }
-
     CellOut<R> o;
     if (ALGO == 1) turb_coare<R, false, SKIN, true>(a.h, in, a.nb_iter, wl, dawn, o);
     else if (ALGO == 2) turb_coare<R, true, SKIN, true>(a.h, in, a.nb_iter, wl, dawn, o);
     else if (ALGO == 3) turb_ncar<R, true>(a.h, in, a.nb_iter, o);
     else if (ALGO == 4) turb_ecmwf<R, SKIN, true>(a.h, in, a.nb_iter, wl, o);
     else turb_andreas<R, true>(a.h, in, a.nb_iter, o);
-
-    const R d[16] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
-                     o.dT_cs, o.dT_wl, o.Hz_wl};
+    const R d[10] = {o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10, o.dT_cs, o.dT_wl, o.Hz_wl};
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (a.out[i]) a.out[i][k] = d[i];
-    if (SKIN) {   // T_s, q_s are INTENT(inout): skin temperature and its saturation humidity on return
-        a.T_s[k] = o.T_s;
-        a.q_s[k] = o.q_s;
-    }
+    for (int i = 0; i < 10; ++i)
+        if (a.out[6 + i]) a.out[6 + i][k] = d[i];
     if (WL && a.wl_store) {
         a.wl0[k] = wl[0];
         a.wl1[k] = wl[1];
         if (ALGO != 4) { a.wl2[k] = wl[2]; a.wl3[k] = wl[3]; }
+    }
+    res[0] = o.Cd; res[1] = o.Ch; res[2] = o.Ce; res[3] = o.t_zu; res[4] = o.q_zu; res[5] = o.Ubzu; res[6] = o.T_s; res[7] = o.q_s;
+}
+
+// Same four phases as flux_kernel (ab_kernels.hip): owners park the inputs of a tile in LDS and forecast each cell's
+// branches, the tile is sorted, waves fetch groups of like-behaved cells, owners store.  NCAR keeps one lane per cell.
+template <class R, int ALGO, int SKIN>
+__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const TurbArgs<R> a)
+{
+    constexpr bool ANYSKIN = SKIN != 0;
+    if (ALGO == 3) {
+        const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+        if (k >= a.n) return;
+        CellIn<R> in;
+        in.sst = a.T_s[k]; in.theta_zt = a.theta_zt[k]; in.ssq = a.q_s[k]; in.q_zt = a.q_zt[k]; in.wnd = a.U_zu[k];
+        in.slp = R(101000.); in.qsw = R(0.); in.rlw = R(0.);
+        R res[8];
+        turb_cell<R, ALGO, SKIN>(a, k, in, res);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.out[i][k] = res[i];
+        return;
+    }
+    using T = Tile<R, ALGO, ANYSKIN>;
+    __shared__ R s_f[T::kFields][T::kCells];       // in: T_s theta q_s q_zt U [slp] [qsw rlw] ; out: the 8 results (6 without skin)
+    __shared__ unsigned short s_inv[T::kCells];
+    __shared__ unsigned char s_bkt[T::kCells];
+    __shared__ unsigned long long s_wtot[kBlock / 64][4];
+    __shared__ int s_next;
+    const int tid = threadIdx.x;
+    const int rounds = a.rounds;
+    const long tile0 = (long)blockIdx.x * ((long)rounds * kBlock);
+    if (tid == 0) s_next = 0;
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const int j = r * kBlock + tid;
+        const long k = tile0 + j;
+        int bkt = kBuckets - 1;
+        if (k < a.n) {
+            const R Ts = a.T_s[k], th = a.theta_zt[k], qs = a.q_s[k], q = a.q_zt[k], w = a.U_zu[k];
+            s_f[0][j] = Ts; s_f[1][j] = th; s_f[2][j] = qs; s_f[3][j] = q; s_f[4][j] = w;
+            R slp = R(101000.), qsw = R(0.), rlw = R(0.);
+            if (ANYSKIN) {
+                slp = a.slp[k]; qsw = a.qsw[k]; rlw = a.rad_lw[k];
+                s_f[5][j] = slp; s_f[ANYSKIN ? 6 : 0][j] = qsw; s_f[ANYSKIN ? 7 : 0][j] = rlw;
+            }
+            bkt = 0;
+            if (a.regroup) {
+                const bool wll = (SKIN & kSkinWL) && a.wl_load;
+                // the flux kernel's forecast: with the cool skin off no 0.25 K first guess, with the warm layer off no warm-layer bins
+                bkt = forecast_bucket<ALGO, (SKIN & kSkinWL) != 0>((float)((SKIN & kSkinCS) && !(SKIN & kSkinWL) ? Ts - R(0.25) : Ts), (float)th,
+                                                                (float)q, (float)w, 0.f, (float)slp, (float)qsw, (float)rlw, wll,
+                                                                wll ? (float)a.wl0[k] : 0.f, (wll && ALGO != 4) ? (float)a.wl1[k] : 20.f);
+            }
+        }
+        s_bkt[j] = (unsigned char)bkt;
+    }
+    __syncthreads();
+    if (a.regroup) {
+        tile_sort<T::kCells>(s_bkt, s_inv, s_wtot, tid, rounds);
+    } else {
+        for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+#pragma unroll 1
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&s_next, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= rounds * (kBlock / 64)) break;
+        const int j = s_inv[g * 64 + lane];
+        const long k = tile0 + j;
+        if (k >= a.n) continue;
+        CellIn<R> in;
+        in.sst = s_f[0][j]; in.theta_zt = s_f[1][j]; in.ssq = s_f[2][j]; in.q_zt = s_f[3][j]; in.wnd = s_f[4][j];
+        in.slp = ANYSKIN ? s_f[5][j] : R(101000.);
+        in.qsw = ANYSKIN ? s_f[ANYSKIN ? 6 : 0][j] : R(0.);
+        in.rlw = ANYSKIN ? s_f[ANYSKIN ? 7 : 0][j] : R(0.);
+        R res[8];
+        turb_cell<R, ALGO, SKIN>(a, k, in, res);
+#pragma unroll
+        for (int i = 0; i < (ANYSKIN ? 8 : 6); ++i) s_f[i][j] = res[i];    // the slot is read by this lane only: reuse it
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const int j = r * kBlock + tid;
+        const long k = tile0 + j;
+        if (k >= a.n) break;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.out[i][k] = s_f[i][j];
+        if (ANYSKIN) {   // T_s, q_s are INTENT(inout): skin temperature and its saturation humidity on return
+            a.T_s[k] = s_f[ANYSKIN ? 6 : 0][j];
+            a.q_s[k] = s_f[ANYSKIN ? 7 : 0][j];
+        }
     }
 }
 
@@ -87,7 +166,10 @@ template <class R, int ALGO, int SKIN> static hipError_t launch_t(const TurbCall
     a.h = make_heights<R>(c.zt, c.zu);
     a.nb_iter = c.nb_iter; a.wl_load = c.wl_load; a.wl_store = c.wl_store; a.isecday = c.isecday;
     a.dawn_uniform = dawn_at_lon0(c.isecday);
-    const long nblk = (c.n + kBlock - 1) / kBlock;
+    a.regroup = c.regroup ? 1 : 0;
+    a.rounds = tile_rounds(c.n, Tile<R, ALGO, (SKIN != 0)>::kRounds);
+    const long tile = (ALGO == 3) ? kBlock : (long)a.rounds * kBlock;
+    const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;
     hipLaunchKernelGGL((turb_kernel<R, ALGO, SKIN>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a);
     return hipGetLastError();

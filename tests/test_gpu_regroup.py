@@ -54,3 +54,33 @@ def test_regrouped_tiny_and_large_grids(oracle):
         got = _run("ecmwf", True, f, n)[0]
         for k in ref:
             np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{ni}x{nj} {k}")
+
+
+@pytest.mark.parametrize("algo,cs,wl", [("coare3p6", True, True), ("coare3p6", True, False), ("coare3p0", False, True),
+                                        ("ecmwf", True, True), ("coare3p6", False, False), ("andreas", False, False)])
+def test_regrouped_turb_bits_equal_natural_order(oracle, algo, cs, wl):
+    """The TURB_* entry (ab_session_turb) runs on the same tile machinery."""
+    import aerobulk_amd as ab
+    ni, nj = 911, 29
+    f = oracle.synth_fields(ni, nj)
+    n = ni * nj
+    L = oracle.lib()
+    wnd = np.sqrt(f["u_zu"] ** 2 + f["v_zu"] ** 2)
+    theta = f["t_zt"] + 0.0196
+    ssq = 0.98 * 3.8e-3 * np.exp(0.0687 * (f["sst"] - 273.15))
+    skin = cs or wl
+    res = []
+    for on in (False, True):
+        with ab.Session(algo, n, 1, 3, False) as s:
+            s.set_regroup(on)
+            d = s.set_diagnostics(("CdN", "u_star", "L", "dT_cs", "dT_wl"))
+            rec = []
+            for kt in (1, 2, 3):
+                T_s, q_s = f["sst"].copy(), ssq.copy()
+                o = s.turb(kt, 2.0, 10.0, T_s, theta, q_s, f["hum_zt"], wnd, cs, wl, Qsw=0.934 * f["rad_sw"] if skin else None,
+                           rad_lw=f["rad_lw"] if skin else None, slp=f["slp"] if skin else None, nb_iter=5)
+                rec.append({**{k: v.copy() for k, v in o.items()}, **{k: v.copy() for k, v in d.items()}, "T_s": T_s, "q_s": q_s})
+            res.append(rec)
+    for a, b in zip(*res):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{algo} cs={cs} wl={wl} {k}")
