@@ -1,12 +1,13 @@
 // ab_ice_kernels.hip — the sea-ice bulk algorithms TURB_ICE_NEMO / AN05 / LU12 / LG15 as HIP kernels (gfx950).
 //
-// ice_kernel<R,ALGO>: one lane per cell, coalesced streaming of 5-6 input and 6-13 output fields, the nb_iter iteration in
-// registers (ab_physics_ice.hpp).  Algorithmic bytes per cell, fp64: 5 in + 6 out = 88 B (+ 8 B ice concentration for
+// ice_kernel<R,ALGO>: coalesced streaming of 5-6 input and 6-13 output fields, the nb_iter iteration in registers
+// (ab_physics_ice.hpp).  Algorithmic bytes per cell, fp64: 5 in + 6 out = 88 B (+ 8 B ice concentration for
 // LU12, + 8 B per OPTIONAL output).  NEMO / LU12 are HBM-bound (no iteration), AN05 / LG15 VALU-bound like the open-ocean
 // algorithms.
 #include "ab_kernels.hpp"
 #include "ab_physics_ice.hpp"
 #include "ab_launch.hpp"
+#include "ab_tile.hpp"
 
 namespace ab {
 
@@ -15,21 +16,12 @@ template <class R> struct IceArgs {
     R *out[13];
     long n;
     Heights<R> h;
-    int nb_iter;
+    int nb_iter, regroup, rounds;
 };
 
-template <class R, int ALGO> __global__ void __launch_bounds__(kBlock) ice_kernel(const IceArgs<R> a)
+template <class R, int ALGO>
+__device__ __forceinline__ void ice_cell(const IceArgs<R> &a, const IceIn<R> &in, IceOut<R> &o)
 {
-    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= a.n) return;
-    IceIn<R> in;
-    in.Ts_i = a.Ts_i[k];
-    in.theta_zt = a.theta_zt[k];
-    in.qs_i = a.qs_i[k];
-    in.q_zt = a.q_zt[k];
-    in.wnd = a.U_zu[k];
-    in.frice = (ALGO == 3) ? a.frice[k] : R(0.);
-    IceOut<R> o;
     if (ALGO == 1) {
         turb_ice_const<R>(a.h, in, KIce<R>::rCd_ice, o);
     } else if (ALGO == 2) {
@@ -40,10 +32,90 @@ template <class R, int ALGO> __global__ void __launch_bounds__(kBlock) ice_kerne
     } else {
         turb_ice_lg15<R>(a.h, in, a.frice[a.n - 1], a.nb_iter, o);   // wave-uniform load of the last cell's concentration
     }
-    const R d[13] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ub, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10};
+}
+
+// NEMO / LU12 (no iteration, HBM-bound): one lane per cell.  AN05 / LG15 (nb_iter iterations with stable / unstable branches):
+// the LDS-staged, regrouped tiles of flux_kernel (ab_tile.hpp); the bucket is the sign of the air-ice virtual temperature
+// difference in four bins.
+template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) ice_kernel(const IceArgs<R> a)
+{
+    if (ALGO == 1 || ALGO == 3) {
+        const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+        if (k >= a.n) return;
+        IceIn<R> in;
+        in.Ts_i = a.Ts_i[k]; in.theta_zt = a.theta_zt[k]; in.qs_i = a.qs_i[k]; in.q_zt = a.q_zt[k]; in.wnd = a.U_zu[k];
+        in.frice = (ALGO == 3) ? a.frice[k] : R(0.);
+        IceOut<R> o;
+        ice_cell<R, ALGO>(a, in, o);
+        const R d[13] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ub, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10};
 #pragma unroll
-    for (int i = 0; i < 13; ++i)
-        if (a.out[i]) a.out[i][k] = d[i];
+        for (int i = 0; i < 13; ++i)
+            if (a.out[i]) a.out[i][k] = d[i];
+        return;
+    }
+    using T = Tile<R, ALGO, false>;               // 6 fields: in Ts theta qs q U ; out the six mandatory results
+    __shared__ R s_f[T::kFields][T::kCells];
+    __shared__ unsigned short s_inv[T::kCells];
+    __shared__ unsigned char s_bkt[T::kCells];
+    __shared__ unsigned long long s_wtot[kBlock / 64][4];
+    __shared__ int s_next;
+    const int tid = threadIdx.x;
+    const int rounds = a.rounds;
+    const long tile0 = (long)blockIdx.x * ((long)rounds * kBlock);
+    if (tid == 0) s_next = 0;
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const int j = r * kBlock + tid;
+        const long k = tile0 + j;
+        int bkt = kBuckets - 1;
+        if (k < a.n) {
+            const R Ts = a.Ts_i[k], th = a.theta_zt[k], qs = a.qs_i[k], q = a.q_zt[k], w = a.U_zu[k];
+            s_f[0][j] = Ts; s_f[1][j] = th; s_f[2][j] = qs; s_f[3][j] = q; s_f[4][j] = w;
+            bkt = 0;
+            if (a.regroup) {
+                const float dthv = (float)th * (1.f + 0.608f * (float)q) - (float)Ts * (1.f + 0.608f * (float)qs);
+                bkt = 4 * (dthv < -0.3f ? 0 : (dthv < 0.f ? 1 : (dthv < 0.3f ? 2 : 3)));
+            }
+        }
+        s_bkt[j] = (unsigned char)bkt;
+    }
+    __syncthreads();
+    if (a.regroup) {
+        tile_sort<T::kCells>(s_bkt, s_inv, s_wtot, tid, rounds);
+    } else {
+        for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+#pragma unroll 1
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&s_next, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= rounds * (kBlock / 64)) break;
+        const int j = s_inv[g * 64 + lane];
+        const long k = tile0 + j;
+        if (k >= a.n) continue;
+        IceIn<R> in;
+        in.Ts_i = s_f[0][j]; in.theta_zt = s_f[1][j]; in.qs_i = s_f[2][j]; in.q_zt = s_f[3][j]; in.wnd = s_f[4][j];
+        in.frice = R(0.);
+        IceOut<R> o;
+        ice_cell<R, ALGO>(a, in, o);
+        const R d7[7] = {o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10};
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            if (a.out[6 + i]) a.out[6 + i][k] = d7[i];           // OPTIONAL outputs: straight to global memory
+        s_f[0][j] = o.Cd; s_f[1][j] = o.Ch; s_f[2][j] = o.Ce; s_f[3][j] = o.t_zu; s_f[4][j] = o.q_zu; s_f[5][j] = o.Ub;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const int j = r * kBlock + tid;
+        const long k = tile0 + j;
+        if (k >= a.n) break;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.out[i][k] = s_f[i][j];
+    }
 }
 
 template <class R, int ALGO> static hipError_t launch_t(const IceCall &c, hipStream_t stream)
@@ -55,7 +127,10 @@ template <class R, int ALGO> static hipError_t launch_t(const IceCall &c, hipStr
     a.n = c.n;
     a.h = make_heights<R>(c.zt, c.zu);
     a.nb_iter = c.nb_iter;
-    const long nblk = (c.n + kBlock - 1) / kBlock;
+    a.regroup = 1;
+    a.rounds = tile_rounds(c.n, Tile<R, ALGO, false>::kRounds);
+    const long tile = (ALGO == 1 || ALGO == 3) ? kBlock : (long)a.rounds * kBlock;
+    const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;
     hipLaunchKernelGGL((ice_kernel<R, ALGO>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a);
     return hipGetLastError();
