@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the j-block sharding + packed-gather assembly that bench.py uses for N>1.
+"""CPU, world_size 2 / 4 / 8 over gloo: the j-block sharding + packed-gather assembly that bench.py uses for N>1.
 The per-rank compute is stood in by the CPU oracle (the HIP kernel needs a GPU; the path is pointwise, so the
 sharding logic is independent of who computes a cell).  Checks that the gathered global field is bit-identical
 to the single-process result — the property the multi-GPU run relies on (no halo)."""
@@ -44,13 +44,13 @@ def _worker(rank, world, port, ni, nj, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nj", [40, 41])  # divisible and ragged row counts
-def test_jblock_sharding_and_gather_reproduce_single_process(oracle, nj):
+@pytest.mark.parametrize("world,nj", [(2, 40), (2, 41), (4, 9), (8, 37)])  # divisible, ragged, and ranks with few rows
+def test_jblock_sharding_and_gather_reproduce_single_process(oracle, world, nj):
     import torch.multiprocessing as mp
-    ni, world = 32, 2
+    ni = 32
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + nj
+    port = 29500 + (os.getpid() % 2000) + nj + 100 * world
     procs = [ctx.Process(target=_worker, args=(r, world, port, ni, nj, q)) for r in range(world)]
     for p in procs:
         p.start()
