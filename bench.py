@@ -52,6 +52,25 @@ def shard_rows(nj, world, rank):
     return j0, max(min(per, nj - j0), 0), per
 
 
+def shard_rows_root_heavy(nj, world, rank, rows_peer):
+    """j-blocks for the gathered run: ranks 1..N-1 own `rows_peer` rows each (behind rank 0's block), rank 0 owns the rest.
+    Rank 0 is the destination of the gather: its own rows never cross a link, so it takes MORE rows than its peers until its
+    compute time equals the time its peers need to compute AND ship theirs (balanced_peer_rows)."""
+    rows_peer = max(1, min(int(rows_peer), nj // world if nj >= world else 1))
+    nj0 = nj - (world - 1) * rows_peer
+    if rank == 0:
+        return 0, nj0, rows_peer
+    return nj0 + (rank - 1) * rows_peer, rows_peer, rows_peer
+
+
+def balanced_peer_rows(nj, world, t_cell, bytes_per_cell_on_link, link_bytes_per_s):
+    """Rows per peer that equalise rank 0's compute, t_cell (1 - (N-1) f), with a peer's compute-and-ship time
+    f max(t_cell, bytes/link_rate): f = t_cell / (P + (N-1) t_cell).  Fast links (P = t_cell) give the equal split 1/N."""
+    p = max(t_cell, bytes_per_cell_on_link / max(link_bytes_per_s, 1.0))
+    f = t_cell / (p + (world - 1) * t_cell)
+    return max(1, min(int(round(f * nj)), max(nj // world, 1)))
+
+
 def cpu_baseline(algo, skin, niter, zt, zu):
     """Reference Fortran (oracle/_ref, unmodified AeroBulk compiled with amdflang) timed on the host cores on a bounded
     sample of the same synthetic workload: first on ONE core (the reference is single-threaded), then on all cores at
@@ -101,6 +120,10 @@ def main():
                                                         "fields are bit-identical (outside the timed region)")
     ap.add_argument("--gather-ts", action="store_true", help="N>1: also gather the skin temperature T_s (the north_star gather is "
                                                            "the output tau / Q_L / Q_H / E arrays: 5 fields; T_s stays on its GPU)")
+    ap.add_argument("--peer-rows", type=int, default=0,
+                    help="N>1 with the gather: rows owned by each of the ranks 1..N-1 (rank 0, the gather's destination, owns the "
+                         "rest).  0 = measured: link rate and kernel rate are timed during set-up and the split balances rank 0's "
+                         "compute against its peers' compute + transfer; -1 = equal split")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row sub-blocks per rank (gather of one overlaps compute of the next)")
     a = ap.parse_args()
 
@@ -129,26 +152,81 @@ def main():
     ni, nj = (int(x) for x in a.grid.lower().split("x"))
     skin = (not a.no_skin) and a.algo in ("coare3p0", "coare3p6", "ecmwf")
     zt, zu = 2.0, 10.0
-    j0, njl, per = shard_rows(nj, world, rank)
     esz = 8 if a.precision == "f64" else 4
     tdt = torch.float64 if a.precision == "f64" else torch.float32
-    n_local = ni * njl
-
-    # Each rank's j-block is cut into `chunks` row sub-blocks so that the RCCL gather of sub-block c overlaps the
-    # kernel of sub-block c+1 (N == 1: one chunk, no communication).
-    chunks = 1 if world == 1 else max(1, min(a.chunks, per))
-    cr = -(-per // chunks)                       # rows per chunk (padded, identical on every rank)
-    n_cpad = ni * cr
     nout = 6 if skin else 5
     names = ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")[:nout]
     ngat = nout if a.gather_ts else 5            # fields that travel to rank 0
+    gathered = world > 1 and not a.no_gather
+
+    # ---- sharding.  Without a gather: equal j-blocks.  With it: rank 0 (the destination) owns more rows than its peers
+    # (shard_rows_root_heavy); how many is measured here unless --peer-rows says otherwise.
+    tune = None
+    if gathered:
+        rows_peer = a.peer_rows if a.peer_rows > 0 else -(-nj // world)
+        if a.peer_rows == 0:
+            # (1) what one link delivers when all peers send at once: a few gathers of 32 MB per rank
+            nb = 4 * 1024 * 1024
+            tb = torch.zeros(nb, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            tl = [torch.empty_like(tb) for _ in range(world)] if rank == 0 else None
+            for _ in range(2):
+                dist.gather(tb, tl, dst=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dist.gather(tb, tl, dst=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_gather = (time.perf_counter() - t0) / 5
+            del tb, tl
+            decision = torch.zeros(1, dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
+            if rank == 0:
+                try:
+                    # (2) what one GPU computes: the same kernel on ~1 M cells of the same fields
+                    rs = max(1, min(nj, (1 << 20) // ni))
+                    fs = ab.synth_fields_device(ni, nj, 0, rs, precision=a.precision, device=dev, with_rad=True)
+                    with ab.Session(a.algo, ni, rs, 1, skin, precision=a.precision, device=dev_index) as ss:
+                        ss.set_humidity("sh")
+                        best = 1e9
+                        for it in range(40):
+                            ss.compute(1, zt, zu, *[fs[k] for k in IN6], Niter=a.niter, rad_sw=fs["rad_sw"] if skin else None,
+                                       rad_lw=fs["rad_lw"] if skin else None, want_T_s=skin, check=False)
+                            if it >= 30:
+                                best = min(best, ss.last_kernel_ms())
+                    t_cell = best * 1e-3 / (ni * rs)
+                    link = nb * 8 / t_gather
+                    rows_peer = balanced_peer_rows(nj, world, t_cell, ngat * esz, link)
+                    tune = {"link_GBps": round(link / 1e9, 1), "kernel_Mcell_per_s": round(1e-6 / t_cell, 1)}
+                except Exception as e:      # never lose the run to the tuning: equal split
+                    tune = {"failed": str(e)}
+                decision[0] = rows_peer
+            dist.broadcast(decision, src=0)
+            rows_peer = int(decision.item())
+        j0, njl, per = shard_rows_root_heavy(nj, world, rank, rows_peer)
+        rows_peer = per
+    else:
+        j0, njl, per = shard_rows(nj, world, rank)
+        rows_peer = per
+    n_local = ni * njl
+
+    # Each rank's j-block is cut into `chunks` row sub-blocks so that the RCCL gather of sub-block c overlaps the
+    # kernel of sub-block c+1 (N == 1: one chunk, no communication).  Peers' chunks are padded to one common size (the
+    # gather needs equal payloads); rank 0's own, larger block is cut into as many chunks of its own size.
+    chunks = 1 if world == 1 else max(1, min(a.chunks, rows_peer))
+    cr_peer = -(-rows_peer // chunks)            # rows per peer chunk (padded, identical on every peer)
+    cr = -(-max(njl, 1) // chunks)               # rows per chunk of THIS rank
+    n_cpad = ni * cr
+    n_gpad = ni * cr_peer                        # cells per gathered chunk
 
     # synthetic inputs generated straight into HBM; outputs packed [chunk, field, cell] for ONE gather per chunk
     f = ab.synth_fields_device(ni, nj, j0, max(njl, 1), precision=a.precision, device=dev, with_rad=True)
     outbuf = torch.zeros((chunks, nout, n_cpad), dtype=tdt, device=dev)
     gather_lists = None
-    if world > 1 and rank == 0 and not a.no_gather:
-        gather_lists = [[torch.empty((ngat, n_cpad), dtype=tdt, device=dev) for _ in range(world)] for _ in range(chunks)]
+    send0 = None
+    if gathered and rank == 0:     # rank 0's rows stay where they are; it joins the collective with an empty payload
+        gather_lists = [[torch.empty((ngat, n_gpad), dtype=tdt, device=dev) for _ in range(world)] for _ in range(chunks)]
+        send0 = torch.zeros((ngat, n_gpad), dtype=tdt, device=dev)
 
     work = []  # (session, inputs, rad, out) per non-empty chunk
     for c in range(chunks):
@@ -172,11 +250,12 @@ def main():
             if w is not None:
                 sess, ins, rad, out = w
                 sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
-            if world > 1 and not a.no_gather:
+            if gathered:
+                payload = send0 if rank == 0 else outbuf[c, :ngat]
                 if a.backend == "nccl":
-                    pending.append(dist.gather(outbuf[c, :ngat], gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
+                    pending.append(dist.gather(payload, gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
                 else:  # test-only path: gloo gathers host tensors
-                    host = outbuf[c, :ngat].cpu()
+                    host = payload.cpu()
                     gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                     dist.gather(host, gl, dst=0)
                     if rank == 0:
@@ -192,13 +271,18 @@ def main():
             torch.cuda.synchronize()
 
     def assemble():
-        """rank 0: global fields [nout, ni*nj] from the gathered chunk buffers (rank-major j-blocks, chunk-major inside)."""
+        """rank 0: global fields [ngat, ni*nj]: its own block (never gathered) + the peers' gathered chunk buffers."""
         glob = torch.empty((ngat, ni * nj), dtype=tdt, device=dev)
-        for r in range(world):
-            rj0, rnjl, _ = shard_rows(nj, world, r)
+        for c in range(chunks):                                   # own rows
+            r0 = min(c * cr, njl)
+            rows = max(min(cr, njl - r0), 0)
+            if rows:
+                glob[:, r0 * ni:(r0 + rows) * ni] = outbuf[c, :ngat, :rows * ni]
+        for r in range(1, world):
+            rj0, rnjl, _ = shard_rows_root_heavy(nj, world, r, rows_peer)
             for c in range(chunks):
-                r0 = min(c * cr, rnjl)
-                rows = max(min(cr, rnjl - r0), 0)
+                r0 = min(c * cr_peer, rnjl)
+                rows = max(min(cr_peer, rnjl - r0), 0)
                 if rows:
                     glob[:, (rj0 + r0) * ni:(rj0 + r0 + rows) * ni] = gather_lists[c][r][:, :rows * ni]
         return glob
@@ -239,7 +323,7 @@ def main():
     k_ms = sum(kdur) / max(len(kdur), 1)
 
     verify_msg = None
-    if a.verify and world > 1 and not a.no_gather and rank == 0:
+    if a.verify and gathered and rank == 0:
         glob = assemble()
         ff = ab.synth_fields_device(ni, nj, precision=a.precision, device=dev, with_rad=True)
         with ab.Session(a.algo, ni, nj, 1, skin, precision=a.precision, device=dev_index) as s1:
@@ -267,8 +351,11 @@ def main():
             "config": {"workload": f"{a.algo}{' + cool-skin/warm-layer' if skin else ''}, {ni}x{nj} grid, nb_iter={a.niter}, "
                                    f"zt=2 zu=10, one time record (jt=1=Nt), inputs/outputs resident in HBM",
                        "grid": [ni, nj], "algo": a.algo, "skin": skin, "nb_iter": a.niter,
-                       "sharding": f"j-block x{world}" + ("" if world == 1 or a.no_gather else
-                                                            f" + RCCL gather of {', '.join(names[:ngat])} to rank 0, {chunks} overlapped row chunks per rank")},
+                       "sharding": f"j-block x{world}" + ("" if not gathered else
+                                                            f": rank 0 owns {nj - (world - 1) * rows_peer} rows, ranks 1..{world - 1} {rows_peer} rows each "
+                                                            f"(rank 0 is the gather's destination; its compute is balanced against the peers' compute + transfer)"
+                                                            f" + RCCL gather of {', '.join(names[:ngat])} to rank 0, {chunks} overlapped row chunks per rank"),
+                       **({"sharding_tuning": tune} if tune else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None,

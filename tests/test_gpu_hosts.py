@@ -144,23 +144,27 @@ def test_init_checks_on_gpu_match_reference_conditions(oracle):
         assert s.init(*base, rad_sw=lw, rad_lw=lw)["n_masked"] == 4
 
 
-def test_bench_sharded_path_two_ranks_one_gpu():
-    """bench.py's N>1 path (j-block sharding, row chunks, packed gather, reassembly) run as 2 ranks that share the one
-    visible GPU, with the gloo backend standing in for RCCL (RCCL refuses two ranks per device).  --verify makes rank 0
-    recompute the whole grid alone and demand bit-identical gathered fields."""
+@pytest.mark.parametrize("world,extra", [(2, []), (2, ["--peer-rows", "-1"]), (3, ["--peer-rows", "40", "--gather-ts"]), (4, [])])
+def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
+    """bench.py's N>1 path (root-heavy j-block sharding measured or given, row chunks, packed gather, reassembly) run as
+    several ranks that share the one visible GPU, with the gloo backend standing in for RCCL (RCCL refuses two ranks per
+    device).  --verify makes rank 0 recompute the whole grid alone and demand bit-identical gathered fields."""
     import sys
     import torch
     if torch.cuda.device_count() < 1:
         pytest.skip("no GPU")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--grid", "720x333", "--backend", "gloo", "--verify", "--chunks", "3", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29533 + world + len(extra)), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
+           "--warmup", "1", "--grid", "720x333", "--backend", "gloo", "--verify", "--chunks", "3", "--no-cpu-baseline", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["verify"].startswith("gathered == single-GPU")
+    assert res["n_gpus"] == world and res["verify"].startswith("gathered == single-GPU")
     assert res["scaling"] == "strong" and res["value"] > 0
+    assert "rank 0 owns" in res["config"]["sharding"]
+    if not extra:
+        assert "link_GBps" in res["config"]["sharding_tuning"], res["config"]
 
 
 def test_sharded_init_statistics_match_global_init(oracle):

@@ -77,3 +77,24 @@ def test_shard_rows_partition():
                 if njl:
                     assert j0 == pos
                 pos += njl
+
+
+def test_root_heavy_sharding_and_balance_formula():
+    """bench.py's gathered run: rank 0 (destination of the gather) owns more rows; the split equalises its compute with the peers'
+    compute + transfer and falls back to the equal split when links are fast."""
+    from bench import balanced_peer_rows, shard_rows_root_heavy
+    for nj, world in ((3600, 8), (3600, 2), (37, 8), (41, 2), (8, 8)):
+        for rp in (1, max(nj // world, 1), 10 ** 6):
+            rows = [shard_rows_root_heavy(nj, world, r, rp) for r in range(world)]
+            assert sum(r[1] for r in rows) == nj and rows[0][0] == 0
+            pos = 0
+            for j0, njl, per in rows:
+                assert j0 == pos and njl >= 1
+                pos += njl
+            assert all(r[1] == rows[1][1] for r in rows[1:]) and rows[0][1] >= rows[1][1]
+    t_cell = 3.5e-3 / 15.552e6
+    assert balanced_peer_rows(3600, 8, t_cell, 40, 1e18) == 450                 # infinitely fast links: equal split
+    slow = balanced_peer_rows(3600, 8, t_cell, 40, 60e9)
+    assert 300 < slow < 450
+    nj0 = 3600 - 7 * slow                                                          # both sides take about the same time
+    assert abs(nj0 * t_cell - slow * 40 / 60e9) / (nj0 * t_cell) < 0.02
