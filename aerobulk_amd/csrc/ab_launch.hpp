@@ -5,7 +5,10 @@
 
 namespace ab {
 
-constexpr int kBlock = 256;  // 4 waves of 64 lanes, one per SIMD
+#ifndef AB_BLOCK
+#define AB_BLOCK 256
+#endif
+constexpr int kBlock = AB_BLOCK;  // 256: 4 waves of 64 lanes, one per SIMD
 
 template <class R> static Heights<R> make_heights(double zt, double zu)
 {

@@ -16,7 +16,7 @@ constexpr int kBuckets = 16;     // 4 stability bins x 4 warm-layer bins
 template <class R, int ALGO, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // flux: sst theta q_zt u v slp [qsw rlw] ; turb: 8 / 6 too
     // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) + bucket (1 B) per cell
-    static constexpr int kWaves = AB_WAVES_PER_EU;
+    static constexpr int kWaves = AB_WAVES_PER_EU * 256 / kBlock;      // resident blocks per CU
     static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
@@ -143,7 +143,7 @@ static inline long resident_block_slots()
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        slots = (long)cus * AB_WAVES_PER_EU;
+        slots = (long)cus * (AB_WAVES_PER_EU * 256 / kBlock);
     }
     return slots;
 }
