@@ -59,6 +59,8 @@ SYMBOLS = {
                 + [C.POINTER(Diag), C.c_long, C.c_long]),
     "ab_turb_neutral_10m": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, vp]),
     "ab_turb_ice": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(IceFields), C.c_long, C.c_int, C.c_int, vp]),
+    "ab_turb_ice_easy": (C.c_int, [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(IceFields), C.c_long,
+                                   C.c_int, C.c_int, vp]),
     "ab_ice_algo_from_string": (C.c_int, [C.c_char_p]),
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),
     "ab_session_check": (C.c_int, [vp]),

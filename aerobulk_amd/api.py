@@ -326,13 +326,13 @@ def synth_fields_device(Ni, Nj, j0=0, nj_local=None, precision="f64", device="cu
     return f
 
 
-ICE_ALGOS = {"nemo": 1, "an05": 2, "lu12": 3, "lg15": 4}
+ICE_ALGOS = {"nemo": 1, "an05": 2, "lu12": 3, "lg15": 4, "easy": 5}
 ICE_OUT = ("Cd", "Ch", "Ce", "t_zu", "q_zu", "Ub", "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10")
 
 
-def turb_ice(calgo, zt, zu, Ts_i, theta_zt, qs_i, q_zt, U_zu, frice=None, nb_iter=5, optional=ICE_OUT[6:], precision="f64"):
-    """TURB_ICE_NEMO / AN05 / LU12 / LG15 (src/ice/mod_blk_ice_*.f90) on flat arrays: numpy (host) or torch (device).
-    Returns the dict of the six mandatory outputs plus the requested OPTIONAL ones."""
+def turb_ice(calgo, zt, zu, Ts_i, theta_zt, qs_i, q_zt, U_zu, frice=None, nb_iter=5, optional=ICE_OUT[6:], precision="f64", cxn=None):
+    """TURB_ICE_NEMO / AN05 / LU12 / LG15 / EASY (src/ice/mod_blk_ice_*.f90) on flat arrays: numpy (host) or torch (device).
+    Returns the dict of the six mandatory outputs plus the requested OPTIONAL ones.  `cxn` = (CdN, ChN, CeN) for "easy"."""
     lib = _lib.load()
     if calgo not in ICE_ALGOS:
         raise AerobulkError(3, f"sea-ice algorithm {calgo} is unknown")
@@ -355,8 +355,14 @@ def turb_ice(calgo, zt, zu, Ts_i, theta_zt, qs_i, q_zt, U_zu, frice=None, nb_ite
         stream = 0
     for k, a in out.items():
         setattr(f, k, _ptr(a, dtype, n)[0])
-    rc = lib.ab_turb_ice(ICE_ALGOS[calgo], float(zt), float(zu), int(nb_iter), C.byref(f), n, AB_F64 if precision == "f64" else AB_F32,
-                         AB_MEM_DEVICE if dev else AB_MEM_HOST, C.c_void_p(stream or 0))
+    if calgo == "easy":
+        if cxn is None:
+            raise AerobulkError(10, "TURB_ICE_EASY needs cxn = (CdN, ChN, CeN)")
+        rc = lib.ab_turb_ice_easy(float(zt), float(zu), int(nb_iter), float(cxn[0]), float(cxn[1]), float(cxn[2]), C.byref(f), n,
+                                  AB_F64 if precision == "f64" else AB_F32, AB_MEM_DEVICE if dev else AB_MEM_HOST, C.c_void_p(stream or 0))
+    else:
+        rc = lib.ab_turb_ice(ICE_ALGOS[calgo], float(zt), float(zu), int(nb_iter), C.byref(f), n, AB_F64 if precision == "f64" else AB_F32,
+                             AB_MEM_DEVICE if dev else AB_MEM_HOST, C.c_void_p(stream or 0))
     if rc:
         _raise(rc)
     if dev:

@@ -17,6 +17,7 @@ template <class R> struct IceArgs {
     long n;
     Heights<R> h;
     int nb_iter, regroup, rounds;
+    R cxn[3];   // TURB_ICE_EASY: prescribed CdN, ChN, CeN
 };
 
 template <class R, int ALGO>
@@ -29,12 +30,14 @@ __device__ __forceinline__ void ice_cell(const IceArgs<R> &a, const IceIn<R> &in
     } else if (ALGO == 3) {   // skin drag of z0 = 0.69 mm + form drag (mod_blk_ice_lu12.f90:156-160)
         const R zi = Mth<R>::rcp(a.h.log_zu - R(-7.278818960372969));
         turb_ice_const<R>(a.h, in, K<R>::vkarmn2 * zi * zi + cdn10_f_lu13<R>(in.frice), o);
-    } else {
+    } else if (ALGO == 4) {
         turb_ice_lg15<R>(a.h, in, a.frice[a.n - 1], a.nb_iter, o);   // wave-uniform load of the last cell's concentration
+    } else {
+        turb_ice_easy<R>(a.h, in, a.cxn[0], a.cxn[1], a.cxn[2], a.nb_iter, o);
     }
 }
 
-// NEMO / LU12 (no iteration, HBM-bound): one lane per cell.  AN05 / LG15 (nb_iter iterations with stable / unstable branches):
+// NEMO / LU12 (no iteration, HBM-bound): one lane per cell.  AN05 / LG15 / EASY (nb_iter iterations with stable / unstable branches):
 // the LDS-staged, regrouped tiles of flux_kernel (ab_tile.hpp); the bucket is the sign of the air-ice virtual temperature
 // difference in four bins.
 template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) ice_kernel(const IceArgs<R> a)
@@ -127,6 +130,7 @@ template <class R, int ALGO> static hipError_t launch_t(const IceCall &c, hipStr
     a.n = c.n;
     a.h = make_heights<R>(c.zt, c.zu);
     a.nb_iter = c.nb_iter;
+    for (int i = 0; i < 3; ++i) a.cxn[i] = (R)c.cxn[i];
     a.regroup = 1;
     a.rounds = tile_rounds(c.n, Tile<R, ALGO, false>::kRounds);
     const long tile = (ALGO == 1 || ALGO == 3) ? kBlock : (long)a.rounds * kBlock;
@@ -143,6 +147,7 @@ template <class R> static hipError_t launch_r(const IceCall &c, hipStream_t s)
     case 2: return launch_t<R, 2>(c, s);
     case 3: return launch_t<R, 3>(c, s);
     case 4: return launch_t<R, 4>(c, s);
+    case 5: return launch_t<R, 5>(c, s);
     default: return hipErrorInvalidValue;
     }
 }

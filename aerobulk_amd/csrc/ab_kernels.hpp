@@ -58,6 +58,7 @@ struct IceCall {
     double zt, zu;
     int algo;        // enum ab_ice_algo
     int f32, nb_iter;
+    double cxn[3];   // TURB_ICE_EASY: prescribed CdN, ChN, CeN
 };
 hipError_t launch_turb_ice(const IceCall &c, hipStream_t stream);
 

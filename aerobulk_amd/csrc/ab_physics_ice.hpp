@@ -166,6 +166,52 @@ __device__ __forceinline__ void turb_ice_an05(const Heights<R> &h, const IceIn<R
     o.UN10 = u_star * K<R>::inv_vk * (h.log_10 - lz0);
 }
 
+// turb_ice_easy mod_blk_ice_easy.f90:44-209: stability correction (psi of Andreas 2005) of PRESCRIBED neutral coefficients
+template <class R>
+__device__ __forceinline__ void turb_ice_easy(const Heights<R> &h, const IceIn<R> &in, R CdN, R ChN, R CeN, int nb_iter, IceOut<R> &o)
+{
+    using M = Mth<R>;
+    const R zsqrtCDN = M::sqrt(CdN), zi_sq = M::rcp(zsqrtCDN);
+    const R Ubzu = vmax(in.wnd, KIce<R>::wspd_thrshld);
+    R t_zu = vmax(in.theta_zt, R(100.)), q_zu = vmax(in.q_zt, R(0.1e-6));
+    R Cd_i = CdN, Ch_i = ChN, Ce_i = CeN;
+    R u_star = R(0.), t_star = R(0.), q_star = R(0.), psm = R(0.);
+#pragma unroll 1
+    for (int jit = 1; jit <= nb_iter; ++jit) {
+        const R dt_zu = t_zu - in.Ts_i, dq_zu = q_zu - in.qs_i;          // no floor here (:147-148)
+        const R sq = M::sqrt(Cd_i);
+        u_star = sq * Ubzu;
+        const R isq = M::rcp(vmax(sq, R(1.E-15)));
+        t_star = Ch_i * dt_zu * isq;
+        q_star = Ce_i * dq_zu * isq;
+        const R z1oL = one_on_l(t_zu, q_zu, u_star, t_star, q_star);
+        const R zeta_u = sclamp(h.zu * z1oL, R(50.));
+        R psh;
+        psi_ice<R>(zeta_u, &psm, &psh);
+        const R a = R(1.) + zsqrtCDN * K<R>::inv_vk * (h.log_zu10 - psm);
+        Cd_i = vmin(vmax(M::div(CdN, a * a), K<R>::Cx_min), R(1.9E-3));
+        const R b = (h.log_zu10 - psh) * K<R>::inv_vk * zi_sq;
+        const R c = M::sqrt(Cd_i) * zi_sq;
+        Ch_i = vmin(vmax(M::div(ChN * c, R(1.) + ChN * b), K<R>::Cx_min), R(1.9E-3));
+        Ce_i = vmin(vmax(M::div(CeN * c, R(1.) + CeN * b), K<R>::Cx_min), R(1.9E-3));
+        if (!h.zt_eq_zu) {
+            R psht;
+            psi_ice<R>(sclamp(h.zt * z1oL, R(50.)), nullptr, &psht);
+            const R d = psh - psht + h.log_ztu;
+            t_zu = in.theta_zt - t_star * K<R>::inv_vk * d;
+            q_zu = vmax(R(0.), in.q_zt - q_star * K<R>::inv_vk * d);
+        }
+    }
+    o.Cd = Cd_i; o.Ch = Ch_i; o.Ce = Ce_i; o.t_zu = t_zu; o.q_zu = q_zu; o.Ub = Ubzu;
+    o.CdN = CdN; o.ChN = ChN; o.CeN = CeN;
+    const R sq = M::sqrt(Cd_i);
+    const R lz0 = h.log_zu - (M::div(K<R>::vkarmn, sq) + psm);          // z0_from_Cd with psi, mod_phymbl.f90:1346
+    o.z0 = M::exp(lz0);
+    o.us = u_star;
+    o.L = M::rcp(one_on_l(t_zu, q_zu, u_star, t_star, q_star));
+    o.UN10 = sq * Ubzu * K<R>::inv_vk * (h.log_10 - lz0);               // UN10_from_CD :1545
+}
+
 // ---------------------------------------------------------------- Lupkes & Gryanik 2015
 // f_m_louis_sclr / f_h_louis_sclr mod_phymbl.f90:1419-1479 (rc_louis = 5: 3 c^2 = 75, a_m = 10, a_h = 15)
 template <class R> __device__ __forceinline__ R f_louis(R z_o_z0_p1, R pRib, R pCxn, R ra)

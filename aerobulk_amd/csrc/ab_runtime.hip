@@ -785,18 +785,37 @@ int ab_turb_neutral_10m(int algo, int nb_iter, const void *U_N10, void *CdN10, v
 // ---- sea ice: stateless; host callers are staged through a grow-only scratch
 int ab_ice_algo_from_string(const char *calgo)
 {
-    static const char *names[5] = {"", "nemo", "an05", "lu12", "lg15"};
+    static const char *names[6] = {"", "nemo", "an05", "lu12", "lg15", "easy"};
     if (!calgo) return 0;
-    for (int i = 1; i <= 4; ++i)
+    for (int i = 1; i <= 5; ++i)
         if (strcmp(calgo, names[i]) == 0) return i;
     return 0;
 }
 
+static int turb_ice_impl(int ice_algo, double zt, double zu, int nb_iter, const double cxn[3], const ab_ice_fields *f, long n,
+                         int precision, int mem, void *stream);
+
 int ab_turb_ice(int ice_algo, double zt, double zu, int nb_iter, const ab_ice_fields *f, long n, int precision, int mem,
                 void *stream)
 {
-    if (!f) return fail(AB_ERR_ARG, "ab_turb_ice: NULL fields");
     if (ice_algo < AB_ICE_NEMO || ice_algo > AB_ICE_LG15) return fail(AB_ERR_ALGO, "sea-ice algorithm id %d is unknown!!!", ice_algo);
+    const double none[3] = {0., 0., 0.};
+    return turb_ice_impl(ice_algo, zt, zu, nb_iter, none, f, n, precision, mem, stream);
+}
+
+int ab_turb_ice_easy(double zt, double zu, int nb_iter, double CdN, double ChN, double CeN, const ab_ice_fields *f, long n,
+                     int precision, int mem, void *stream)
+{
+    if (!(CdN > 0.) || !(ChN > 0.) || !(CeN > 0.)) return fail(AB_ERR_ARG, "TURB_ICE_EASY: neutral coefficients must be > 0");
+    if (nb_iter < 1) return fail(AB_ERR_ARG, "TURB_ICE_EASY: nb_iter < 1");
+    const double cxn[3] = {CdN, ChN, CeN};
+    return turb_ice_impl(AB_ICE_EASY, zt, zu, nb_iter, cxn, f, n, precision, mem, stream);
+}
+
+static int turb_ice_impl(int ice_algo, double zt, double zu, int nb_iter, const double cxn[3], const ab_ice_fields *f, long n,
+                         int precision, int mem, void *stream)
+{
+    if (!f) return fail(AB_ERR_ARG, "ab_turb_ice: NULL fields");
     if (n <= 0 || nb_iter < 0) return fail(AB_ERR_ARG, "ab_turb_ice: bad n / nb_iter");
     if (precision != AB_F64 && precision != AB_F32) return fail(AB_ERR_ARG, "bad precision %d", precision);
     if (!f->Ts_i || !f->theta_zt || !f->qs_i || !f->q_zt || !f->U_zu) return fail(AB_ERR_ARG, "ab_turb_ice: NULL input field");
@@ -813,6 +832,7 @@ int ab_turb_ice(int ice_algo, double zt, double zu, int nb_iter, const ab_ice_fi
     ab::IceCall c;
     memset(&c, 0, sizeof c);
     c.n = n; c.zt = zt; c.zu = zu; c.algo = ice_algo; c.f32 = precision == AB_F32; c.nb_iter = nb_iter;
+    for (int i = 0; i < 3; ++i) c.cxn[i] = cxn[i];
     if (mem == AB_MEM_DEVICE) {
         c.Ts_i = hin[0]; c.theta_zt = hin[1]; c.qs_i = hin[2]; c.q_zt = hin[3]; c.U_zu = hin[4]; c.frice = hin[5];
         for (int i = 0; i < 13; ++i) c.out[i] = hout[i];

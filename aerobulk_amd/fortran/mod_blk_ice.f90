@@ -14,7 +14,7 @@ MODULE mod_ab_ice
    USE mod_const, ONLY: wp, nb_iter
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: ab_ice_generic
+   PUBLIC :: ab_ice_generic, ab_ice_easy
 
    !! mirror of `ab_ice_fields` (include/aerobulk_amd.h)
    TYPE, BIND(C) :: ab_ice_fields
@@ -33,6 +33,15 @@ MODULE mod_ab_ice
          TYPE(C_PTR),     VALUE :: stream
          INTEGER(C_INT) :: istat
       END FUNCTION ab_turb_ice
+      FUNCTION ab_turb_ice_easy( zt, zu, niter, CdN, ChN, CeN, f, n, iprecision, mem, stream ) BIND(C, NAME='ab_turb_ice_easy') RESULT(istat)
+         IMPORT :: C_INT, C_LONG, C_DOUBLE, C_PTR, ab_ice_fields
+         INTEGER(C_INT),  VALUE :: niter, iprecision, mem
+         REAL(C_DOUBLE),  VALUE :: zt, zu, CdN, ChN, CeN
+         TYPE(ab_ice_fields), INTENT(in) :: f
+         INTEGER(C_LONG), VALUE :: n
+         TYPE(C_PTR),     VALUE :: stream
+         INTEGER(C_INT) :: istat
+      END FUNCTION ab_turb_ice_easy
       FUNCTION ab_last_error() BIND(C, NAME='ab_last_error') RESULT(cptr)
          IMPORT :: C_PTR
          TYPE(C_PTR) :: cptr
@@ -104,6 +113,34 @@ CONTAINS
          IF( istat /= 0 ) CALL stop_with_library_message()
       END SUBROUTINE ice_contig
    END SUBROUTINE ab_ice_generic
+
+   SUBROUTINE ab_ice_easy( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, CdN, ChN, CeN, Cd, Ch, Ce, t_zu, q_zu, Ub, xz0, xu_star, xL, xUN10 )
+      REAL(wp),                 INTENT(in)  :: zt, zu, CdN, ChN, CeN
+      REAL(wp), DIMENSION(:,:), INTENT(in)  :: Ts_i, t_zt, qs_i, q_zt, U_zu
+      REAL(wp), DIMENSION(:,:), INTENT(out) :: Cd, Ch, Ce, t_zu, q_zu, Ub
+      REAL(wp), DIMENSION(:,:), INTENT(out), OPTIONAL :: xz0, xu_star, xL, xUN10
+      CALL easy_contig( SIZE(Ts_i), Ts_i, t_zt, qs_i, q_zt, U_zu, Cd, Ch, Ce, t_zu, q_zu, Ub, xz0, xu_star, xL, xUN10 )
+   CONTAINS
+      SUBROUTINE easy_contig( n, a1, a2, a3, a4, a5, o1, o2, o3, o4, o5, o6, d4, d5, d6, d7 )
+         INTEGER, INTENT(in) :: n
+         REAL(wp), DIMENSION(n), INTENT(in),  TARGET :: a1, a2, a3, a4, a5
+         REAL(wp), DIMENSION(n), INTENT(out), TARGET :: o1, o2, o3, o4, o5, o6
+         REAL(wp), DIMENSION(n), INTENT(out), TARGET, OPTIONAL :: d4, d5, d6, d7
+         TYPE(ab_ice_fields) :: f
+         INTEGER(C_INT) :: istat
+         f%Ts_i = C_LOC(a1) ; f%theta_zt = C_LOC(a2) ; f%qs_i = C_LOC(a3) ; f%q_zt = C_LOC(a4) ; f%U_zu = C_LOC(a5)
+         f%Cd = C_LOC(o1) ; f%Ch = C_LOC(o2) ; f%Ce = C_LOC(o3) ; f%t_zu = C_LOC(o4) ; f%q_zu = C_LOC(o5) ; f%Ub = C_LOC(o6)
+         f%frice = C_NULL_PTR ; f%CdN = C_NULL_PTR ; f%ChN = C_NULL_PTR ; f%CeN = C_NULL_PTR
+         f%z0 = C_NULL_PTR ; f%u_star = C_NULL_PTR ; f%L = C_NULL_PTR ; f%UN10 = C_NULL_PTR
+         IF( PRESENT(d4) ) f%z0     = C_LOC(d4)
+         IF( PRESENT(d5) ) f%u_star = C_LOC(d5)
+         IF( PRESENT(d6) ) f%L      = C_LOC(d6)
+         IF( PRESENT(d7) ) f%UN10   = C_LOC(d7)
+         istat = ab_turb_ice_easy( REAL(zt,C_DOUBLE), REAL(zu,C_DOUBLE), INT(nb_iter,C_INT), REAL(CdN,C_DOUBLE), REAL(ChN,C_DOUBLE), &
+            &                      REAL(CeN,C_DOUBLE), f, INT(n,C_LONG), 0_C_INT, 0_C_INT, C_NULL_PTR )
+         IF( istat /= 0 ) CALL stop_with_library_message()
+      END SUBROUTINE easy_contig
+   END SUBROUTINE ab_ice_easy
 
 END MODULE mod_ab_ice
 
@@ -186,3 +223,25 @@ CONTAINS
          &                 CdN=CdN, ChN=ChN, CeN=CeN, xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10 )
    END SUBROUTINE TURB_ICE_LG15
 END MODULE mod_blk_ice_lg15
+
+
+MODULE mod_blk_ice_easy
+   USE mod_const, ONLY: wp
+   USE mod_ab_ice
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_ICE_EASY
+CONTAINS
+   SUBROUTINE TURB_ICE_EASY( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu,     &
+      &                      CdN, ChN, CeN,                            &
+      &                      Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu,   &
+      &                      xz0, xu_star, xL, xUN10 )
+      REAL(wp), INTENT(in )                 :: zt, zu
+      REAL(wp), INTENT(in ), DIMENSION(:,:) :: Ts_i, t_zt, qs_i, q_zt, U_zu
+      REAL(wp), INTENT(in )                 :: CdN, ChN, CeN
+      REAL(wp), INTENT(out), DIMENSION(:,:) :: Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu
+      REAL(wp), INTENT(out), OPTIONAL, DIMENSION(:,:) :: xz0, xu_star, xL, xUN10
+      CALL ab_ice_easy( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, CdN, ChN, CeN, Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu, &
+         &              xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10 )
+   END SUBROUTINE TURB_ICE_EASY
+END MODULE mod_blk_ice_easy

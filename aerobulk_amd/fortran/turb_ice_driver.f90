@@ -5,19 +5,20 @@
 ! uses the public interface of the modules, so the SAME file builds against aerobulk_amd/fortran/mod_blk_ice.f90
 ! (-> libaerobulk_amd.so -> HIP kernels) and against the unmodified reference (oracle/_ref/ref_ice_driver.x, golden data).
 !
-!   usage: turb_ice_driver.x <nemo|an05|lu12|lg15> <niter> <zt> <zu> <n> <in.bin> <out.bin>
-!   in.bin : 6 planes of n float64: Ts_i theta_zt qs_i q_zt U_zu frice
+!   usage: turb_ice_driver.x <nemo|easy|an05|lu12|lg15> <niter> <zt> <zu> <n> <in.bin> <out.bin>
+!   in.bin : 6 planes of n float64: Ts_i theta_zt qs_i q_zt U_zu frice, then CdN ChN CeN (3 float64, read by `easy`)
 !   out.bin: 13 planes: Cd Ch Ce t_zu q_zu Ub CdN ChN CeN z0 u_star L UN10
 PROGRAM turb_ice_driver
    USE mod_const, ONLY: wp, nb_iter
    USE mod_blk_ice_nemo
+   USE mod_blk_ice_easy
    USE mod_blk_ice_an05
    USE mod_blk_ice_lu12
    USE mod_blk_ice_lg15
    IMPLICIT NONE
    CHARACTER(len=512) :: carg, calgo, cfin, cfout
    INTEGER :: n
-   REAL(wp) :: zt, zu
+   REAL(wp) :: zt, zu, zcxn(3)
    REAL(wp), DIMENSION(:,:), ALLOCATABLE :: Ts, tht, qs, q_zt, W, fri
    REAL(wp), DIMENSION(:,:), ALLOCATABLE :: Cd, Ch, Ce, t_zu, q_zu, Ub, CdN, ChN, CeN, z0, us, xL, UN10
 
@@ -33,13 +34,17 @@ PROGRAM turb_ice_driver
    ALLOCATE( Cd(n,1), Ch(n,1), Ce(n,1), t_zu(n,1), q_zu(n,1), Ub(n,1) )
    ALLOCATE( CdN(n,1), ChN(n,1), CeN(n,1), z0(n,1), us(n,1), xL(n,1), UN10(n,1) )
    OPEN(11, FILE=TRIM(cfin), ACCESS='STREAM', FORM='UNFORMATTED', STATUS='OLD')
-   READ(11) Ts, tht, qs, q_zt, W, fri
+   READ(11) Ts, tht, qs, q_zt, W, fri, zcxn
    CLOSE(11)
 
    SELECT CASE( TRIM(calgo) )
    CASE('nemo')
       CALL TURB_ICE_NEMO( zt, zu, Ts, tht, qs, q_zt, W, Cd, Ch, Ce, t_zu, q_zu, Ub, &
          &                CdN=CdN, ChN=ChN, CeN=CeN, xz0=z0, xu_star=us, xL=xL, xUN10=UN10 )
+   CASE('easy')
+      CdN = zcxn(1) ; ChN = zcxn(2) ; CeN = zcxn(3)
+      CALL TURB_ICE_EASY( zt, zu, Ts, tht, qs, q_zt, W, zcxn(1), zcxn(2), zcxn(3), Cd, Ch, Ce, t_zu, q_zu, Ub, &
+         &                xz0=z0, xu_star=us, xL=xL, xUN10=UN10 )
    CASE('an05')
       CALL TURB_ICE_AN05( zt, zu, Ts, tht, qs, q_zt, W, Cd, Ch, Ce, t_zu, q_zu, Ub, &
          &                CdN=CdN, ChN=ChN, CeN=CeN, xz0=z0, xu_star=us, xL=xL, xUN10=UN10 )

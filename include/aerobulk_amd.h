@@ -197,7 +197,7 @@ int ab_turb_neutral_10m(int algo, int nb_iter, const void *U_N10, void *CdN10, v
  *   frice      : ice concentration, required by LU12 and LG15 (NULL otherwise).  NB LG15 reproduces the reference, whose
  *                CdN_f_LG15_light (mod_cdn_form_ice.f90:304) gives every cell the form drag of the LAST cell of the array
  *   Cd..Ub     : required outputs; CdN..UN10 optional (NULL = not wanted) */
-enum ab_ice_algo { AB_ICE_NEMO = 1, AB_ICE_AN05 = 2, AB_ICE_LU12 = 3, AB_ICE_LG15 = 4 };
+enum ab_ice_algo { AB_ICE_NEMO = 1, AB_ICE_AN05 = 2, AB_ICE_LU12 = 3, AB_ICE_LG15 = 4, AB_ICE_EASY = 5 };
 typedef struct ab_ice_fields {
     const void *Ts_i, *theta_zt, *qs_i, *q_zt, *U_zu, *frice;
     void *Cd, *Ch, *Ce, *t_zu, *q_zu, *Ub;
@@ -206,6 +206,10 @@ typedef struct ab_ice_fields {
 int ab_turb_ice(int ice_algo, double zt, double zu, int nb_iter, const ab_ice_fields *f, long n, int precision, int mem,
                 void *stream);
 int ab_ice_algo_from_string(const char *calgo);
+/* TURB_ICE_EASY( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, CdN, ChN, CeN, Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu, xz0, xu_star, xL, xUN10 )
+ * (mod_blk_ice_easy.f90:44-47): the neutral coefficients are prescribed SCALARS; f->CdN / ChN / CeN, if given, receive them back. */
+int ab_turb_ice_easy(double zt, double zu, int nb_iter, double CdN, double ChN, double CeN, const ab_ice_fields *f, long n,
+                     int precision, int mem, void *stream);
 
 /* Copy the persistent warm-layer state (planes dT_wl, Hz_wl, Qnt_ac, Tau_ac; ECMWF uses the
  * first two) to host doubles — diagnostics pdT_wl/pHz_wl of TURB_COARE3P6, mod_blk_coare3p6.f90:406-407. */

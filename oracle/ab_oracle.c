@@ -1258,6 +1258,53 @@ static void turb_ice_lg15(double zt, double zu, double Ts_i, double t_zt, double
     o->UN10 = sqrt(Cd_i) * Ubzu / vkarmn * log(10. / z0_from_cd(zu, zCdN_s + zCdN_f));
 }
 
+/* turb_ice_easy, mod_blk_ice_easy.f90:44-209: Andreas-2005-type stability correction of PRESCRIBED neutral coefficients */
+static void turb_ice_easy(double zt, double zu, double Ts_i, double t_zt, double qs_i, double q_zt, double U_zu, double CdN,
+                          double ChN, double CeN, int nb_iter, ice_out *o)
+{
+    int l_zt_equal_zu = (fabs(zu - zt) < 0.01);
+    double zsqrtCDN = sqrt(CdN), zlog1 = log(zt / zu), zlog2 = log(zu / 10.);
+    double Ubzu = dmax(U_zu, wspd_thrshld_ice);
+    double t_zu = dmax(t_zt, 100.), q_zu = dmax(q_zt, 0.1e-6);
+    double Cd_i = CdN, Ch_i = ChN, Ce_i = CeN;
+    double u_star = 0., t_star = 0., q_star = 0., zeta_u = 0.;
+    for (int jit = 1; jit <= nb_iter; ++jit) {
+        double dt_zu = t_zu - Ts_i, dq_zu = q_zu - qs_i;          /* no floor here (:147-148) */
+        double ztmp0 = sqrt(Cd_i);
+        u_star = ztmp0 * Ubzu;
+        ztmp0 = 1. / dmax(ztmp0, 1.E-15);
+        t_star = Ch_i * dt_zu * ztmp0;
+        q_star = Ce_i * dq_zu * ztmp0;
+        ztmp0 = abo_one_on_l(t_zu, q_zu, u_star, t_star, q_star);
+        ztmp0 = fsign(dmin(fabs(ztmp0), 200.), ztmp0);
+        zeta_u = zu * ztmp0;
+        zeta_u = fsign(dmin(fabs(zeta_u), 50.0), zeta_u);
+        double zeta_t = 0.;
+        if (!l_zt_equal_zu) {
+            zeta_t = zt * ztmp0;
+            zeta_t = fsign(dmin(fabs(zeta_t), 50.0), zeta_t);
+        }
+        ztmp0 = 1. + zsqrtCDN / vkarmn * (zlog2 - abo_psi_m_ice(zeta_u));
+        Cd_i = dmin(dmax(CdN / (ztmp0 * ztmp0), Cx_min), 1.9E-3);
+        ztmp0 = (zlog2 - abo_psi_h_ice(zeta_u)) / vkarmn / zsqrtCDN;
+        double ztmp1 = sqrt(Cd_i) / zsqrtCDN;
+        Ch_i = dmin(dmax(ChN * ztmp1 / (1. + ChN * ztmp0), Cx_min), 1.9E-3);
+        Ce_i = dmin(dmax(CeN * ztmp1 / (1. + CeN * ztmp0), Cx_min), 1.9E-3);
+        if (!l_zt_equal_zu) {
+            ztmp0 = abo_psi_h_ice(zeta_u) - abo_psi_h_ice(zeta_t) + zlog1;
+            t_zu = t_zt - t_star / vkarmn * ztmp0;
+            q_zu = dmax(0., q_zt - q_star / vkarmn * ztmp0);
+        }
+    }
+    o->Cd = Cd_i; o->Ch = Ch_i; o->Ce = Ce_i; o->t_zu = t_zu; o->q_zu = q_zu; o->Ub = Ubzu;
+    o->CdN = CdN; o->ChN = ChN; o->CeN = CeN;
+    double psm = abo_psi_m_ice(zeta_u);
+    o->z0 = z0_from_cd_psi(zu, Cd_i, psm);
+    o->us = u_star;
+    o->L = 1. / abo_one_on_l(t_zu, q_zu, u_star, t_star, q_star);
+    o->UN10 = un10_from_cd(zu, Ubzu, Cd_i, psm);
+}
+
 /* TURB_ICE_<algo> over n cells.  ice_algo: 1 nemo, 2 an05, 3 lu12, 4 lg15.  frice (ice concentration) is read by lu12
  * (per cell, mod_cdn_form_ice.f90:147-191 with rMu_0 = rNu_0 = 1, rBeta_0 = 1.4) and lg15 (last cell only, see above).
  * diag: 13 planes Cd Ch Ce t_zu q_zu Ub CdN ChN CeN z0 u_star L UN10. */
@@ -1332,6 +1379,19 @@ int abo_turb_neutral_10m(int algo, long n, int nb_iter, const double *U_N10, dou
         ChN10[k] = vkarmn2 / (ztmp0 * log(zu / z0t));
         CeN10[k] = vkarmn2 / (ztmp0 * log(zu / z0q));
         pz0[k] = z0;
+    }
+    return 0;
+}
+
+int abo_turb_ice_easy(long n, double zt, double zu, int nb_iter, const double *Ts_i, const double *t_zt, const double *qs_i,
+                      const double *q_zt, const double *U_zu, double CdN, double ChN, double CeN, double *diag)
+{
+    if (!diag || nb_iter < 1) return 2;
+    for (long k = 0; k < n; ++k) {
+        ice_out o;
+        turb_ice_easy(zt, zu, Ts_i[k], t_zt[k], qs_i[k], q_zt[k], U_zu[k], CdN, ChN, CeN, nb_iter, &o);
+        const double d[13] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ub, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10};
+        for (int s = 0; s < 13; ++s) diag[(long)s * n + k] = d[s];
     }
     return 0;
 }

@@ -72,6 +72,9 @@ int abo_turb(int algo, int kt, long n, double zt, double zu, int nb_iter, int us
  * diag: 13 planes of n doubles: Cd Ch Ce t_zu q_zu Ub CdN ChN CeN z0 u_star L UN10. */
 int abo_turb_ice(int ice_algo, long n, double zt, double zu, int nb_iter, const double *Ts_i, const double *t_zt,
                  const double *qs_i, const double *q_zt, const double *U_zu, const double *frice, double *diag);
+/* TURB_ICE_EASY (mod_blk_ice_easy.f90:44-47): the neutral coefficients CdN, ChN, CeN are prescribed scalars. */
+int abo_turb_ice_easy(long n, double zt, double zu, int nb_iter, const double *Ts_i, const double *t_zt, const double *qs_i,
+                      const double *q_zt, const double *U_zu, double CdN, double ChN, double CeN, double *diag);
 double abo_psi_m_ice(double zeta);
 double abo_psi_h_ice(double zeta);
 

@@ -65,6 +65,8 @@ def lib():
             C.c_int, _dp, _dp]
         L.abo_turb_ice.restype = C.c_int
         L.abo_turb_ice.argtypes = [C.c_int, C.c_long, C.c_double, C.c_double, C.c_int] + [_dp] * 7
+        L.abo_turb_ice_easy.restype = C.c_int
+        L.abo_turb_ice_easy.argtypes = [C.c_long, C.c_double, C.c_double, C.c_int] + [_dp] * 5 + [C.c_double] * 3 + [_dp]
         for name in ("abo_psi_m_ice", "abo_psi_h_ice"):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double]
@@ -318,7 +320,8 @@ def oracle_turb_series(algo, use_cs, use_wl, niter, zt, zu, lon, isec, recs):
 
 
 # ------------------------------------------------------------------ sea ice (src/ice/)
-ICE_ALGOS = {"nemo": 1, "an05": 2, "lu12": 3, "lg15": 4}
+ICE_ALGOS = {"nemo": 1, "an05": 2, "lu12": 3, "lg15": 4, "easy": 5}
+EASY_CXN = (1.5e-3, 1.3e-3, 1.4e-3)   # prescribed neutral coefficients of the golden TURB_ICE_EASY cases
 ICE_IN = ("Ts_i", "theta_zt", "qs_i", "q_zt", "U_zu", "frice")
 ICE_OUT = DIAG_NAMES[:13]
 REF_ICE_EXE = os.path.join(HERE, "_ref", "ref_ice_driver.x")
@@ -330,7 +333,7 @@ def run_ice_driver(exe, algo, niter, zt, zu, f, timeout=3600):
     n = f["Ts_i"].size
     with tempfile.TemporaryDirectory() as td:
         fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
-        np.concatenate([np.ascontiguousarray(f[k], dtype=np.float64) for k in ICE_IN]).tofile(fin)
+        np.concatenate([np.ascontiguousarray(f[k], dtype=np.float64) for k in ICE_IN] + [np.array(EASY_CXN)]).tofile(fin)
         pr = subprocess.run([exe, algo, str(int(niter)), repr(float(zt)), repr(float(zu)), str(n), fin, fout],
                             capture_output=True, text=True, timeout=timeout)
         if pr.returncode != 0 or not os.path.exists(fout) or os.path.getsize(fout) != 13 * n * 8:
@@ -342,7 +345,10 @@ def oracle_turb_ice(algo, niter, zt, zu, f):
     n = f["Ts_i"].size
     d = np.empty(13 * n)
     a = [np.ascontiguousarray(f[k], dtype=np.float64) for k in ICE_IN]
-    rc = lib().abo_turb_ice(ICE_ALGOS[algo], n, zt, zu, niter, *[_p(x) for x in a], _p(d))
+    if algo == "easy":
+        rc = lib().abo_turb_ice_easy(n, zt, zu, niter, *[_p(x) for x in a[:5]], *EASY_CXN, _p(d))
+    else:
+        rc = lib().abo_turb_ice(ICE_ALGOS[algo], n, zt, zu, niter, *[_p(x) for x in a], _p(d))
     if rc:
         raise RuntimeError(f"abo_turb_ice rc={rc}")
     return dict(zip(ICE_OUT, d.reshape(13, n)))

@@ -34,7 +34,7 @@ def make_inputs():
     return dict(Ts_i=Ts, theta_zt=tht, qs_i=qs, q_zt=q, U_zu=W, frice=fri)
 
 
-CASES = [("nemo", 5, 2.0, 10.0), ("an05", 5, 2.0, 10.0), ("an05", 8, 10.0, 10.0), ("an05", 4, 2.0, 12.5), ("lu12", 5, 2.0, 10.0),
+CASES = [("nemo", 5, 2.0, 10.0), ("easy", 5, 2.0, 10.0), ("easy", 8, 10.0, 10.0), ("an05", 5, 2.0, 10.0), ("an05", 8, 10.0, 10.0), ("an05", 4, 2.0, 12.5), ("lu12", 5, 2.0, 10.0),
          ("lg15", 5, 2.0, 10.0), ("lg15", 8, 10.0, 10.0), ("lg15", 3, 3.0, 15.0)]
 
 

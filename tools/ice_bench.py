@@ -19,12 +19,13 @@ def main():
     q = (0.5 + 0.6 * r(0.3247179572447460, 0.3)) * 3.8e-3 * torch.exp(0.09 * (tht - 273.15))
     W = 0.05 + 24. * r(0.8191725133961645, 0.4) ** 2
     fri = torch.clamp(-0.05 + 1.1 * r(0.4142135623730951, 0.5), 0., 1.)
-    for algo in ("nemo", "an05", "lu12", "lg15"):
+    for algo in ("nemo", "an05", "lu12", "lg15", "easy"):
         best = 1e9
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ab.turb_ice(algo, 2.0, 10.0, Ts, tht, qs, q, W, frice=fri if algo in ("lu12", "lg15") else None, optional=())
+            ab.turb_ice(algo, 2.0, 10.0, Ts, tht, qs, q, W, frice=fri if algo in ("lu12", "lg15") else None, optional=(),
+                        cxn=(1.5e-3, 1.3e-3, 1.4e-3) if algo == "easy" else None)
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
