@@ -36,7 +36,7 @@ class TurbFields(C.Structure):
 class IceFields(C.Structure):
     """ab_ice_fields: arguments of a TURB_ICE_* routine."""
     NAMES = ("Ts_i", "theta_zt", "qs_i", "q_zt", "U_zu", "frice", "Cd", "Ch", "Ce", "t_zu", "q_zu", "Ub",
-             "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10")
+             "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10", "CdN_frm")
     _fields_ = [(n, C.c_void_p) for n in NAMES]
 
 

@@ -328,12 +328,17 @@ def synth_fields_device(Ni, Nj, j0=0, nj_local=None, precision="f64", device="cu
 
 ICE_ALGOS = {"nemo": 1, "an05": 2, "lu12": 3, "lg15": 4, "easy": 5}
 ICE_OUT = ("Cd", "Ch", "Ce", "t_zu", "q_zu", "Ub", "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10")
+ICE_OUT_LG15 = ICE_OUT + ("CdN_frm",)      # TURB_ICE_LG15_IO's form-drag output (mod_blk_ice_lg15_io.f90:71)
 
 
 def turb_ice(calgo, zt, zu, Ts_i, theta_zt, qs_i, q_zt, U_zu, frice=None, nb_iter=5, optional=ICE_OUT[6:], precision="f64", cxn=None):
     """TURB_ICE_NEMO / AN05 / LU12 / LG15 / EASY (src/ice/mod_blk_ice_*.f90) on flat arrays: numpy (host) or torch (device).
-    Returns the dict of the six mandatory outputs plus the requested OPTIONAL ones.  `cxn` = (CdN, ChN, CeN) for "easy"."""
+    Returns the dict of the six mandatory outputs plus the requested OPTIONAL ones.  `cxn` = (CdN, ChN, CeN) for "easy";
+    "lg15_io" is TURB_ICE_LG15_IO over ice (mod_blk_ice_lg15_io.f90:69): LG15 plus the optional "CdN_frm"."""
     lib = _lib.load()
+    all_out = ICE_OUT
+    if calgo == "lg15_io":
+        calgo, all_out = "lg15", ICE_OUT_LG15
     if calgo not in ICE_ALGOS:
         raise AerobulkError(3, f"sea-ice algorithm {calgo} is unknown")
     dtype = np.float64 if precision == "f64" else np.float32
@@ -345,7 +350,7 @@ def turb_ice(calgo, zt, zu, Ts_i, theta_zt, qs_i, q_zt, U_zu, frice=None, nb_ite
         p, kp = _ptr(a, dtype, n)
         keep.append(kp)
         setattr(f, k, p)
-    names = ICE_OUT[:6] + tuple(k for k in ICE_OUT[6:] if k in optional)
+    names = ICE_OUT[:6] + tuple(k for k in all_out[6:] if k in optional)
     if dev:
         import torch
         out = {k: torch.empty(n, dtype=Ts_i.dtype, device=Ts_i.device) for k in names}

@@ -1,4 +1,4 @@
-// ab_ice_kernels.hip — the sea-ice bulk algorithms TURB_ICE_NEMO / AN05 / LU12 / LG15 as HIP kernels (gfx950).
+// ab_ice_kernels.hip — the sea-ice bulk algorithms TURB_ICE_NEMO / AN05 / LU12 / LG15 (= LG15_IO over ice) / EASY as HIP kernels (gfx950).
 //
 // ice_kernel<R,ALGO>: coalesced streaming of 5-6 input and 6-13 output fields, the nb_iter iteration in registers
 // (ab_physics_ice.hpp).  Algorithmic bytes per cell, fp64: 5 in + 6 out = 88 B (+ 8 B ice concentration for
@@ -13,7 +13,7 @@ namespace ab {
 
 template <class R> struct IceArgs {
     const R *Ts_i, *theta_zt, *qs_i, *q_zt, *U_zu, *frice;
-    R *out[13];
+    R *out[14];
     long n;
     Heights<R> h;
     int nb_iter, regroup, rounds;
@@ -108,6 +108,7 @@ template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, AB_WAVES_
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             if (a.out[6 + i]) a.out[6 + i][k] = d7[i];           // OPTIONAL outputs: straight to global memory
+        if (ALGO == 4 && a.out[13]) a.out[13][k] = o.CdN_frm;
         s_f[0][j] = o.Cd; s_f[1][j] = o.Ch; s_f[2][j] = o.Ce; s_f[3][j] = o.t_zu; s_f[4][j] = o.q_zu; s_f[5][j] = o.Ub;
     }
     __syncthreads();
@@ -126,7 +127,7 @@ template <class R, int ALGO> static hipError_t launch_t(const IceCall &c, hipStr
     IceArgs<R> a;
     a.Ts_i = (const R *)c.Ts_i; a.theta_zt = (const R *)c.theta_zt; a.qs_i = (const R *)c.qs_i;
     a.q_zt = (const R *)c.q_zt; a.U_zu = (const R *)c.U_zu; a.frice = (const R *)c.frice;
-    for (int i = 0; i < 13; ++i) a.out[i] = (R *)c.out[i];
+    for (int i = 0; i < 14; ++i) a.out[i] = (R *)c.out[i];
     a.n = c.n;
     a.h = make_heights<R>(c.zt, c.zu);
     a.nb_iter = c.nb_iter;

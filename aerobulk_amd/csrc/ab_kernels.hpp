@@ -53,7 +53,7 @@ hipError_t launch_neutral10(int algo, int nb_iter, const void *U_N10, void *CdN1
 // One call of a sea-ice TURB_ICE_<algo> routine (src/ice/mod_blk_ice_*.f90).
 struct IceCall {
     const void *Ts_i, *theta_zt, *qs_i, *q_zt, *U_zu, *frice;   // frice: lu12 (per cell), lg15 (its LAST element only)
-    void *out[13];                                              // Cd Ch Ce t_zu q_zu Ub (required) | CdN ChN CeN z0 u_star L UN10
+    void *out[14];                                              // Cd Ch Ce t_zu q_zu Ub (required) | CdN ChN CeN z0 u_star L UN10 | CdN_frm (LG15)
     long n;
     double zt, zu;
     int algo;        // enum ab_ice_algo

@@ -25,6 +25,7 @@ template <class R> struct IceIn {
 };
 template <class R> struct IceOut {
     R Cd, Ch, Ce, t_zu, q_zu, Ub, CdN, ChN, CeN, z0, us, L, UN10;
+    R CdN_frm;   // LG15 only: form-drag part of CdN (TURB_ICE_LG15_IO's optional output)
 };
 
 // first lines of every TURB_ICE_*: wind threshold, floors on t/q, non-zero air-ice differences (e.g. an05 :123-132)
@@ -263,7 +264,7 @@ __device__ __forceinline__ void turb_ice_lg15(const Heights<R> &h, const IceIn<R
         }
     }
     o.Cd = Cd_i; o.Ch = Ch_i; o.Ce = Ch_i; o.t_zu = t_zu; o.q_zu = q_zu; o.Ub = Ubzu;
-    o.CdN = zCdN; o.ChN = zChN_s + zChN_f; o.CeN = o.ChN;
+    o.CdN = zCdN; o.ChN = zChN_s + zChN_f; o.CeN = o.ChN; o.CdN_frm = zCdN_f;
     const R lz0 = h.log_zu - M::div(vk, M::sqrt(zCdN));
     o.z0 = M::exp(lz0);
     const R sq = M::sqrt(Cd_i);

@@ -828,31 +828,32 @@ static int turb_ice_impl(int ice_algo, double zt, double zu, int nb_iter, const 
     const size_t esz = precision == AB_F32 ? 4 : 8, bytes = esz * (size_t)n;
     const void *hin[6] = {f->Ts_i, f->theta_zt, f->qs_i, f->q_zt, f->U_zu,
                           (ice_algo == AB_ICE_LU12 || ice_algo == AB_ICE_LG15) ? f->frice : nullptr};
-    void *hout[13] = {f->Cd, f->Ch, f->Ce, f->t_zu, f->q_zu, f->Ub, f->CdN, f->ChN, f->CeN, f->z0, f->u_star, f->L, f->UN10};
+    if (f->CdN_frm && ice_algo != AB_ICE_LG15) return fail(AB_ERR_ARG, "ab_turb_ice: CdN_frm is an output of TURB_ICE_LG15(_IO) only");
+    void *hout[14] = {f->Cd, f->Ch, f->Ce, f->t_zu, f->q_zu, f->Ub, f->CdN, f->ChN, f->CeN, f->z0, f->u_star, f->L, f->UN10, f->CdN_frm};
     ab::IceCall c;
     memset(&c, 0, sizeof c);
     c.n = n; c.zt = zt; c.zu = zu; c.algo = ice_algo; c.f32 = precision == AB_F32; c.nb_iter = nb_iter;
     for (int i = 0; i < 3; ++i) c.cxn[i] = cxn[i];
     if (mem == AB_MEM_DEVICE) {
         c.Ts_i = hin[0]; c.theta_zt = hin[1]; c.qs_i = hin[2]; c.q_zt = hin[3]; c.U_zu = hin[4]; c.frice = hin[5];
-        for (int i = 0; i < 13; ++i) c.out[i] = hout[i];
+        for (int i = 0; i < 14; ++i) c.out[i] = hout[i];
         AB_HIP(ab::launch_turb_ice(c, (hipStream_t)stream));
         return AB_OK;
     }
-    static void *scratch = nullptr;        // 19 planes, grow-only, one host caller at a time (like the reference)
+    static void *scratch = nullptr;        // 20 planes, grow-only, one host caller at a time (like the reference)
     static size_t scratch_bytes = 0;
     static int scratch_dev = -1;
     int dev = 0;
     AB_HIP(hipGetDevice(&dev));
-    if (scratch_bytes < 19 * bytes || dev != scratch_dev) {
+    if (scratch_bytes < 20 * bytes || dev != scratch_dev) {
         if (scratch) {
             if (scratch_dev >= 0) (void)hipSetDevice(scratch_dev);
             (void)hipFree(scratch);
             (void)hipSetDevice(dev);
         }
         scratch = nullptr; scratch_bytes = 0;
-        AB_HIP(hipMalloc(&scratch, 19 * bytes));
-        scratch_bytes = 19 * bytes;
+        AB_HIP(hipMalloc(&scratch, 20 * bytes));
+        scratch_bytes = 20 * bytes;
         scratch_dev = dev;
     }
     char *base = (char *)scratch;
@@ -864,9 +865,9 @@ static int turb_ice_impl(int ice_algo, double zt, double zu, int nb_iter, const 
         din[i] = base + i * bytes;
     }
     c.Ts_i = din[0]; c.theta_zt = din[1]; c.qs_i = din[2]; c.q_zt = din[3]; c.U_zu = din[4]; c.frice = din[5];
-    for (int i = 0; i < 13; ++i) c.out[i] = hout[i] ? base + (6 + i) * bytes : nullptr;
+    for (int i = 0; i < 14; ++i) c.out[i] = hout[i] ? base + (6 + i) * bytes : nullptr;
     AB_HIP(ab::launch_turb_ice(c, nullptr));
-    for (int i = 0; i < 13; ++i)
+    for (int i = 0; i < 14; ++i)
         if (hout[i]) AB_HIP(hipMemcpyAsync(hout[i], c.out[i], bytes, hipMemcpyDeviceToHost, nullptr));
     AB_HIP(hipStreamSynchronize(nullptr));
     return AB_OK;

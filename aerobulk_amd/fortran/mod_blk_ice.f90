@@ -5,6 +5,8 @@
 !    mod_blk_ice_an05 : TURB_ICE_AN05   (src/ice/mod_blk_ice_an05.f90:41-43)
 !    mod_blk_ice_lu12 : TURB_ICE_LU12   (src/ice/mod_blk_ice_lu12.f90:69-71)
 !    mod_blk_ice_lg15 : TURB_ICE_LG15   (src/ice/mod_blk_ice_lg15.f90:68-70)
+!    mod_blk_ice_lg15_io : TURB_ICE_LG15_IO (src/ice/mod_blk_ice_lg15_io.f90:69-72), over-ice outputs + CdN_frm
+!    mod_blk_ice_easy : TURB_ICE_EASY   (src/ice/mod_blk_ice_easy.f90:44-47)
 ! Same module / routine / dummy-argument names, INTENTs and OPTIONALs; everything goes through ISO_C_BINDING to
 ! `ab_turb_ice` (include/aerobulk_amd.h), i.e. to ice_kernel (aerobulk_amd/csrc/ab_ice_kernels.hip).  `nb_iter` is read from
 ! mod_const like the reference does.  Compile after mod_aerobulk.f90 (mod_const), with -fdefault-real-8.
@@ -21,6 +23,7 @@ MODULE mod_ab_ice
       TYPE(C_PTR) :: Ts_i, theta_zt, qs_i, q_zt, U_zu, frice
       TYPE(C_PTR) :: Cd, Ch, Ce, t_zu, q_zu, Ub
       TYPE(C_PTR) :: CdN, ChN, CeN, z0, u_star, L, UN10
+      TYPE(C_PTR) :: CdN_frm
    END TYPE ab_ice_fields
 
    INTERFACE
@@ -76,28 +79,29 @@ CONTAINS
    END SUBROUTINE stop_with_library_message
 
    SUBROUTINE ab_ice_generic( ialgo, zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, Cd, Ch, Ce, t_zu, q_zu, Ub, &
-      &                       frice, CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      &                       frice, CdN, ChN, CeN, xz0, xu_star, xL, xUN10, CdN_frm )
       INTEGER,                  INTENT(in)  :: ialgo
       REAL(wp),                 INTENT(in)  :: zt, zu
       REAL(wp), DIMENSION(:,:), INTENT(in)  :: Ts_i, t_zt, qs_i, q_zt, U_zu
       REAL(wp), DIMENSION(:,:), INTENT(out) :: Cd, Ch, Ce, t_zu, q_zu, Ub
       REAL(wp), DIMENSION(:,:), INTENT(in),  OPTIONAL :: frice
-      REAL(wp), DIMENSION(:,:), INTENT(out), OPTIONAL :: CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      REAL(wp), DIMENSION(:,:), INTENT(out), OPTIONAL :: CdN, ChN, CeN, xz0, xu_star, xL, xUN10, CdN_frm
       !! explicit-shape dummies: the compiler hands over contiguous storage
       CALL ice_contig( SIZE(Ts_i), Ts_i, t_zt, qs_i, q_zt, U_zu, Cd, Ch, Ce, t_zu, q_zu, Ub, frice, &
-         &             CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+         &             CdN, ChN, CeN, xz0, xu_star, xL, xUN10, CdN_frm )
    CONTAINS
-      SUBROUTINE ice_contig( n, a1, a2, a3, a4, a5, o1, o2, o3, o4, o5, o6, r1, d1, d2, d3, d4, d5, d6, d7 )
+      SUBROUTINE ice_contig( n, a1, a2, a3, a4, a5, o1, o2, o3, o4, o5, o6, r1, d1, d2, d3, d4, d5, d6, d7, d8 )
          INTEGER, INTENT(in) :: n
          REAL(wp), DIMENSION(n), INTENT(in),  TARGET :: a1, a2, a3, a4, a5
          REAL(wp), DIMENSION(n), INTENT(out), TARGET :: o1, o2, o3, o4, o5, o6
          REAL(wp), DIMENSION(n), INTENT(in),  TARGET, OPTIONAL :: r1
-         REAL(wp), DIMENSION(n), INTENT(out), TARGET, OPTIONAL :: d1, d2, d3, d4, d5, d6, d7
+         REAL(wp), DIMENSION(n), INTENT(out), TARGET, OPTIONAL :: d1, d2, d3, d4, d5, d6, d7, d8
          TYPE(ab_ice_fields) :: f
          INTEGER(C_INT) :: istat
          f%Ts_i = C_LOC(a1) ; f%theta_zt = C_LOC(a2) ; f%qs_i = C_LOC(a3) ; f%q_zt = C_LOC(a4) ; f%U_zu = C_LOC(a5)
          f%Cd = C_LOC(o1) ; f%Ch = C_LOC(o2) ; f%Ce = C_LOC(o3) ; f%t_zu = C_LOC(o4) ; f%q_zu = C_LOC(o5) ; f%Ub = C_LOC(o6)
-         f%frice = C_NULL_PTR
+         f%frice = C_NULL_PTR ; f%CdN_frm = C_NULL_PTR
+         IF( PRESENT(d8) ) f%CdN_frm = C_LOC(d8)
          f%CdN = C_NULL_PTR ; f%ChN = C_NULL_PTR ; f%CeN = C_NULL_PTR ; f%z0 = C_NULL_PTR
          f%u_star = C_NULL_PTR ; f%L = C_NULL_PTR ; f%UN10 = C_NULL_PTR
          IF( PRESENT(r1) ) f%frice  = C_LOC(r1)
@@ -130,7 +134,7 @@ CONTAINS
          INTEGER(C_INT) :: istat
          f%Ts_i = C_LOC(a1) ; f%theta_zt = C_LOC(a2) ; f%qs_i = C_LOC(a3) ; f%q_zt = C_LOC(a4) ; f%U_zu = C_LOC(a5)
          f%Cd = C_LOC(o1) ; f%Ch = C_LOC(o2) ; f%Ce = C_LOC(o3) ; f%t_zu = C_LOC(o4) ; f%q_zu = C_LOC(o5) ; f%Ub = C_LOC(o6)
-         f%frice = C_NULL_PTR ; f%CdN = C_NULL_PTR ; f%ChN = C_NULL_PTR ; f%CeN = C_NULL_PTR
+         f%frice = C_NULL_PTR ; f%CdN = C_NULL_PTR ; f%ChN = C_NULL_PTR ; f%CeN = C_NULL_PTR ; f%CdN_frm = C_NULL_PTR
          f%z0 = C_NULL_PTR ; f%u_star = C_NULL_PTR ; f%L = C_NULL_PTR ; f%UN10 = C_NULL_PTR
          IF( PRESENT(d4) ) f%z0     = C_LOC(d4)
          IF( PRESENT(d5) ) f%u_star = C_LOC(d5)
@@ -245,3 +249,40 @@ CONTAINS
          &              xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10 )
    END SUBROUTINE TURB_ICE_EASY
 END MODULE mod_blk_ice_easy
+
+
+MODULE mod_blk_ice_lg15_io
+   !! TURB_ICE_LG15_IO (src/ice/mod_blk_ice_lg15_io.f90:69-404).  Over ice it is TURB_ICE_LG15 plus the form-drag output
+   !! CdN_frm.  Its over-water outputs (Cd_w, Ch_w, Ce_w, t_zu_w, q_zu_w from Ts_w, qs_w) read work arrays the reference never
+   !! assigns (zz0_s, zCdN_s, zChN_s (:,:,2): ALLOCATEd at :174-175, used at :292-293): there is no defined result to
+   !! reproduce, so asking for them stops with a message; the reference's own caller does not ask either
+   !! (src/ice/test_aerobulk_oce+ice.f90:345-347).
+   USE mod_const, ONLY: wp
+   USE mod_ab_ice
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: TURB_ICE_LG15_IO
+CONTAINS
+   SUBROUTINE TURB_ICE_LG15_IO( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, frice, &
+      &                         Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu,            &
+      &                         Ts_w, qs_w, CdN_frm, Cd_w, Ch_w, Ce_w, t_zu_w, q_zu_w,    &
+      &                         CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      REAL(wp), INTENT(in )                 :: zt, zu
+      REAL(wp), INTENT(in ), DIMENSION(:,:) :: Ts_i, t_zt, qs_i, q_zt, U_zu, frice
+      REAL(wp), INTENT(out), DIMENSION(:,:) :: Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu
+      REAL(wp), INTENT(in ), DIMENSION(:,:), OPTIONAL :: Ts_w, qs_w
+      REAL(wp), INTENT(out), DIMENSION(:,:), OPTIONAL :: CdN_frm, Cd_w, Ch_w, Ce_w, t_zu_w, q_zu_w
+      REAL(wp), INTENT(out), DIMENSION(:,:), OPTIONAL :: CdN, ChN, CeN, xz0, xu_star, xL, xUN10
+      IF( PRESENT(Cd_w) .AND. PRESENT(Ch_w) .AND. PRESENT(Ce_w) .AND. PRESENT(t_zu_w) .AND. PRESENT(q_zu_w) ) THEN
+         IF( .NOT.(PRESENT(Ts_w)) .OR. .NOT.(PRESENT(qs_w)) ) THEN
+            PRINT *, ' ERROR: turb_ice_lg15_io@mod_blk_ice_lg15_io => you must specify "Ts_w" and "qs_w" as input'
+            STOP
+         END IF
+         PRINT *, ' ERROR: turb_ice_lg15_io@mod_blk_ice_lg15_io => the over-water outputs (Cd_w, Ch_w, Ce_w, t_zu_w, q_zu_w)'
+         PRINT *, '        are computed by the reference from unassigned work arrays; they are not available here.'
+         STOP
+      END IF
+      CALL ab_ice_generic( 4, zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu, Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu, frice=frice, &
+         &                 CdN=CdN, ChN=ChN, CeN=CeN, xz0=xz0, xu_star=xu_star, xL=xL, xUN10=xUN10, CdN_frm=CdN_frm )
+   END SUBROUTINE TURB_ICE_LG15_IO
+END MODULE mod_blk_ice_lg15_io

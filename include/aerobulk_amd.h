@@ -202,6 +202,7 @@ typedef struct ab_ice_fields {
     const void *Ts_i, *theta_zt, *qs_i, *q_zt, *U_zu, *frice;
     void *Cd, *Ch, *Ce, *t_zu, *q_zu, *Ub;
     void *CdN, *ChN, *CeN, *z0, *u_star, *L, *UN10;
+    void *CdN_frm;   /* AB_ICE_LG15 only: form-drag part of CdN, the CdN_frm of TURB_ICE_LG15_IO (mod_blk_ice_lg15_io.f90:71,346) */
 } ab_ice_fields;
 int ab_turb_ice(int ice_algo, double zt, double zu, int nb_iter, const ab_ice_fields *f, long n, int precision, int mem,
                 void *stream);

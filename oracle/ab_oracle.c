@@ -1192,8 +1192,16 @@ static void turb_ice_an05(double zt, double zu, double Ts_i, double t_zt, double
     o->UN10 = u_star / vkarmn * log(10. / z0);
 }
 
-/* turb_ice_lg15, mod_blk_ice_lg15.f90:68-307.  frice_last: CdN_f_LG15_light (mod_cdn_form_ice.f90:272-307) assigns its WHOLE
- * result array inside its cell loop, so every cell ends up with the form drag of the LAST cell of the array. */
+/* CdN_f_LG15_light (mod_cdn_form_ice.f90:272-307) assigns its WHOLE result array inside its cell loop, so every cell ends
+ * up with the form drag of the LAST cell of the array: frice_last. */
+double abo_cdn_f_lg15_light(double zu, double frice_last)
+{
+    double ztmp = 1. / rz0_i_f_0;
+    double zrlog = log(10. * ztmp) / log(zu * ztmp);
+    return rce10_i_0 * zrlog * zrlog * frice_last * pow(1. - frice_last, rbeta_0_miz);
+}
+
+/* turb_ice_lg15, mod_blk_ice_lg15.f90:68-307 (= the over-ice part of turb_ice_lg15_io, mod_blk_ice_lg15_io.f90:69-404) */
 static void turb_ice_lg15(double zt, double zu, double Ts_i, double t_zt, double qs_i, double q_zt, double U_zu,
                           double frice_last, int nb_iter, ice_out *o)
 {
@@ -1206,13 +1214,8 @@ static void turb_ice_lg15(double zt, double zu, double Ts_i, double t_zt, double
     double zCdN_s = cd_from_z0(zu, zz0_s);
     double zChN_s = vkarmn2 / (log(zu / zz0_s) * log(zu / (ralpha_0 * zz0_s)));
     double zz0_f = rz0_i_f_0;
-    double zCdN_f, zChN_f;
-    {
-        double ztmp = 1. / zz0_f;
-        double zrlog = log(10. * ztmp) / log(zu * ztmp);
-        zCdN_f = rce10_i_0 * zrlog * zrlog * frice_last * pow(1. - frice_last, rbeta_0_miz);
-        zChN_f = zCdN_f / (1. + log(1. / ralpha_0) / vkarmn * sqrt(zCdN_f));
-    }
+    double zCdN_f = abo_cdn_f_lg15_light(zu, frice_last);
+    double zChN_f = zCdN_f / (1. + log(1. / ralpha_0) / vkarmn * sqrt(zCdN_f));
     double Cd_i = zCdN_s + zCdN_f;
     double Ch_i = zChN_s + zChN_f;
     double RiB = abo_ri_bulk(zt, Ts_i, t_zt, qs_i, q_zt, Ubzu);

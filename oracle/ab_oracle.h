@@ -73,6 +73,9 @@ int abo_turb(int algo, int kt, long n, double zt, double zu, int nb_iter, int us
 int abo_turb_ice(int ice_algo, long n, double zt, double zu, int nb_iter, const double *Ts_i, const double *t_zt,
                  const double *qs_i, const double *q_zt, const double *U_zu, const double *frice, double *diag);
 /* TURB_ICE_EASY (mod_blk_ice_easy.f90:44-47): the neutral coefficients CdN, ChN, CeN are prescribed scalars. */
+/* CdN_f_LG15_light (mod_cdn_form_ice.f90:272-307) for the concentration of the LAST cell: the value every cell receives
+ * (TURB_ICE_LG15 / TURB_ICE_LG15_IO; the optional CdN_frm output of the latter, mod_blk_ice_lg15_io.f90:346) */
+double abo_cdn_f_lg15_light(double zu, double frice_last);
 int abo_turb_ice_easy(long n, double zt, double zu, int nb_iter, const double *Ts_i, const double *t_zt, const double *qs_i,
                       const double *q_zt, const double *U_zu, double CdN, double ChN, double CeN, double *diag);
 double abo_psi_m_ice(double zeta);

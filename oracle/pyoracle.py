@@ -70,6 +70,8 @@ def lib():
         for name in ("abo_psi_m_ice", "abo_psi_h_ice"):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double]
+        L.abo_cdn_f_lg15_light.restype = C.c_double
+        L.abo_cdn_f_lg15_light.argtypes = [C.c_double, C.c_double]
         L.abo_turb_neutral_10m.restype = C.c_int
         L.abo_turb_neutral_10m.argtypes = [C.c_int, C.c_long, C.c_int] + [_dp] * 5
         L.abo_synth_fields.restype = None
@@ -336,9 +338,13 @@ def run_ice_driver(exe, algo, niter, zt, zu, f, timeout=3600):
         np.concatenate([np.ascontiguousarray(f[k], dtype=np.float64) for k in ICE_IN] + [np.array(EASY_CXN)]).tofile(fin)
         pr = subprocess.run([exe, algo, str(int(niter)), repr(float(zt)), repr(float(zu)), str(n), fin, fout],
                             capture_output=True, text=True, timeout=timeout)
-        if pr.returncode != 0 or not os.path.exists(fout) or os.path.getsize(fout) != 13 * n * 8:
+        if pr.returncode != 0 or not os.path.exists(fout) or os.path.getsize(fout) != 14 * n * 8:
             raise RuntimeError(f"{exe} failed (rc={pr.returncode}):\n" + pr.stdout[-2000:] + pr.stderr[-2000:])
-        return dict(zip(ICE_OUT, np.fromfile(fout, dtype=np.float64).reshape(13, n)))
+        d = np.fromfile(fout, dtype=np.float64).reshape(14, n)
+        o = dict(zip(ICE_OUT, d[:13]))
+        if algo == "lg15_io":
+            o["CdN_frm"] = d[13]
+        return o
 
 
 def oracle_turb_ice(algo, niter, zt, zu, f):
@@ -348,10 +354,13 @@ def oracle_turb_ice(algo, niter, zt, zu, f):
     if algo == "easy":
         rc = lib().abo_turb_ice_easy(n, zt, zu, niter, *[_p(x) for x in a[:5]], *EASY_CXN, _p(d))
     else:
-        rc = lib().abo_turb_ice(ICE_ALGOS[algo], n, zt, zu, niter, *[_p(x) for x in a], _p(d))
+        rc = lib().abo_turb_ice(ICE_ALGOS["lg15" if algo == "lg15_io" else algo], n, zt, zu, niter, *[_p(x) for x in a], _p(d))
     if rc:
         raise RuntimeError(f"abo_turb_ice rc={rc}")
-    return dict(zip(ICE_OUT, d.reshape(13, n)))
+    o = dict(zip(ICE_OUT, d.reshape(13, n)))
+    if algo == "lg15_io":   # TURB_ICE_LG15_IO over ice = TURB_ICE_LG15 + the form-drag output (same for every cell, see abo_cdn_f_lg15_light)
+        o["CdN_frm"] = np.full(n, lib().abo_cdn_f_lg15_light(zu, float(a[5][-1])))
+    return o
 
 
 # ------------------------------------------------------------------ TURB_NEUTRAL_10M

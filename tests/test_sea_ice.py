@@ -1,4 +1,4 @@
-"""Sea-ice bulk algorithms TURB_ICE_NEMO / EASY / AN05 / LU12 / LG15.
+"""Sea-ice bulk algorithms TURB_ICE_NEMO / EASY / AN05 / LU12 / LG15 / LG15_IO.
 
 Golden data: tests/golden/ice_*.npz from tools/gen_ice_golden.py: the UNMODIFIED reference's src/ice modules behind our own
 driver source aerobulk_amd/fortran/turb_ice_driver.f90; the same driver linked with the HIP engine must reproduce them."""
@@ -13,6 +13,10 @@ from conftest import GOLDEN, ROOT, assert_parity
 MAN = json.load(open(os.path.join(GOLDEN, "ice_manifest.json")))
 OUT = ("Cd", "Ch", "Ce", "t_zu", "q_zu", "Ubzu", "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10")
 FDRV = os.path.join(ROOT, "aerobulk_amd", "fortran", "turb_ice_driver.x")
+
+
+def _out(case):
+    return OUT + ("CdN_frm",) if case["algo"] == "lg15_io" else OUT
 
 
 def _load(case):
@@ -39,7 +43,7 @@ def _well_conditioned(ref, f):
 def test_oracle_ice_matches_reference(oracle, case):
     f, ref = _load(case)
     got = oracle.oracle_turb_ice(case["algo"], case["niter"], case["zt"], case["zu"], f)
-    for k in OUT:
+    for k in _out(case):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)      # the C restatement is bit-exact here
 
 
@@ -62,13 +66,13 @@ def test_hip_ice_matches_reference(case, device):
     else:
         a = f
     o = ab.turb_ice(case["algo"], case["zt"], case["zu"], a["Ts_i"], a["theta_zt"], a["qs_i"], a["q_zt"], a["U_zu"],
-                    frice=a["frice"] if case["algo"] in ("lu12", "lg15") else None, nb_iter=case["niter"],
-                    cxn=(1.5e-3, 1.3e-3, 1.4e-3) if case["algo"] == "easy" else None)
+                    frice=a["frice"] if case["algo"] in ("lu12", "lg15", "lg15_io") else None, nb_iter=case["niter"],
+                    optional=_out(case)[6:], cxn=(1.5e-3, 1.3e-3, 1.4e-3) if case["algo"] == "easy" else None)
     got = {("Ubzu" if k == "Ub" else k): (v.cpu().numpy() if device else v) for k, v in o.items()}
     ok = _well_conditioned(ref, f)
     g, r = _inv_l(got), _inv_l(ref)
-    assert_parity({k: v[ok] for k, v in g.items()}, {k: v[ok] for k, v in r.items()}, OUT, abs_frac=1e-11, label=case["name"])
-    assert_parity(g, r, OUT, tol=1e-7, abs_frac=1e-8, label=case["name"] + " (all cells)")
+    assert_parity({k: v[ok] for k, v in g.items()}, {k: v[ok] for k, v in r.items()}, _out(case), abs_frac=1e-11, label=case["name"])
+    assert_parity(g, r, _out(case), tol=1e-7, abs_frac=1e-8, label=case["name"] + " (all cells)")
 
 
 @pytest.mark.gpu
@@ -81,7 +85,7 @@ def test_hip_fortran_ice_driver_matches_reference(oracle, case):
     got = oracle.run_ice_driver(FDRV, case["algo"], case["niter"], case["zt"], case["zu"], f)
     ok = _well_conditioned(ref, f)
     g, r = _inv_l(got), _inv_l(ref)
-    assert_parity({k: v[ok] for k, v in g.items()}, {k: v[ok] for k, v in r.items()}, OUT, abs_frac=1e-11, label=case["name"] + " [fortran]")
+    assert_parity({k: v[ok] for k, v in g.items()}, {k: v[ok] for k, v in r.items()}, _out(case), abs_frac=1e-11, label=case["name"] + " [fortran]")
 
 
 @pytest.mark.gpu
@@ -104,6 +108,8 @@ def test_ice_argument_errors_and_fp32():
     f, ref = _load([c for c in MAN if c["algo"] == "an05"][0])
     with pytest.raises(ab.AerobulkError):
         ab.turb_ice("lu12", 2.0, 10.0, f["Ts_i"], f["theta_zt"], f["qs_i"], f["q_zt"], f["U_zu"])      # frice missing
+    o = ab.turb_ice("an05", 2.0, 10.0, f["Ts_i"], f["theta_zt"], f["qs_i"], f["q_zt"], f["U_zu"], optional=("CdN_frm",))
+    assert "CdN_frm" not in o                   # the form-drag output exists for LG15(_IO) only
     with pytest.raises(ab.AerobulkError):
         ab.turb_ice("best", 2.0, 10.0, f["Ts_i"], f["theta_zt"], f["qs_i"], f["q_zt"], f["U_zu"])
     o = ab.turb_ice("an05", 2.0, 10.0, *[f[k].astype(np.float32) for k in ("Ts_i", "theta_zt", "qs_i", "q_zt", "U_zu")], precision="f32")

@@ -1,5 +1,5 @@
 """Golden data of the sea-ice bulk algorithms: 2048 synthetic polar cells run through the UNMODIFIED
-reference's TURB_ICE_NEMO / AN05 / LU12 / LG15 by oracle/_ref/ref_ice_driver.x (= aerobulk_amd/fortran/turb_ice_driver.f90
+reference's TURB_ICE_NEMO / EASY / AN05 / LU12 / LG15 / LG15_IO by oracle/_ref/ref_ice_driver.x (= aerobulk_amd/fortran/turb_ice_driver.f90
 linked with the reference's src/ice modules).  Needs /root/reference.
 
     python tools/gen_ice_golden.py   ->  tests/golden/ice_inputs.npz, ice_<case>.npz, ice_manifest.json
@@ -35,7 +35,8 @@ def make_inputs():
 
 
 CASES = [("nemo", 5, 2.0, 10.0), ("easy", 5, 2.0, 10.0), ("easy", 8, 10.0, 10.0), ("an05", 5, 2.0, 10.0), ("an05", 8, 10.0, 10.0), ("an05", 4, 2.0, 12.5), ("lu12", 5, 2.0, 10.0),
-         ("lg15", 5, 2.0, 10.0), ("lg15", 8, 10.0, 10.0), ("lg15", 3, 3.0, 15.0)]
+         ("lg15", 5, 2.0, 10.0), ("lg15", 8, 10.0, 10.0), ("lg15", 3, 3.0, 15.0),
+         ("lg15_io", 5, 2.0, 10.0)]   # TURB_ICE_LG15_IO as src/ice/test_aerobulk_oce+ice.f90:345 calls it, + CdN_frm
 
 
 def main():
