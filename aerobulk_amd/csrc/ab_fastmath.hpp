@@ -100,6 +100,43 @@ template <int N> AB_FM ab_coefs<N> ab_load(const double *g)
     }
     return r;
 }
+// Horner evaluation sum_i g[i] x^i of a table, highest coefficients first, EIGHT coefficients (16 SGPRs) at a time: the
+// address of the next chunk is made to depend on the partial sum, so that a 21-coefficient table occupies 16 scalar
+// registers instead of 48 while it is evaluated (the kernels are at the SGPR limit: every table register beyond that is
+// a spilled loop invariant, reloaded with v_readlane_b32 in the iteration loop).
+template <int N> AB_FM double horner_coefs(const double *g, double x)
+{
+#ifdef AB_WHOLE_TABLES
+    const ab_coefs<N> c = ab_load<N>(g);
+    double p = c.v[N - 1];
+#pragma unroll
+    for (int i = N - 2; i >= 0; --i) p = p_fmac(p, x, c.v[i]);
+    return p;
+#else
+    constexpr int NP = ab_pad4(N), TOP = (NP - 1) & ~7;
+    double p = 0.0;
+#pragma unroll
+    for (int i = TOP; i >= 0; i -= 8) {
+        ab_tabp q = (ab_tabp)g + i;
+        if (i == TOP)
+            asm volatile("" : "+s"(q));
+        else
+            asm volatile("" : "+s"(q), "+v"(p));
+        if (NP - i >= 8) {
+            const ab_d8 t = *(const ab_d8 __attribute__((address_space(4))) *)q;
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+                if (i + k < N) p = (i + k == N - 1) ? t[k] : p_fmac(p, x, t[k]);
+        } else {
+            const ab_d4 t = *(const ab_d4 __attribute__((address_space(4))) *)q;
+#pragma unroll
+            for (int k = 3; k >= 0; --k)
+                if (i + k < N) p = (i + k == N - 1) ? t[k] : p_fmac(p, x, t[k]);
+        }
+    }
+    return p;
+#endif
+}
 #else
 #define AB_TAB static const
 template <int N> AB_FM ab_coefs<N> ab_load(const double *g)
@@ -107,6 +144,12 @@ template <int N> AB_FM ab_coefs<N> ab_load(const double *g)
     ab_coefs<N> r;
     for (int i = 0; i < N; ++i) r.v[i] = g[i];
     return r;
+}
+template <int N> AB_FM double horner_coefs(const double *g, double x)
+{
+    double p = g[N - 1];
+    for (int i = N - 2; i >= 0; --i) p = p_fmac(p, x, g[i]);
+    return p;
 }
 #endif
 AB_TAB double kLogP[ab_pad4(7)] = {0.666666666666667, 0.39999999999899505, 0.28571428625975487, 0.2222221113479508,
@@ -158,10 +201,7 @@ AB_FM double qlog(double x)
     const double f = m - 1.0;
     const double s = qdiv(f, 2.0 + f);
     const double u = s * s;
-    const ab_coefs<7> c = ab_load<7>(kLogP);
-    double p = c.v[6];
-#pragma unroll
-    for (int i = 5; i >= 0; --i) p = p_fmac(p, u, c.v[i]);
+    const double p = horner_coefs<7>(kLogP, u);
     const double ef = (double)e;
     const double t = p_fma(s * u, p, ef * 2.3190468138462996e-17);  // s^3 P + e ln2_lo
     return p_fma(ef, 0.6931471805599453, (s + s) + t);
@@ -172,10 +212,7 @@ AB_FM double qlog10(double x) { return qlog(x) * 0.4342944819032518; }
 // exp(r) = 1 + r + r^2 P(r) on |r| <= ln2/2, P degree 9 (truncation 1.6e-17 relative)
 AB_FM double exp_kernel(double r)
 {
-    const ab_coefs<10> c = ab_load<10>(kExpP);
-    double p = c.v[9];
-#pragma unroll
-    for (int i = 8; i >= 0; --i) p = p_fmac(p, r, c.v[i]);
+    const double p = horner_coefs<10>(kExpP, r);
     return 1.0 + p_fma(r * r, p, r);
 }
 // exp(x), any finite x (saturates to 0 / inf through ldexp)
@@ -208,10 +245,7 @@ AB_FM double qatan(double x)
     const double blo = big ? 6.123233995736766e-17 : (mid ? 3.061616997868383e-17 : 0.0);
     const double t = qdiv(num, den);
     const double u = t * t;
-    const ab_coefs<11> c = ab_load<11>(kAtanP);
-    double p = c.v[10];
-#pragma unroll
-    for (int i = 9; i >= 0; --i) p = p_fmac(p, u, c.v[i]);
+    const double p = horner_coefs<11>(kAtanP, u);
     const double r = bhi + (p_fma(t * u, p, blo) + t);
     return p_copysign(r, x);
 }
@@ -222,10 +256,7 @@ AB_FM double qatan_ge1(double x)
     const bool big = x > 2.414213562373095;
     const double t = qdiv(big ? -1.0 : x - 1.0, big ? x : x + 1.0);
     const double u = t * t;
-    const ab_coefs<11> c = ab_load<11>(kAtanP);
-    double p = c.v[10];
-#pragma unroll
-    for (int i = 9; i >= 0; --i) p = p_fmac(p, u, c.v[i]);
+    const double p = horner_coefs<11>(kAtanP, u);
     return (big ? 1.5707963267948966 : 0.7853981633974483) + (p_fma(t * u, p, big ? 6.123233995736766e-17 : 3.061616997868383e-17) + t);
 }
 // 1/sqrt(x), x > 0 normal: rsq seed, one Newton step, one residual correction (<= 1 ulp)

@@ -21,19 +21,19 @@ template <class R> struct IceArgs {
 };
 
 template <class R, int ALGO>
-__device__ __forceinline__ void ice_cell(const IceArgs<R> &a, const IceIn<R> &in, IceOut<R> &o)
+__device__ __forceinline__ void ice_cell(const IceArgs<R> &a, const Heights<R> &hh, int nb_iter, const IceIn<R> &in, IceOut<R> &o)
 {
     if (ALGO == 1) {
-        turb_ice_const<R>(a.h, in, KIce<R>::rCd_ice, o);
+        turb_ice_const<R>(hh, in, KIce<R>::rCd_ice, o);
     } else if (ALGO == 2) {
-        turb_ice_an05<R>(a.h, in, a.nb_iter, o);
+        turb_ice_an05<R>(hh, in, nb_iter, o);
     } else if (ALGO == 3) {   // skin drag of z0 = 0.69 mm + form drag (mod_blk_ice_lu12.f90:156-160)
-        const R zi = Mth<R>::rcp(a.h.log_zu - R(-7.278818960372969));
-        turb_ice_const<R>(a.h, in, K<R>::vkarmn2 * zi * zi + cdn10_f_lu13<R>(in.frice), o);
+        const R zi = Mth<R>::rcp(hh.log_zu - R(-7.278818960372969));
+        turb_ice_const<R>(hh, in, K<R>::vkarmn2 * zi * zi + cdn10_f_lu13<R>(in.frice), o);
     } else if (ALGO == 4) {
-        turb_ice_lg15<R>(a.h, in, a.frice[a.n - 1], a.nb_iter, o);   // wave-uniform load of the last cell's concentration
+        turb_ice_lg15<R>(hh, in, a.frice[a.n - 1], nb_iter, o);   // wave-uniform load of the last cell's concentration
     } else {
-        turb_ice_easy<R>(a.h, in, a.cxn[0], a.cxn[1], a.cxn[2], a.nb_iter, o);
+        turb_ice_easy<R>(hh, in, a.cxn[0], a.cxn[1], a.cxn[2], nb_iter, o);
     }
 }
 
@@ -49,7 +49,7 @@ template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, AB_WAVES_
         in.Ts_i = a.Ts_i[k]; in.theta_zt = a.theta_zt[k]; in.qs_i = a.qs_i[k]; in.q_zt = a.q_zt[k]; in.wnd = a.U_zu[k];
         in.frice = (ALGO == 3) ? a.frice[k] : R(0.);
         IceOut<R> o;
-        ice_cell<R, ALGO>(a, in, o);
+        ice_cell<R, ALGO>(a, a.h, a.nb_iter, in, o);
         const R d[13] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ub, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10};
 #pragma unroll
         for (int i = 0; i < 13; ++i)
@@ -90,6 +90,9 @@ template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, AB_WAVES_
     }
     __syncthreads();
     const int lane = tid & 63;
+    const Heights<R> hh = detached(a.h);      // loop invariants out of their scalar-load tuples (ab_tile.hpp)
+    int nb_iter = a.nb_iter;
+    uniform_scalar(nb_iter);
 #pragma unroll 1
     for (;;) {
         int g = 0;
@@ -103,7 +106,7 @@ template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, AB_WAVES_
         in.Ts_i = s_f[0][j]; in.theta_zt = s_f[1][j]; in.qs_i = s_f[2][j]; in.q_zt = s_f[3][j]; in.wnd = s_f[4][j];
         in.frice = R(0.);
         IceOut<R> o;
-        ice_cell<R, ALGO>(a, in, o);
+        ice_cell<R, ALGO>(a, hh, nb_iter, in, o);
         const R d7[7] = {o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10};
 #pragma unroll
         for (int i = 0; i < 7; ++i)

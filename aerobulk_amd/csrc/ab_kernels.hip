@@ -49,7 +49,7 @@ template <class R> struct DiagArgs {
 // One cell from its pre-processed inputs to the six outputs of aerobulk_compute: TURB_<algo> (mod_aerobulk_compute.f90
 // :129-176), BULK_FORMULA and the stress vector (:184-194).  k: global cell index (warm-layer state, diagnostics, longitude).
 template <class R, int ALGO, bool SKIN, bool DIAG>
-__device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArgs<R> &dg, const Heights<R> &hh, long k, R sst,
+__device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArgs<R> &dg, const Heights<R> &hh, int nb_iter, long k, R sst,
                                              R theta_zt, R q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
                                              R &zEvap, R &T_s)
 {
@@ -79,11 +79,11 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
 
     CellOut<R> o;
     constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
-    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG>(hh, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 3) turb_ncar<R, DIAG>(hh, in, a.nb_iter, o);
-    else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG>(hh, in, a.nb_iter, wl, o);
-    else turb_andreas<R, DIAG>(hh, in, a.nb_iter, o);
+    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG>(hh, in, nb_iter, wl, dawn, o);
+    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG>(hh, in, nb_iter, wl, dawn, o);
+    else if (ALGO == 3) turb_ncar<R, DIAG>(hh, in, nb_iter, o);
+    else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG>(hh, in, nb_iter, wl, o);
+    else turb_andreas<R, DIAG>(hh, in, nb_iter, o);
     if (DIAG) {
         const R d[16] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
                          o.dT_cs, o.dT_wl, o.Hz_wl};
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));
         else q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));
         R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG>(a, dg, a.h, k, a.sst[k], theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt), q_zt, a.u[k],
+        compute_cell<R, ALGO, SKIN, DIAG>(a, dg, a.h, a.nb_iter, k, a.sst[k], theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt), q_zt, a.u[k],
                                           a.v[k], slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
         a.ql[k] = QL;
         a.qh[k] = QH;
@@ -185,7 +185,9 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
 
     // ---- phase 3: groups of 64 sorted cells, fetched from a queue
     const int lane = tid & 63;
-    const Heights<R> &hh = a.h;
+    const Heights<R> hh = detached(a.h);      // loop invariants out of their scalar-load tuples (ab_tile.hpp)
+    int nb_iter = a.nb_iter;
+    uniform_scalar(nb_iter);
 #pragma unroll 1
     for (;;) {
         int g = 0;
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         if (k >= a.n) continue;
 
         R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG>(a, dg, hh, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
+        compute_cell<R, ALGO, SKIN, DIAG>(a, dg, hh, nb_iter, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
                                           SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
                                           ty, zEvap, T_s);
         // the cell's LDS slot is read by this lane only: reuse it for the results

@@ -71,11 +71,7 @@ AB_TAB double kGoffA[fm::ab_pad4(15)] = {1.2415921763001385, 0.6554537644583072,
                                   5.6079820609247194e-12, -6.519141017660851e-13};
 __device__ __forceinline__ double goff_poly(double x)
 {
-    const fm::ab_coefs<15> c = fm::ab_load<15>(kGoffA);
-    double p = c.v[14];
-#pragma unroll
-    for (int i = 13; i >= 0; --i) p = fm::p_fmac(p, x, c.v[i]);
-    return p;
+    return fm::horner_coefs<15>(kGoffA, x);
 }
 __device__ __forceinline__ float goff_poly(float x)
 {
@@ -87,11 +83,7 @@ __device__ __forceinline__ float goff_poly(float x)
 // Horner evaluation of a constant-memory coefficient table (coefficients fetched with scalar loads)
 template <int N> __device__ __forceinline__ double horner_tab(const double *tab, double x)
 {
-    const fm::ab_coefs<N> c = fm::ab_load<N>(tab);
-    double p = c.v[N - 1];
-#pragma unroll
-    for (int i = N - 2; i >= 0; --i) p = fm::p_fmac(p, x, c.v[i]);
-    return p;
+    return fm::horner_coefs<N>(tab, x);
 }
 template <int N> __device__ __forceinline__ float horner_tab(const double *tab, float x)
 {

@@ -12,7 +12,31 @@ namespace ab {
 #define AB_WAVES_PER_EU 4
 #endif
 
-constexpr int kBuckets = 16;     // 4 stability bins x 4 warm-layer bins
+constexpr int kBuckets = 16;
+
+// detach a wave-uniform value from the scalar-load tuple it arrived in (see flux_kernel, phase 3)
+template <class T> __device__ __forceinline__ void uniform_scalar(T &x)
+{
+    T y;   // a real copy: a tied "+s" operand is coalesced back into the tuple
+    if (sizeof(T) == 8)
+        asm volatile("s_mov_b64 %0, %1" : "=s"(y) : "s"(x));
+    else
+        asm volatile("s_mov_b32 %0, %1" : "=s"(y) : "s"(x));
+    x = y;
+}
+// The kernel arguments arrive as 8- and 16-register scalar loads, and the register allocator spills and reloads such a tuple
+// as a whole (16 v_readlane_b32 per reload, inside the iteration loop): the loop invariants of the iteration are detached
+// from it one by one.  MI355X, 4320x3600 fp64 nb_iter=5: COARE3p6 + skin 3.49 -> 3.46 ms, no skin 1.86 -> 1.81 ms.
+template <class R> __device__ __forceinline__ Heights<R> detached(const Heights<R> &g)
+{
+    Heights<R> h = g;
+#ifndef AB_ARGS_AS_LOADED
+    uniform_scalar(h.zt); uniform_scalar(h.zu); uniform_scalar(h.log_zt); uniform_scalar(h.log_zu); uniform_scalar(h.log_10);
+    uniform_scalar(h.log_ztu); uniform_scalar(h.log_zu10); uniform_scalar(h.fg_ca); uniform_scalar(h.inv_zu);
+    uniform_scalar(h.zt_o_zu); uniform_scalar(h.zt_eq_zu);
+#endif
+    return h;
+}     // 4 stability bins x 4 warm-layer bins
 template <class R, int ALGO, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // flux: sst theta q_zt u v slp [qsw rlw] ; turb: 8 / 6 too
     // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) + bucket (1 B) per cell

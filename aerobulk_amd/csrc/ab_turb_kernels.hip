@@ -27,7 +27,7 @@ template <class R> struct TurbArgs {
 // One cell of a TURB_* call: returns the eight values that go back to the caller's arrays (Cd Ch Ce t_zu q_zu Ubzu T_s q_s);
 // the OPTIONAL outputs and the warm-layer state are written straight to global memory at cell k.
 template <class R, int ALGO, int SKIN>
-__device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, long k, const CellIn<R> &in, R (&res)[8])
+__device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, const Heights<R> &hh, int nb_iter, long k, const CellIn<R> &in, R (&res)[8])
 {
     constexpr bool WL = (SKIN & kSkinWL) != 0;
     R wl[4] = {R(0.), R(0.), R(0.), R(0.)};
@@ -43,11 +43,11 @@ __device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, long k, const Ce
         if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>(a.lon[k], a.isecday) : (a.dawn_uniform != 0);
     }
     CellOut<R> o;
-    if (ALGO == 1) turb_coare<R, false, SKIN, true>(a.h, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 2) turb_coare<R, true, SKIN, true>(a.h, in, a.nb_iter, wl, dawn, o);
-    else if (ALGO == 3) turb_ncar<R, true>(a.h, in, a.nb_iter, o);
-    else if (ALGO == 4) turb_ecmwf<R, SKIN, true>(a.h, in, a.nb_iter, wl, o);
-    else turb_andreas<R, true>(a.h, in, a.nb_iter, o);
+    if (ALGO == 1) turb_coare<R, false, SKIN, true>(hh, in, nb_iter, wl, dawn, o);
+    else if (ALGO == 2) turb_coare<R, true, SKIN, true>(hh, in, nb_iter, wl, dawn, o);
+    else if (ALGO == 3) turb_ncar<R, true>(hh, in, nb_iter, o);
+    else if (ALGO == 4) turb_ecmwf<R, SKIN, true>(hh, in, nb_iter, wl, o);
+    else turb_andreas<R, true>(hh, in, nb_iter, o);
     const R d[10] = {o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10, o.dT_cs, o.dT_wl, o.Hz_wl};
 #pragma unroll
     for (int i = 0; i < 10; ++i)
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const Tur
         in.sst = a.T_s[k]; in.theta_zt = a.theta_zt[k]; in.ssq = a.q_s[k]; in.q_zt = a.q_zt[k]; in.wnd = a.U_zu[k];
         in.slp = R(101000.); in.qsw = R(0.); in.rlw = R(0.);
         R res[8];
-        turb_cell<R, ALGO, SKIN>(a, k, in, res);
+        turb_cell<R, ALGO, SKIN>(a, a.h, a.nb_iter, k, in, res);
 #pragma unroll
         for (int i = 0; i < 6; ++i) a.out[i][k] = res[i];
         return;
@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const Tur
     }
     __syncthreads();
     const int lane = tid & 63;
+    const Heights<R> hh = detached(a.h);      // loop invariants out of their scalar-load tuples (ab_tile.hpp)
+    int nb_iter = a.nb_iter;
+    uniform_scalar(nb_iter);
 #pragma unroll 1
     for (;;) {
         int g = 0;
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const Tur
         in.qsw = ANYSKIN ? s_f[ANYSKIN ? 6 : 0][j] : R(0.);
         in.rlw = ANYSKIN ? s_f[ANYSKIN ? 7 : 0][j] : R(0.);
         R res[8];
-        turb_cell<R, ALGO, SKIN>(a, k, in, res);
+        turb_cell<R, ALGO, SKIN>(a, hh, nb_iter, k, in, res);
 #pragma unroll
         for (int i = 0; i < (ANYSKIN ? 8 : 6); ++i) s_f[i][j] = res[i];    // the slot is read by this lane only: reuse it
     }
