@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -38,6 +39,30 @@ int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess)                                                                          \
             return fail(AB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// Optional ROCTx ranges around the entry points that launch work, for `rocprofv3 --marker-trace` (the reference has no
+// tracing).  Off unless AEROBULK_AMD_ROCTX=1; the marker library is looked up at run time, never linked.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = getenv("AEROBULK_AMD_ROCTX");
+        if (!e || e[0] != '1') return;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+struct Range {
+    static Roctx &tx() { static Roctx r; return r; }
+    bool on;
+    explicit Range(const char *name) : on(tx().push != nullptr) { if (on) tx().push(name); }
+    ~Range() { if (on) tx().pop(); }
+};
 
 const char *kAlgoNames[6] = {"other", "coare3p0", "coare3p6", "ncar", "ecmwf", "andreas"};
 
@@ -322,6 +347,7 @@ int ab_session_init_stats(ab_session *s, const void *sst, const void *t_zt, cons
                           const void *v_zu, const void *slp, const void *rad_sw, const void *rad_lw, int mem,
                           double stats[AB_INIT_NSTATS])
 {
+    Range trace_("ab_session_init_stats");
     if (!s || !stats) return fail(AB_ERR_ARG, "NULL argument");
     if (!sst || !t_zt || !hum_zt || !u_zu || !v_zu || !slp) return fail(AB_ERR_ARG, "ab_session_init: NULL input field");
     AB_HIP(hipSetDevice(s->device));
@@ -426,6 +452,7 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
                        const void *rad_lw, void *ql, void *qh, void *tau_x, void *tau_y, void *evap, void *t_s,
                        int mem, void *stream)
 {
+    Range trace_("ab_session_compute");
     if (!s) return fail(AB_ERR_ARG, "NULL session");
     if (jt < 1) return fail(AB_ERR_JT, "AEROBULK_MODEL => jt < 1 !??\n we are in a Fortran world here...");
     if (jt > s->nt) return fail(AB_ERR_STATE, "jt=%d > nt=%d", jt, s->nt);
@@ -522,6 +549,7 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
 int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int use_wl, int nb_iter,
                     const ab_turb_fields *f, int mem, void *stream)
 {
+    Range trace_("ab_session_turb");
     if (!s || !f) return fail(AB_ERR_ARG, "ab_session_turb: NULL argument");
     if (kt < 1) return fail(AB_ERR_JT, "TURB_%s => kt < 1 !??", ab_algo_name(s->algo));
     if (nb_iter < 0) return fail(AB_ERR_ARG, "nb_iter < 0");
@@ -758,6 +786,7 @@ int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int 
 int ab_turb_neutral_10m(int algo, int nb_iter, const void *U_N10, void *CdN10, void *ChN10, void *CeN10, void *z0, long n,
                         int precision, int mem, void *stream)
 {
+    Range trace_("ab_turb_neutral_10m");
     if (algo < AB_ALGO_COARE3P0 || algo > AB_ALGO_ECMWF)   // andreas: "YET TO BE CODED" + STOP in the reference (:190-191)
         return fail(AB_ERR_ALGO, "ERROR: algorithm %s is not supported yet!", ab_algo_name(algo));
     if (!U_N10 || !CdN10 || !ChN10 || !CeN10 || !z0 || n <= 0 || nb_iter < 0) return fail(AB_ERR_ARG, "ab_turb_neutral_10m: bad argument");
@@ -815,6 +844,7 @@ int ab_turb_ice_easy(double zt, double zu, int nb_iter, double CdN, double ChN, 
 static int turb_ice_impl(int ice_algo, double zt, double zu, int nb_iter, const double cxn[3], const ab_ice_fields *f, long n,
                          int precision, int mem, void *stream)
 {
+    Range trace_("ab_turb_ice");
     if (!f) return fail(AB_ERR_ARG, "ab_turb_ice: NULL fields");
     if (n <= 0 || nb_iter < 0) return fail(AB_ERR_ARG, "ab_turb_ice: bad n / nb_iter");
     if (precision != AB_F64 && precision != AB_F32) return fail(AB_ERR_ARG, "bad precision %d", precision);
