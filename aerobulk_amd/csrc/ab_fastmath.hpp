@@ -152,8 +152,6 @@ template <int N> AB_FM double horner_coefs(const double *g, double x)
     return p;
 }
 #endif
-AB_TAB double kLogP[ab_pad4(7)] = {0.666666666666667, 0.39999999999899505, 0.28571428625975487, 0.2222221113479508,
-                          0.18182889125261723, 0.15331721600556042, 0.14616449685043406};
 AB_TAB double kExpP[ab_pad4(10)] = {0.5000000000000001, 0.16666666666666669, 0.041666666666624164, 0.008333333333330065,
                            0.0013888888917196719, 0.00019841269863040545, 2.4801521322368692e-05,
                            2.7557268480310024e-06, 2.7620075879983367e-07, 2.5100375832561234e-08};
@@ -189,22 +187,76 @@ AB_FM double qsqrt_pos(double x)
 AB_FM double qsqrt(double x) { return x > 0.0 ? qsqrt_pos(x) : (x == 0.0 ? 0.0 : __builtin_nan("")); }
 
 // ---------------------------------------------------------------- log
-// log(x), x > 0 normal.  x = m 2^e, m in [sqrt(1/2), sqrt 2); s = (m-1)/(m+1);
-// log m = 2 atanh s = 2s + s^3 P(s^2), |s| <= 0.1716, P degree 6 (truncation 4.6e-18 relative).
+// log(x), x > 0 normal (1e-300 < x < 1e300), WITHOUT a division (tools/gen_logtab.py):
+//    x = 2^n m, m in [1/sqrt2, sqrt2);  k = rint(64 m) in [45,91];  r = m invc[k] - 1 (one FMA, |r| <= 0.0112);
+//    log x = n ln2 + logc[k] + r + r^2 Q(r),  Q degree 5 (8.2e-17 relative to log1p(r)).
+// invc[k] = double(64/k) and logc[k] = -log(invc[k]) of that ROUNDED value, so the identity is exact; k = 64 holds (1, 0):
+// arguments next to 1 lose nothing.  On the device the 47 pairs live in LDS (752 B per block, filled by lds_tables_init();
+// one ds_read_b128 per log on the LDS pipe): 18 VALU slots instead of 28 for the atanh form, whose (m-1)/(m+1) costs a
+// quarter-rate v_rcp_f64 plus five FMAs.
+constexpr int kLogK0 = 45, kLogK1 = 91, kLogN = kLogK1 - kLogK0 + 1;
+AB_TAB double kLogTab[2 * kLogN] = {
+    1.4222222222222223, -0.35222059358935215, 1.391304347826087, -0.3302416868705768,
+    1.3617021276595744, -0.30873548164961323, 1.3333333333333333, -0.28768207245178085,
+    1.3061224489795917, -0.26706278524904514, 1.28, -0.2468600779315258,
+    1.2549019607843137, -0.22705745063534608, 1.2307692307692308, -0.20763936477824455,
+    1.2075471698113207, -0.18859116980754997, 1.1851851851851851, -0.16989903679539742,
+    1.1636363636363636, -0.15154989812720088, 1.1428571428571428, -0.13353139262452257,
+    1.1228070175438596, -0.11583181552512165, 1.103448275862069, -0.09844007281325251,
+    1.0847457627118644, -0.0813456394539524, 1.0666666666666667, -0.06453852113757116,
+    1.0491803278688525, -0.04800921918636066, 1.032258064516129, -0.03174869831458027,
+    1.0158730158730158, -0.015748356968139112, 1.0, 0.0,
+    0.9846153846153847, 0.015504186535965199, 0.9696969696969697, 0.03077165866675366,
+    0.9552238805970149, 0.04580953603129422, 0.9411764705882353, 0.060624621816434854,
+    0.927536231884058, 0.07522342123758752, 0.9142857142857143, 0.08961215868968717,
+    0.9014084507042254, 0.10379679368164355, 0.8888888888888888, 0.11778303565638351,
+    0.8767123287671232, 0.13157635778871932, 0.8648648648648649, 0.14518200984449783,
+    0.8533333333333334, 0.15860503017663852, 0.8421052631578947, 0.17185025692665928,
+    0.8311688311688312, 0.18492233849401193, 0.8205128205128205, 0.19782574332991992,
+    0.810126582278481, 0.21056476910734964, 0.8, 0.2231435513142097,
+    0.7901234567901234, 0.23556607131276697, 0.7804878048780488, 0.2478361639045812,
+    0.7710843373493976, 0.259957524436926, 0.7619047619047619, 0.2719337154836418,
+    0.7529411764705882, 0.2837681731306446, 0.7441860465116279, 0.2954642128938359,
+    0.735632183908046, 0.3070250352949119, 0.7272727272727273, 0.3184537311185346,
+    0.7191011235955056, 0.32975328637246804, 0.7111111111111111, 0.3409265869705932,
+    0.7032967032967034, 0.3519764231571781};
+AB_TAB double kLogQ[ab_pad4(6)] = {-0.5000000000000073, 0.33333333333333987, -0.24999999892817357, 0.19999999904726232,
+                          -0.16668981738710087, 0.14287772132727572};
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+static __shared__ __attribute__((aligned(16))) double s_logtab[2 * kLogN];
+// every kernel that may evaluate a log calls this first (all threads), then __syncthreads()
+AB_FM void lds_tables_init()
+{
+    for (int i = (int)threadIdx.x; i < 2 * kLogN; i += (int)blockDim.x) s_logtab[i] = kLogTab[i];
+}
+AB_FM double log_invc(int k) { return s_logtab[2 * (k - kLogK0)]; }
+// -DAB_LOG_LATE_LOGC issues the load of logc after the polynomial (the asm ties the address to q) so that the pair does
+// not sit in four VGPRs across it.  Measured: it takes the COARE + skin kernels from 22 to 10 spilled VGPRs without making
+// them faster, and costs every other kernel 5 % (exposed LDS latency): off.
+AB_FM double log_logc(int k, double &q)
+{
+#ifdef AB_LOG_LATE_LOGC
+    asm volatile("" : "+v"(k), "+v"(q));
+#endif
+    return s_logtab[2 * (k - kLogK0) + 1];
+}
+AB_FM int p_lo32(double z) { return __double2loint(z); }
+#else
+AB_FM double log_invc(int k) { return kLogTab[2 * (k - kLogK0)]; }
+AB_FM double log_logc(int k, double &) { return kLogTab[2 * (k - kLogK0) + 1]; }
+AB_FM int p_lo32(double z) { int64_t b; std::memcpy(&b, &z, 8); return (int)(uint32_t)b; }
+#endif
 AB_FM double qlog(double x)
 {
-    double m = p_mant(x);
-    int e = p_exp(x);
-    const bool lo = m < 0.70710678118654752;
-    m = lo ? m + m : m;
-    e = lo ? e - 1 : e;
-    const double f = m - 1.0;
-    const double s = qdiv(f, 2.0 + f);
-    const double u = s * s;
-    const double p = horner_coefs<7>(kLogP, u);
-    const double ef = (double)e;
-    const double t = p_fma(s * u, p, ef * 2.3190468138462996e-17);  // s^3 P + e ln2_lo
-    return p_fma(ef, 0.6931471805599453, (s + s) + t);
+    const int t = 1 - p_exp(x * 1.4142135623730951);          // x sqrt2 in [2^(e-1), 2^e): n = e - 1 = -t
+    const double m = p_ldexp(x, t);                           // [1/sqrt2, sqrt2) (+- 1 ulp at the ends)
+    const int k = p_lo32(p_fma(m, 64.0, 6755399441055744.0)); // rint(64 m) in the low word of 64 m + 1.5 2^52
+    const double r = p_fma(m, log_invc(k), -1.0);
+    double q = horner_coefs<6>(kLogQ, r);
+    const double logc = log_logc(k, q);
+    const double nf = (double)t;                              // = -n
+    const double lo = p_fma(-nf, 1.9082149292705877e-10, p_fma(r * r, q, r));   // n ln2_lo + log1p(r)
+    return p_fma(-nf, 0.6931471803691238, logc + lo);         // n ln2_hi: 21 trailing zero bits, exact
 }
 AB_FM double qlog10(double x) { return qlog(x) * 0.4342944819032518; }
 

@@ -42,6 +42,7 @@ __device__ __forceinline__ void ice_cell(const IceArgs<R> &a, const Heights<R> &
 // difference in four bins.
 template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) ice_kernel(const IceArgs<R> a)
 {
+    math_tables_init<R>();
     if (ALGO == 1 || ALGO == 3) {
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
         if (k >= a.n) return;

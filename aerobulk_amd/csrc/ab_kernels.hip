@@ -51,7 +51,8 @@ template <class R> struct DiagArgs {
 template <class R, int ALGO, bool SKIN, bool DIAG>
 __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArgs<R> &dg, const Heights<R> &hh, int nb_iter, long k, R sst,
                                              R theta_zt, R q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
-                                             R &zEvap, R &T_s)
+                                             R &zEvap, R &T_s, const volatile R *pu = nullptr, const volatile R *pv = nullptr,
+                                             volatile R *park = nullptr, int pstride = 0)
 {
     using M = Mth<R>;
     CellIn<R> in;
@@ -79,8 +80,8 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
 
     CellOut<R> o;
     constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
-    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG>(hh, in, nb_iter, wl, dawn, o);
-    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG>(hh, in, nb_iter, wl, dawn, o);
+    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG>(hh, in, nb_iter, wl, dawn, o, park, pstride);
+    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 3) turb_ncar<R, DIAG>(hh, in, nb_iter, o);
     else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG>(hh, in, nb_iter, wl, o);
     else turb_andreas<R, DIAG>(hh, in, nb_iter, o);
@@ -104,8 +105,9 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
     ty = R(0.);
     if (in.wnd > R(1.E-3)) {
         const R s = zTaum / in.wnd;
-        tx = s * uu;
-        ty = s * vv;
+        // tiled path: u and v are still in the cell's LDS slots; re-reading them here keeps 4 VGPRs free across the iteration
+        tx = s * (pu ? *pu : uu);
+        ty = s * (pv ? *pv : vv);
     }
     T_s = o.T_s;
 }
@@ -113,6 +115,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
 template <class R, int ALGO, bool SKIN, bool DIAG>
 __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
 {
+    math_tables_init<R>();
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
         if (k >= a.n) return;
@@ -201,7 +204,9 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         R QL, QH, tx, ty, zEvap, T_s;
         compute_cell<R, ALGO, SKIN, DIAG>(a, dg, hh, nb_iter, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
                                           SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
-                                          ty, zEvap, T_s);
+                                          ty, zEvap, T_s, &s_f[3][j], &s_f[4][j],
+                                          // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare
+                                          (SKIN && sizeof(R) == 8) ? &s_f[0][j] : nullptr, T::kCells);
         // the cell's LDS slot is read by this lane only: reuse it for the results
         s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = T_s;
     }
@@ -278,6 +283,7 @@ __global__ void __launch_bounds__(kBlock) init_stats_kernel(const R *sst, const 
                                                             const R *v, const R *slp, const R *rsw, const R *rlw,
                                                             long n, double *partials)
 {
+    math_tables_init<double>();
     double cnt = 0.;
     double sum[kStatFields], mn[kStatFields], mx[kStatFields];
 #pragma unroll
@@ -363,6 +369,7 @@ template <class R>
 __global__ void __launch_bounds__(kBlock) synth_kernel(R *sst, R *t_zt, R *q_zt, R *u, R *v, R *slp, R *rsw, R *rlw,
                                                        long ni, long j0, long n)
 {
+    math_tables_init<double>();
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
     const double i = (double)(k % ni + 1), j = (double)(j0 + k / ni + 1);
@@ -413,6 +420,7 @@ hipError_t launch_synth(void *sst, void *t_zt, void *q_zt, void *u, void *v, voi
 // Unit-test hook for the fp64 device math of ab_fastmath.hpp (tests/test_gpu_math.py).
 __global__ void __launch_bounds__(kBlock) math_test_kernel(int op, const double *x, const double *y, double *o, long n)
 {
+    math_tables_init<double>();
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
     const double a = x[k], b = y ? y[k] : 1.0;

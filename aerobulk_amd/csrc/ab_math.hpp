@@ -15,6 +15,16 @@
 
 namespace ab {
 
+// Block prologue of every kernel whose fp64 math may take a log: fill the LDS table of fm::qlog, then a barrier.  The fp32
+// paths use the hardware transcendentals and need nothing.  Must run before any early return of the kernel.
+template <class R> __device__ __forceinline__ void math_tables_init()
+{
+    if constexpr (sizeof(R) == 8) {
+        fm::lds_tables_init();
+        __syncthreads();
+    }
+}
+
 template <class R> struct Mth;
 
 template <> struct Mth<double> {

@@ -499,9 +499,12 @@ template <class R> struct CellOut {
 // l_use_cs (cool skin), bit 1 = l_use_wl (warm layer).  aerobulk_compute always switches both on together
 // (mod_aerobulk_compute.f90:133,144: SKIN = 3); callers of TURB_* may choose either (ab_session_turb).
 constexpr int kSkinCS = 1, kSkinWL = 2, kSkinBoth = 3;
+// park / pstride: optional per-lane scratch words park[i * pstride], i = 0,1,2,5,6 (LDS slots of the caller's tile).  The warm-layer state beyond dT_wl and the
+// two WL_COARE constants are only touched by the live WL_COARE calls (jit = 1 and the divisors of nb_iter): parked there they
+// do not hold ten VGPRs across the rest of the iteration (the COARE + skin kernels sit at the 128-VGPR limit).
 template <class R, bool V36, int SKIN, bool DIAG = false>
 __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
-                                           bool dawn, CellOut<R> &o)
+                                           bool dawn, CellOut<R> &o, volatile R *park = nullptr, int pstride = 0)
 {
     using M = Mth<R>;
     const R vk = K<R>::vkarmn;
@@ -523,6 +526,11 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             wc.zcd2 = M::sqrt(R(2.) * zalpha * K<R>::grav * R(1. / (0.65 * 1025.)))
                       * R(1. / 271219.5770957547);                    // / rCp0_w**1.5 :156
         }
+    }
+    const bool parked = WL && park != nullptr;
+    if (parked) {
+        park[0] = wl[1]; park[pstride] = wl[2]; park[2 * pstride] = wl[3];
+        park[5 * pstride] = wc.zcd1; park[6 * pstride] = wc.zcd2;
     }
     R zus, zts, zqs, t_zu, q_zu, Ubzu, zz0;
     first_guess_coare(h, T_s, in.theta_zt, q_s, in.q_zt, zUzu, V36 ? charn_coare3p6(zUzu) : charn_coare3p0(zUzu),
@@ -592,7 +600,12 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
                 R zQns, zTau, zQlat;
                 update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
                                  zQlat);                               // :367-368
+                if (parked) {
+                    wl[1] = park[0]; wl[2] = park[pstride]; wl[3] = park[2 * pstride];
+                    wc.zcd1 = park[5 * pstride]; wc.zcd2 = park[6 * pstride];
+                }
                 wl_coare(wl, wc, in.qsw, zQns, zTau, true);            // :370
+                if (parked) { park[0] = wl[1]; park[pstride] = wl[2]; park[2 * pstride] = wl[3]; }
             }
             T_s = xSST + wl[0];
             if (CS) T_s = T_s + zdT_cs;                                // :373-374
@@ -603,6 +616,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             zdq = sfloor(q_zu - q_s, R(1.E-12));
         }
     }
+    if (parked) { wl[1] = park[0]; wl[2] = park[pstride]; wl[3] = park[2 * pstride]; }
     const R ztmp0 = M::div(zus, Ubzu);                                 // :386-389
     o.Cd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);
     o.Ch = vmax(M::div(ztmp0 * zts, zdt), K<R>::Cx_min);

@@ -65,6 +65,7 @@ __device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, const Heights<R>
 template <class R, int ALGO, int SKIN>
 __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const TurbArgs<R> a)
 {
+    math_tables_init<R>();
     constexpr bool ANYSKIN = SKIN != 0;
     if (ALGO == 3) {
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -206,6 +207,7 @@ template <class R> static hipError_t launch_r(const TurbCall &c, hipStream_t s)
 template <class R, int ALGO>
 __global__ void __launch_bounds__(kBlock) neutral10_kernel(const R *U_N10, R *CdN10, R *ChN10, R *CeN10, R *pz0, long n, int nb_iter)
 {
+    math_tables_init<R>();
     using M = Mth<R>;
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
