@@ -152,9 +152,17 @@ template <int N> AB_FM double horner_coefs(const double *g, double x)
     return p;
 }
 #endif
-AB_TAB double kExpP[ab_pad4(10)] = {0.5000000000000001, 0.16666666666666669, 0.041666666666624164, 0.008333333333330065,
-                           0.0013888888917196719, 0.00019841269863040545, 2.4801521322368692e-05,
-                           2.7557268480310024e-06, 2.7620075879983367e-07, 2.5100375832561234e-08};
+// T[j] = 2^(j/32) of qexp (tools/gen_exptab.py)
+constexpr int kExpN = 32;
+AB_TAB double kExpTab[kExpN] = {
+    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
+    1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775,
+    1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
+    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
+    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228,
+    1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
+    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072,
+    1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
 AB_TAB double kAtanP[ab_pad4(11)] = {-0.3333333333333333, 0.1999999999999552, -0.14285714284666542, 0.11111111015256361,
                             -0.09090904578123903, 0.07692183190826087, -0.06664511447381948, 0.0585814891280221,
                             -0.0508544973794026, 0.03923165829558719, -0.01917688711906226};
@@ -224,10 +232,12 @@ AB_TAB double kLogQ[ab_pad4(6)] = {-0.5000000000000073, 0.33333333333333987, -0.
                           -0.16668981738710087, 0.14287772132727572};
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
 static __shared__ __attribute__((aligned(16))) double s_logtab[2 * kLogN];
+static __shared__ double s_exptab[kExpN];
 // every kernel that may evaluate a log calls this first (all threads), then __syncthreads()
 AB_FM void lds_tables_init()
 {
     for (int i = (int)threadIdx.x; i < 2 * kLogN; i += (int)blockDim.x) s_logtab[i] = kLogTab[i];
+    for (int i = (int)threadIdx.x; i < kExpN; i += (int)blockDim.x) s_exptab[i] = kExpTab[i];
 }
 AB_FM double log_invc(int k) { return s_logtab[2 * (k - kLogK0)]; }
 // -DAB_LOG_LATE_LOGC issues the load of logc after the polynomial (the asm ties the address to q) so that the pair does
@@ -261,27 +271,37 @@ AB_FM double qlog(double x)
 AB_FM double qlog10(double x) { return qlog(x) * 0.4342944819032518; }
 
 // ---------------------------------------------------------------- exp
-// exp(r) = 1 + r + r^2 P(r) on |r| <= ln2/2, P degree 9 (truncation 1.6e-17 relative)
-AB_FM double exp_kernel(double r)
+// exp(x) with a 32-entry table (tools/gen_exptab.py):  x = (32 e + j) ln2/32 + r, |r| <= ln2/64:
+//    exp x = 2^e T[j] (1 + r + r^2 P(r)),  T[j] = 2^(j/32),  P degree 4 (2.2e-19 relative) instead of degree 9 on |r| <= ln2/2.
+// T lives in LDS next to the log table (256 B per block, lds_tables_init()); 16 VALU slots instead of 19.
+// Any finite x: the exponent goes through a saturating conversion and ldexp (0 / inf beyond +-745).
+AB_TAB double kExpQ[ab_pad4(5)] = {0.5, 0.16666666666581356, 0.04166666666656003, 0.008333362425171237, 0.0013888925253674421};
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+AB_FM double exp_t(int j) { return s_exptab[j]; }
+#else
+AB_FM double exp_t(int j) { return kExpTab[j]; }
+#endif
+// 2^e T[j] (1 + r + r^2 P(r)) for k = 32 e + j
+AB_FM double exp_finish(double r, int k)
 {
-    const double p = horner_coefs<10>(kExpP, r);
-    return 1.0 + p_fma(r * r, p, r);
+    const double t = exp_t(k & (kExpN - 1));
+    const double q = p_fma(r * r, horner_coefs<5>(kExpQ, r), r);
+    return p_ldexp(p_fma(t, q, t), k >> 5);
 }
-// exp(x), any finite x (saturates to 0 / inf through ldexp)
 AB_FM double qexp(double x)
 {
-    const double k = p_rint(x * 1.4426950408889634);
-    double r = p_fma(-k, 0.6931471803691238, x);        // ln2_hi: 21 trailing zero bits, k*hi exact
-    r = p_fma(-k, 1.9082149292705877e-10, r);           // ln2_lo
-    return p_ldexp(exp_kernel(r), (int)k);
+    const double k = p_rint(x * 46.16624130844683);     // 32/ln2
+    double r = p_fma(-k, 0.021660849393811077, x);      // ln2/32, 30-bit head: k*head exact
+    r = p_fma(-k, -1.312785960212839e-12, r);           // tail
+    return exp_finish(r, (int)k);
 }
 // 10^x
 AB_FM double qexp10(double x)
 {
-    const double k = p_rint(x * 3.321928094887362);
-    double r = p_fma(-k, 0.3010299955494702, x);        // log10(2)_hi (21 trailing zero bits)
-    r = p_fma(-k, 1.1451100898021838e-10, r);           // log10(2)_lo
-    return p_ldexp(exp_kernel(r * 2.302585092994046), (int)k);
+    const double k = p_rint(x * 106.30169903639559);    // 32/log10(2)
+    double r = p_fma(-k, 0.009407187360920943, x);      // log10(2)/32, 30-bit head
+    r = p_fma(-k, 3.5784690306318245e-12, r);           // tail
+    return exp_finish(r * 2.302585092994046, (int)k);
 }
 
 // ---------------------------------------------------------------- atan

@@ -48,7 +48,7 @@ template <class R> struct DiagArgs {
 // loads and stores stay coalesced and each field is still read once and written once.
 // One cell from its pre-processed inputs to the six outputs of aerobulk_compute: TURB_<algo> (mod_aerobulk_compute.f90
 // :129-176), BULK_FORMULA and the stress vector (:184-194).  k: global cell index (warm-layer state, diagnostics, longitude).
-template <class R, int ALGO, bool SKIN, bool DIAG>
+template <class R, int ALGO, bool SKIN, bool DIAG, bool TILED = false>
 __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArgs<R> &dg, const Heights<R> &hh, int nb_iter, long k, R sst,
                                              R theta_zt, R q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
                                              R &zEvap, R &T_s, const volatile R *pu = nullptr, const volatile R *pv = nullptr,
@@ -106,8 +106,13 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
     if (in.wnd > R(1.E-3)) {
         const R s = zTaum / in.wnd;
         // tiled path: u and v are still in the cell's LDS slots; re-reading them here keeps 4 VGPRs free across the iteration
-        tx = s * (pu ? *pu : uu);
-        ty = s * (pv ? *pv : vv);
+        if constexpr (TILED) {
+            tx = s * *pu;
+            ty = s * *pv;
+        } else {
+            tx = s * uu;
+            ty = s * vv;
+        }
     }
     T_s = o.T_s;
 }
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         if (k >= a.n) continue;
 
         R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG>(a, dg, hh, nb_iter, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
+        compute_cell<R, ALGO, SKIN, DIAG, true>(a, dg, hh, nb_iter, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
                                           SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
                                           ty, zEvap, T_s, &s_f[3][j], &s_f[4][j],
                                           // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare

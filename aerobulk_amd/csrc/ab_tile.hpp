@@ -41,7 +41,7 @@ template <class R, int ALGO, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // flux: sst theta q_zt u v slp [qsw rlw] ; turb: 8 / 6 too
     // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) + bucket (1 B) per cell
     static constexpr int kWaves = AB_WAVES_PER_EU * 256 / kBlock;      // resident blocks per CU
-    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 768 : 0);   // 768: fm::s_logtab (752 B)
+    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0);   // 1024: fm::s_logtab (752 B) + fm::s_exptab (256 B)
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;
