@@ -27,7 +27,8 @@ template <class R> struct TurbArgs {
 // One cell of a TURB_* call: returns the eight values that go back to the caller's arrays (Cd Ch Ce t_zu q_zu Ubzu T_s q_s);
 // the OPTIONAL outputs and the warm-layer state are written straight to global memory at cell k.
 template <class R, int ALGO, int SKIN>
-__device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, const Heights<R> &hh, int nb_iter, long k, const CellIn<R> &in, R (&res)[8])
+__device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, const Heights<R> &hh, int nb_iter, long k, const CellIn<R> &in, R (&res)[8],
+                                          volatile R *park = nullptr, int pstride = 0)
 {
     constexpr bool WL = (SKIN & kSkinWL) != 0;
     R wl[4] = {R(0.), R(0.), R(0.), R(0.)};
@@ -43,8 +44,8 @@ __device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, const Heights<R>
         if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>(a.lon[k], a.isecday) : (a.dawn_uniform != 0);
     }
     CellOut<R> o;
-    if (ALGO == 1) turb_coare<R, false, SKIN, true>(hh, in, nb_iter, wl, dawn, o);
-    else if (ALGO == 2) turb_coare<R, true, SKIN, true>(hh, in, nb_iter, wl, dawn, o);
+    if (ALGO == 1) turb_coare<R, false, SKIN, true>(hh, in, nb_iter, wl, dawn, o, park, pstride);
+    else if (ALGO == 2) turb_coare<R, true, SKIN, true>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 3) turb_ncar<R, true>(hh, in, nb_iter, o);
     else if (ALGO == 4) turb_ecmwf<R, SKIN, true>(hh, in, nb_iter, wl, o);
     else turb_andreas<R, true>(hh, in, nb_iter, o);
@@ -139,7 +140,8 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const Tur
         in.qsw = ANYSKIN ? s_f[ANYSKIN ? 6 : 0][j] : R(0.);
         in.rlw = ANYSKIN ? s_f[ANYSKIN ? 7 : 0][j] : R(0.);
         R res[8];
-        turb_cell<R, ALGO, SKIN>(a, hh, nb_iter, k, in, res);
+        // the cell's inputs are in registers now: its tile slots serve turb_coare as scratch words (ab_physics.hpp)
+        turb_cell<R, ALGO, SKIN>(a, hh, nb_iter, k, in, res, ((SKIN & kSkinWL) && sizeof(R) == 8) ? &s_f[0][j] : nullptr, T::kCells);
 #pragma unroll
         for (int i = 0; i < (ANYSKIN ? 8 : 6); ++i) s_f[i][j] = res[i];    // the slot is read by this lane only: reuse it
     }
