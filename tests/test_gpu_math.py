@@ -33,6 +33,8 @@ N = 2_000_000
 CASES = [  # (op, sampler, reference(longdouble), max ulp)
     ("log", lambda: np.exp(RNG.uniform(-60, 60, N)), np.log, 2.5),
     ("log", lambda: RNG.uniform(0.5, 2.0, N), np.log, 2.5),
+    ("log", lambda: 1.0 + RNG.uniform(-8e-3, 8e-3, N), np.log, 2.5),        # the table bin around 1 (c = 1, log c = 0 exactly)
+    ("log", lambda: 1.0 + RNG.uniform(-1e-9, 1e-9, N), np.log, 2.5),        # results of 1e-9 and below: relative accuracy kept
     ("log10", lambda: np.exp(RNG.uniform(-30, 15, N)), np.log10, 4.0),
     ("exp", lambda: RNG.uniform(-700, 700, N), np.exp, 1.5),
     ("exp", lambda: RNG.uniform(-3, 3, N), np.exp, 1.5),
