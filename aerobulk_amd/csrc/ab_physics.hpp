@@ -192,17 +192,30 @@ __device__ __forceinline__ void bulk_formula(R pzu, R pts, R pqs, R pThta, R pqa
     pQsen = zUrho * pCh * (pThta - pts) * (K<R>::rCp_dry + K<R>::rCp_vap * pqa);
     pQlat = (R(2.501) - R(0.00237) * (pts - K<R>::rt0)) * R(1.e6) * pEvap;  // L_vap :590
 }
-// UPDATE_QNSOL_TAU_SCLR :1059-1103 (+ qlw_net_sclr :1291-1314)
+// UPDATE_QNSOL_TAU_SCLR :1059-1103 (+ qlw_net_sclr :1291-1314).  The routine forms Ch = (u*/Ub) theta*/zdt and Ce = (u*/Ub) q*/zdq
+// with zdt, zdq the floored air-sea differences (:1076-1077) and hands them to BULK_FORMULA, which multiplies them by the
+// unfloored differences again (:1190-1191): Ch (theta - T_s) = (u*/Ub) theta* exactly unless |theta - T_s| < 1e-9 (likewise q
+// with 1e-12).  The two divisions are therefore only executed on those (rare) lanes.
 template <class R>
 __device__ __forceinline__ void update_qnsol_tau(R pzu, R pts, R pqs, R pThta, R pqa, R pust, R ptst, R pqst,
                                                  R pwnd, R pUb, R pslp, R prlw, R &pQns, R &pTau, R &pQlat)
 {
-    const R zdt = sfloor(pThta - pts, R(1.E-09));
-    const R zdq = sfloor(pqa - pqs, R(1.E-12));
-    const R zz0 = Mth<R>::div(pust, pUb);
-    R zQsen, zEvap;
-    bulk_formula(pzu, pts, pqs, pThta, pqa, zz0 * zz0, Mth<R>::div(zz0 * ptst, zdt), Mth<R>::div(zz0 * pqst, zdq), pwnd,
-                 pUb, pslp, pTau, zQsen, pQlat, zEvap);
+    using M = Mth<R>;
+    const R dth = pThta - pts, dq = pqa - pqs;
+    const R zz0 = M::div(pust, pUb);
+    R chdt = zz0 * ptst, cedq = zz0 * pqst;                        // Ch (theta - T_s), Ce (q - q_s)
+    if (M::abs(dth) < R(1.E-09)) chdt = M::div(chdt, sfloor(dth, R(1.E-09))) * dth;
+    if (M::abs(dq) < R(1.E-12)) cedq = M::div(cedq, sfloor(dq, R(1.E-12))) * dq;
+    // BULK_FORMULA_SCLR :1149-1203 with those products (see bulk_formula above)
+    const R zta = pThta - K<R>::rgamma_dry * pzu;
+    const R zir = M::rcp(K<R>::R_dry * zta * (R(1.) + K<R>::rctv0 * pqa));
+    R zrho = vmax(pslp * zir, R(0.8));
+    zrho = vmax((pslp - zrho * K<R>::grav * pzu) * zir, R(0.8));
+    const R zUrho = pUb * vmax(zrho, R(1.));
+    pTau = zUrho * (zz0 * zz0) * pwnd;
+    const R zEvap = zUrho * cedq;
+    const R zQsen = zUrho * chdt * (K<R>::rCp_dry + K<R>::rCp_vap * pqa);
+    pQlat = (R(2.501) - R(0.00237) * (pts - K<R>::rt0)) * R(1.e6) * zEvap;  // L_vap :590
     const R zt2 = pts * pts;
     pQns = pQlat + zQsen + K<R>::emiss_w * (prlw - K<R>::stefan * zt2 * zt2);
 }
@@ -228,12 +241,18 @@ template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R 
     const R ztmp = K<R>::rnu0_w * ziu;
     const R zql = COARE ? M::div(R(0.026) * vmin(pQlat, R(0.)) * R(4190. / 2.46e+6), palpha) : R(0.);
     const R zdwarm = vmin(R(6.) * ztmp, R(0.007));
+    const R ziz6 = zusw * R(1. / (6. * 1.e-6));                     // 1/(6 nu/u*w), K<R>::rnu0_w = 1e-6
+    // delta and, for the absorption profile below, 1/delta = (1 + x^0.75)^(1/3) / (6 nu/u*w) = y rcbrt(y)^2 u*w/(6 nu): no division
+    R zidelta;
     auto delta = [&](R pQd) -> R {
         const R zQd = pQd + zql;
-        if (nonneg(zQd)) return zdwarm;                       // warming of the viscous layer (rare)
+        if (nonneg(zQd)) { zidelta = M::rcp(zdwarm); return zdwarm; }   // warming of the viscous layer (rare)
         const R x = vmax(zA * zQd, R(1.E-280));                     // floor 0 -> tiny: 1 + x^0.75 is unchanged
         const R sx = M::sqrt_pos(x);
-        return R(6.) * M::rcbrt(R(1.) + sx * M::sqrt_pos(sx)) * ztmp;  // 6 (1 + x^0.75)^(-1/3) nu/u*w
+        const R y = R(1.) + sx * M::sqrt_pos(sx);
+        const R rc = M::rcbrt(y);
+        zidelta = (y * rc) * (rc * ziz6);
+        return R(6.) * rc * ztmp;                                   // 6 (1 + x^0.75)^(-1/3) nu/u*w
     };
     R zQabs = pQnsol;
     R zdelta = delta(zQabs);
@@ -241,7 +260,7 @@ template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R 
     if (pQsw != R(0.))
 #pragma unroll 1
     for (int jc = 0; jc < 4; ++jc) {
-        const R zfr = vmax(c0 + R(11.) * zdelta - M::div(R(6.6E-5), zdelta) * (R(1.) - M::exp(zdelta * R(-1. / 8.E-4))), R(0.01));
+        const R zfr = vmax(c0 + R(11.) * zdelta - (R(6.6E-5) * zidelta) * (R(1.) - M::exp(zdelta * R(-1. / 8.E-4))), R(0.01));
         zQabs = pQnsol + zfr * pQsw;
         zdelta = delta(zQabs);
     }
