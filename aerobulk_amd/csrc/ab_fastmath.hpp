@@ -8,8 +8,11 @@
 // arguments and needs ~1e-15 relative accuracy (parity bar: 1e-10 on the fluxes), so each function
 // below is: hardware seed (v_rcp_f64 / v_rsq_f64 / v_log_f32+v_exp_f32) or frexp range reduction,
 // one Newton/Halley step, a near-minimax polynomial (tools/gen_poly.py, 60-digit Chebyshev fits;
-// truncation errors quoted per table) evaluated with FMAs.  Measured accuracy on the MI355X:
-// tests/test_gpu_math.py (max error in ulp vs 50-digit references).
+// truncation errors quoted per table) evaluated with FMAs.  log and exp, the two most frequent, are
+// table-driven (tools/gen_logtab.py, tools/gen_exptab.py): 1 008 B of tables per block in LDS, one
+// ds_read per call, no division in log (an fp64 v_rcp/v_rsq/v_sqrt issues at a quarter of the FMA
+// rate, profiles/r1_instr_rates.txt).  Measured accuracy on the MI355X: tests/test_gpu_math.py (max
+// error in ulp vs 80-bit references).
 //
 // The same source compiles for the host (AB_FASTMATH_HOST: seeds emulated with float-rounded
 // values) so that tests/test_fastmath_host.py can check the algorithms without a GPU.
