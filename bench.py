@@ -45,6 +45,11 @@ def committed_pmc(algo, skin, ni, nj, niter, precision):
     return None
 
 
+def fp64_flops(pmc):
+    f = pmc["fp64_insts_per_launch"]
+    return 64.0 * (2.0 * f["fma"] + f["mul"] + f["add"] + f["trans"])
+
+
 def shard_rows(nj, world, rank):
     """Contiguous j-blocks: every rank owns ceil(nj/world) rows except possibly the last ones."""
     per = -(-nj // world)
@@ -364,6 +369,10 @@ def main():
                          "binding_resource": "fp64 VALU issue" if a.precision == "f64" else "fp32 VALU issue",
                          "valu_busy": round(pmc["valu_busy"], 3) if pmc else None,
                          "valu_insts_per_cell": round(pmc["valu_insts_per_cell"]) if pmc else None,
+                         # fp64 arithmetic actually issued (PMC wave-instruction counts x 64 lanes, an FMA = 2 flops) over the
+                         # live kernel time, against the fp64 vector peak (MI355X_MICROARCH.md: 78.6 TFLOP/s)
+                         "fp64_tflops": round(fp64_flops(pmc) / (k_ms * 1e-3) / 1e12, 2) if (pmc and k_ms > 0) else None,
+                         "fp64_vector_peak_tflops": 78.6,
                          "note": "the kernel is VALU-bound (hundreds of fp64 transcendentals per cell), not HBM-bound; traffic/valu_* are "
                                  "rocprofv3 PMC figures of the committed profile of this same command (profiles/), DESIGN.md §3.1"},
         }
