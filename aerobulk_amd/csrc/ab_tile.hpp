@@ -177,6 +177,9 @@ static inline long resident_block_slots()
 static inline int tile_rounds(long n, int max_rounds)
 {
     long rounds = n / ((long)kBlock * resident_block_slots());
+#ifdef AB_FORCE_ROUNDS
+    rounds = AB_FORCE_ROUNDS;
+#endif
     return (int)(rounds < 1 ? 1 : (rounds > max_rounds ? max_rounds : rounds));
 }
 
