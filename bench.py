@@ -129,6 +129,8 @@ def main():
                     help="N>1 with the gather: rows owned by each of the ranks 1..N-1 (rank 0, the gather's destination, owns the "
                          "rest).  0 = measured: link rate and kernel rate are timed during set-up and the split balances rank 0's "
                          "compute against its peers' compute + transfer; -1 = equal split")
+    ap.add_argument("--no-early-gather", action="store_true", help="N>1, RCCL: rank 0 joins the gather of chunk c after computing its "
+                                                                    "own chunk c (instead of before)")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row sub-blocks per rank (gather of one overlaps compute of the next)")
     a = ap.parse_args()
 
@@ -248,14 +250,22 @@ def main():
         out = {k: outbuf[c, i, :rows * ni] for i, k in enumerate(names)}
         work.append((sess, ins, rad, out))
 
+    # Rank 0 contributes nothing to the gather (its rows stay where they are) but is the destination of every peer, and it owns
+    # the largest block.  With RCCL it therefore joins the gather of chunk c BEFORE computing its own chunk c (the collective
+    # then only waits for rank 0's chunk c-1): a peer's chunk lands while rank 0 is still computing, and the last gather of a
+    # step overlaps rank 0's last chunk instead of following it.
+    early = gathered and rank == 0 and a.backend == "nccl" and not a.no_early_gather
+
     def step():
         pending = []
         for c in range(chunks):
+            if early:
+                pending.append(dist.gather(send0, gather_lists[c], dst=0, async_op=True))
             w = work[c]
             if w is not None:
                 sess, ins, rad, out = w
                 sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
-            if gathered:
+            if gathered and not early:
                 payload = send0 if rank == 0 else outbuf[c, :ngat]
                 if a.backend == "nccl":
                     pending.append(dist.gather(payload, gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
