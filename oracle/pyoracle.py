@@ -43,15 +43,22 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
-_lib = None
+_libs = {}
+ORACLE_FMA_SO = os.path.join(HERE, "liboracle_fma.so")   # the same C file compiled with FMA contraction: conditioning probe
 
 
-def lib():
-    global _lib
+def ref_variant_so(variant):
+    """oracle/_ref/var_<variant>/libaerobulk_ref.so: the reference under another of its own arch/ flag sets (oracle/Makefile)."""
+    return REF_SO if variant in (None, "O2") else os.path.join(HERE, "_ref", "var_" + variant, "libaerobulk_ref.so")
+
+
+def lib(variant=None):
+    so = ORACLE_SO if variant is None else os.path.join(HERE, f"liboracle_{variant}.so")
+    _lib = _libs.get(so)
     if _lib is None:
-        if not os.path.exists(ORACLE_SO):
-            raise RuntimeError(f"{ORACLE_SO} missing: run `make -C oracle` (or __graft_entry__.build())")
-        L = C.CDLL(ORACLE_SO)
+        if not os.path.exists(so):
+            raise RuntimeError(f"{so} missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(so)
         L.abo_compute.restype = C.c_int
         L.abo_compute.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, C.c_double, C.c_double, C.c_int,
                                   C.c_int, C.c_int] + [_dp] * 8 + [_dp] * 6 + [_dp, C.c_int, _dp]
@@ -91,7 +98,7 @@ def lib():
         L.abo_z0tq_lkb.argtypes = [C.c_int, C.c_double, C.c_double]
         L.abo_delta_skin_layer.restype = C.c_double
         L.abo_delta_skin_layer.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
-        _lib = L
+        _lib = _libs[so] = L
     return _lib
 
 
@@ -109,9 +116,10 @@ def synth_fields(ni, nj, j0=0, nj_local=None):
 class OracleSession:
     """CPU oracle counterpart of one aerobulk_model() time loop (jt = 1..nt)."""
 
-    def __init__(self, algo, n, nt=1, use_skin=False, hum_type="sh"):
+    def __init__(self, algo, n, nt=1, use_skin=False, hum_type="sh", variant=None):
         self.algo, self.n, self.nt, self.use_skin = algo, int(n), int(nt), bool(use_skin)
         self.hum_type = hum_type
+        self.variant = variant        # None: the pinned oracle; "fma": the same source with contracted a*b+c
         self.wl = np.zeros(4 * self.n)
 
     def compute(self, jt, zt, zu, niter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw=None, rad_lw=None,
@@ -119,7 +127,7 @@ class OracleSession:
         n = self.n
         o = {k: np.empty(n) for k in ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")}
         d = np.empty(16 * n) if diag else None
-        rc = lib().abo_compute_diag(ALGOS[self.algo], jt, self.nt, n, zt, zu, niter, int(self.use_skin),
+        rc = lib(self.variant).abo_compute_diag(ALGOS[self.algo], jt, self.nt, n, zt, zu, niter, int(self.use_skin),
                                     HUM[self.hum_type], _p(sst), _p(t_zt), _p(hum_zt), _p(u_zu), _p(v_zu), _p(slp),
                                     _p(rad_sw), _p(rad_lw), _p(o["ql"]), _p(o["qh"]), _p(o["tau_x"]), _p(o["tau_y"]),
                                     _p(o["evap"]), _p(o["t_s"]), _p(self.wl), isecday_utc, _p(lon), _p(d))
@@ -176,7 +184,7 @@ pickle.dump(res, open(fout, "wb"))
 """
 
 
-def run_reference(algo, records, zt, zu, niter, use_skin=False, with_rad=None, timeout=3600):
+def run_reference(algo, records, zt, zu, niter, use_skin=False, with_rad=None, timeout=3600, variant=None):
     """Run aerobulk_model(jt=1..nt) of the UNMODIFIED reference (through its own C entry points
     aerobulk_cxx_skin / aerobulk_cxx_no_skin, src/mod_aerobulk_cxx.f90:29-95) in a fresh process.
     `records` is a list (one per time record) of dicts of flat float64 arrays.
@@ -192,7 +200,7 @@ def run_reference(algo, records, zt, zu, niter, use_skin=False, with_rad=None, t
         fin, fout = os.path.join(td, "in.pkl"), os.path.join(td, "out.pkl")
         with open(fin, "wb") as fh:
             pickle.dump(case, fh)
-        pr = subprocess.run([sys.executable, "-c", _CHILD, REF_SO, fin, fout], capture_output=True, text=True,
+        pr = subprocess.run([sys.executable, "-c", _CHILD, ref_variant_so(variant), fin, fout], capture_output=True, text=True,
                             timeout=timeout)
         if not os.path.exists(fout):
             raise RuntimeError("reference aborted (STOP):\n" + pr.stdout[-2000:] + pr.stderr[-2000:])

@@ -1,9 +1,12 @@
 """Randomised parity: inputs drawn over the whole range AEROBULK_INIT accepts (mod_const.f90:138-146), including calm, very
-stable and very unstable cells, winds of 50 m/s, zt = zu and odd heights; HIP (regrouped tiles) against the oracle."""
+stable and very unstable cells, winds of 40 m/s, zt = zu and odd heights; HIP (regrouped tiles) against the oracle, twelve seeds,
+three consecutive records with the warm-layer state carried for the skin configurations.  Metric: oracle/parity.py — every value
+within 1e-10 (floor 1e-6 of the field maximum) or within 4 ulp of backward error (near-calm, strongly stable cells where the
+iteration runs on its clamps: the reference moves as much when one input moves by one ulp, profiles/r2_illcond_study.txt)."""
 import numpy as np
 import pytest
 
-from conftest import assert_parity
+from conftest import assert_hot_parity, sensitivity
 
 pytestmark = pytest.mark.gpu
 OUT = (("QL", "ql"), ("QH", "qh"), ("Tau_x", "tau_x"), ("Tau_y", "tau_y"), ("Evap", "evap"), ("T_s", "t_s"))
@@ -24,24 +27,36 @@ def _fields(seed, n):
                 rad_sw=np.where(r.uniform(size=n) < 0.3, 0.0, r.uniform(0.0, 1100.0, n)), rad_lw=r.uniform(150.0, 480.0, n))
 
 
-@pytest.mark.parametrize("seed", [11, 23])
+SEEDS = list(range(100, 112))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 @pytest.mark.parametrize("algo,skin,zt,zu,niter", [("coare3p6", True, 2.0, 10.0, 5), ("coare3p6", False, 10.0, 10.0, 8),
                                                     ("coare3p0", True, 3.5, 17.0, 4), ("ecmwf", True, 2.0, 10.0, 6),
                                                     ("ecmwf", False, 2.0, 10.0, 5), ("ncar", False, 2.0, 10.0, 5),
                                                     ("andreas", False, 8.0, 12.0, 7)])
 def test_random_inputs_match_oracle(oracle, seed, algo, skin, zt, zu, niter):
     import aerobulk_amd as ab
-    n = 40000 + 13 * seed                                  # ragged: not a multiple of any tile size
+    n = 60000 + 13 * seed                                  # ragged: not a multiple of any tile size
     f = _fields(seed, n)
+    if seed % 2:                                           # odd seeds: winds kept below the 10 N/m2 abort so that all records complete
+        keep = np.hypot(f["u_zu"], f["v_zu"]) < 30.0
+        f = {k: np.ascontiguousarray(v[keep]) for k, v in f.items()}
+        n = int(keep.sum())
+    nt = 3 if skin else 1
     ins = [f[k] for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")]
-    ref = oracle.OracleSession(algo, n, 1, skin).compute(1, zt, zu, niter, *ins, rad_sw=f["rad_sw"] if skin else None,
-                                                         rad_lw=f["rad_lw"] if skin else None)
-    try:
-        with ab.Session(algo, n, 1, 1, skin) as s:
-            got = s.compute(1, zt, zu, *ins, Niter=niter, rad_sw=f["rad_sw"] if skin else None, rad_lw=f["rad_lw"] if skin else None)
-    except ab.AerobulkError as e:                         # 40 m/s over a very unstable cell may exceed 10 N/m2: both must agree
-        assert e.status == 8 and ref["rc"] == 1, (e, ref["rc"])
-        return
-    assert ref["rc"] == 0
+    rad = dict(rad_sw=f["rad_sw"] if skin else None, rad_lw=f["rad_lw"] if skin else None)
+    osess = oracle.OracleSession(algo, n, nt, skin)
+    sens = sensitivity(oracle, algo, skin, zt, zu, niter, f, nt=nt)
     keys = OUT if skin else OUT[:5]
-    assert_parity({kr: got[k] for k, kr in keys}, ref, [kr for _, kr in keys], label=f"fuzz {algo} skin={skin} seed={seed}")
+    with ab.Session(algo, n, 1, nt, skin) as s:
+        for jt in range(1, nt + 1):
+            ref = osess.compute(jt, zt, zu, niter, *ins, **rad)
+            try:
+                got = s.compute(jt, zt, zu, *ins, Niter=niter, **rad)
+            except ab.AerobulkError as e:                 # 40 m/s over a very unstable cell may exceed 10 N/m2: both must agree
+                assert e.status == 8 and ref["rc"] == 1, (e, ref["rc"])
+                return
+            assert ref["rc"] == 0
+            assert_hot_parity({kr: got[k] for k, kr in keys}, ref, [kr for _, kr in keys], sens=sens, jt=jt,
+                              label=f"fuzz {algo} skin={skin} seed={seed} jt={jt}")

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, assert_parity, load_golden_case, load_manifest
+from conftest import GOLDEN, assert_hot_parity, load_golden_case, load_manifest, sensitivity
 
 pytestmark = pytest.mark.gpu
 IN6 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")
@@ -15,10 +15,12 @@ CAP = {"ql": "QL", "qh": "QH", "tau_x": "Tau_x", "tau_y": "Tau_y", "evap": "Evap
 
 
 @pytest.mark.parametrize("case", load_manifest(), ids=lambda c: c["name"])
-def test_hip_matches_reference_golden(case):
+def test_hip_matches_reference_golden(case, oracle):
     import aerobulk_amd as ab
     inp, recs, keys = load_golden_case(case)
     n = inp["sst"].size
+    sens = sensitivity(oracle, case["algo"], case["skin"], case["zt"], case["zu"], case["niter"], inp, nt=case["nt"],
+                       hum_type=case["hum_type"])
     with ab.Session(case["algo"], n, 1, case["nt"], case["skin"]) as s:
         rep = s.init(*[inp[k] for k in IN6], rad_sw=inp["rad_lw"] if case["skin"] else None,
                      rad_lw=inp["rad_lw"] if case["skin"] else None)
@@ -27,7 +29,7 @@ def test_hip_matches_reference_golden(case):
             got = s.compute(jt, case["zt"], case["zu"], *[inp[k] for k in IN6], Niter=case["niter"],
                             rad_sw=inp["rad_sw"] if case["skin"] else None, rad_lw=inp["rad_lw"] if case["skin"] else None)
             got = {k: got[CAP[k]] for k in keys}
-            assert_parity(got, ref, keys, label=f"{case['name']} jt={jt}")
+            assert_hot_parity(got, ref, keys, sens=sens, jt=jt, label=f"{case['name']} jt={jt}")
 
 
 def test_hip_reproduces_17_digit_pins():

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, assert_parity
+from conftest import GOLDEN, ROOT, assert_hot_parity, sensitivity
 
 pytestmark = pytest.mark.gpu
 IN6 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")
@@ -88,17 +88,19 @@ def test_python_aerobulk_model_protocol(oracle):
     assert r1["init_report"]["hum_type"] == "sh" and r1["init_report"]["n_masked"] == 0
     r2 = ab.aerobulk_model(2, 2, "coare3p6", 2.0, 10.0, *args, l_use_skin=True, rad_sw=F["rad_sw"], rad_lw=F["rad_lw"])  # Niter sticky
     s = oracle.OracleSession("coare3p6", ni * nj, 2, True)
+    sens = sensitivity(oracle, "coare3p6", True, 2.0, 10.0, 6, f, nt=2)
     for jt, r in ((1, r1), (2, r2)):
         o = s.compute(jt, 2.0, 10.0, 6, *[f[k] for k in IN6], rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
         got = {k: r[c].ravel(order="F") for k, c in (("ql", "QL"), ("qh", "QH"), ("tau_x", "Tau_x"), ("tau_y", "Tau_y"),
                                                       ("evap", "Evap"), ("t_s", "T_s"))}
         assert r["QL"].shape == (ni, nj)
-        assert_parity(got, o, ("ql", "qh", "tau_x", "tau_y", "evap", "t_s"), label=f"model jt={jt}")
+        assert_hot_parity(got, o, ("ql", "qh", "tau_x", "tau_y", "evap", "t_s"), sens=sens, jt=jt, label=f"model jt={jt}")
     # radiation given but no skin: T_s is returned and equals sst
     r = ab.aerobulk_model(1, 1, "ecmwf", 2.0, 10.0, *args, Niter=5, rad_sw=F["rad_sw"], rad_lw=F["rad_lw"])
     np.testing.assert_array_equal(r["T_s"], F["sst"])
     o = oracle.OracleSession("ecmwf", ni * nj).compute(1, 2.0, 10.0, 5, *[f[k] for k in IN6])
-    assert_parity({"ql": r["QL"].ravel(order="F")}, o, ("ql",), label="ecmwf no skin w/ rad")
+    assert_hot_parity({"ql": r["QL"].ravel(order="F")}, o, ("ql",), sens=sensitivity(oracle, "ecmwf", False, 2.0, 10.0, 5, f),
+                      label="ecmwf no skin w/ rad")
 
 
 def test_init_checks_on_gpu_match_reference_conditions(oracle):
