@@ -26,6 +26,11 @@
 #include <cstdint>
 #include <cstring>
 #define AB_FM inline
+#ifndef __HIPCC__   // plain C++ compiler (tests/fastmath_host.cpp, tools/costmodel.cpp): the HIP function attributes mean nothing
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#endif
 #endif
 
 namespace ab {
@@ -48,6 +53,9 @@ AB_FM float p_log2f(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f
 AB_FM float p_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }    // v_exp_f32
 AB_FM double p_abs(double x) { return __builtin_fabs(x); }
 AB_FM double p_copysign(double a, double b) { return __builtin_copysign(a, b); }
+AB_FM float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }       // v_rcp_f32
+AB_FM float f_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }     // v_sqrt_f32
+AB_FM float f_rsq(float x) { return __builtin_amdgcn_rsqf(x); }       // v_rsq_f32
 #else
 AB_FM double p_rcp(double x) { return (1.0 / x) * (1.0 + 1.2e-7); }   // deliberately float-grade (2^-23)
 AB_FM double p_rsq(double x) { return (1.0 / std::sqrt(x)) * (1.0 - 1.2e-7); }
@@ -61,6 +69,9 @@ AB_FM float p_log2f(float x) { return std::log2(x) * (1.0f + 1e-7f); }
 AB_FM float p_exp2f(float x) { return std::exp2(x) * (1.0f - 1e-7f); }
 AB_FM double p_abs(double x) { return std::fabs(x); }
 AB_FM double p_copysign(double a, double b) { return std::copysign(a, b); }
+AB_FM float f_rcp(float x) { return 1.0f / x; }
+AB_FM float f_sqrt(float x) { return std::sqrt(x); }
+AB_FM float f_rsq(float x) { return 1.0f / std::sqrt(x); }
 #endif
 
 // Polynomial coefficient tables.  On the device they live in constant memory (64-byte aligned, padded to a multiple of 4
@@ -179,20 +190,23 @@ AB_FM double qdiv(double a, double b)
     const double q = a * r;
     return p_fma(p_fma(-b, q, a), r, q);
 }
+// 1/b: rcp seed r0 = (1 - e)/b with |e| <= 2^-22, then ONE cubic step r0 (1 + e + e^2) = (1 - e^3)/b: three FMA-class operations
+// instead of the four of two Newton steps; the only rounding that matters is the last FMA's (<= 0.5 ulp + 2^-66).
 AB_FM double qrcp(double b)
 {
-    double r = p_rcp(b);
-    r = p_fma(p_fma(-b, r, 1.0), r, r);
-    return p_fma(p_fma(-b, r, 1.0), r, r);
+    const double r = p_rcp(b);
+    const double e = p_fma(-b, r, 1.0);
+    return p_fma(r, p_fma(e, e, e), r);
 }
-// sqrt(x), x > 0 strictly (normal): Goldschmidt-coupled step + residual correction
+// sqrt(x), x > 0 strictly (normal): g0 = x y, y = rsq(x) (2^-23); two residual corrections g += (x - g^2) (y/2).  The half
+// reciprocal root is never refined: it only multiplies residuals (2^-23, then 2^-45 relative), so its own 2^-23 error enters at
+// 2^-46 and 2^-68.  Six FMA-class operations after the seed (was seven with the coupled Goldschmidt update), <= 0.5 ulp + 2^-67.
 AB_FM double qsqrt_pos(double x)
 {
     const double y = p_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double r = p_fma(-h, g, 0.5);
-    g = p_fma(g, r, g);
-    h = p_fma(h, r, h);
+    double g = x * y;
+    const double h = 0.5 * y;
+    g = p_fma(p_fma(-g, g, x), h, g);
     return p_fma(p_fma(-g, g, x), h, g);
 }
 AB_FM double qsqrt(double x) { return x > 0.0 ? qsqrt_pos(x) : (x == 0.0 ? 0.0 : __builtin_nan("")); }
@@ -349,6 +363,16 @@ AB_FM double qrcbrt_mid(double x)
     const double r = (double)p_exp2f(p_log2f((float)x) * -0.33333334f);
     const double h = p_fma(-(x * (r * r)), r, 1.0);      // 1 - x r^3
     return p_fma(r * h, p_fma(h, 0.2222222222222222, 0.3333333333333333), r);
+}
+// x^(-1/4) for x in [2^-100, 2^100] (float range): fp32 log2/exp2 seed u (relative error d <= ~1e-6), one cubic step on
+// h = 1 - x u^4 (= 4 d): u (1 + h/4 + 5 h^2/32), truncation 15/128 h^3 < 1e-17.  13.5 issue slots; x^0.75 = x * that, where two
+// square roots cost 20.
+AB_FM double qrqrt_mid(double x)
+{
+    const double u = (double)p_exp2f(p_log2f((float)x) * -0.25f);
+    const double u2 = u * u;
+    const double h = p_fma(-x, u2 * u2, 1.0);
+    return p_fma(u * h, p_fma(h, 0.15625, 0.25), u);
 }
 // cbrt(x), x >= 0.  Arguments below 2^-100 return 0 (callers add the square of it to O(1) terms).
 AB_FM double qcbrt(double x)

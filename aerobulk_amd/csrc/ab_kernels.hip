@@ -51,8 +51,8 @@ template <class R> struct DiagArgs {
 template <class R, int ALGO, bool SKIN, bool DIAG, bool TILED = false>
 __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArgs<R> &dg, const Heights<R> &hh, int nb_iter, long k, R sst,
                                              R theta_zt, R q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
-                                             R &zEvap, R &T_s, const volatile R *pu = nullptr, const volatile R *pv = nullptr,
-                                             volatile R *park = nullptr, int pstride = 0)
+                                             R &zEvap, R &T_s, lds_cvptr<R> pu = nullptr, lds_cvptr<R> pv = nullptr,
+                                             lds_vptr<R> park = nullptr, int pstride = 0)
 {
     using M = Mth<R>;
     CellIn<R> in;
@@ -209,9 +209,9 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         R QL, QH, tx, ty, zEvap, T_s;
         compute_cell<R, ALGO, SKIN, DIAG, true>(a, dg, hh, nb_iter, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
                                           SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
-                                          ty, zEvap, T_s, &s_f[3][j], &s_f[4][j],
+                                          ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
                                           // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare
-                                          (SKIN && sizeof(R) == 8) ? &s_f[0][j] : nullptr, T::kCells);
+                                          (SKIN && sizeof(R) == 8) ? (lds_vptr<R>)&s_f[0][j] : (lds_vptr<R>)nullptr, T::kCells);
         // the cell's LDS slot is read by this lane only: reuse it for the results
         s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = T_s;
     }
@@ -443,6 +443,7 @@ __global__ void __launch_bounds__(kBlock) math_test_kernel(int op, const double 
     case 9: r = fm::qrcbrt_mid(a); break;
     case 10: r = e_sat<double>(a); break;
     case 11: r = pow_pos<double>(a, b); break;
+    case 12: r = fm::qrqrt_mid(a); break;
     default: r = 0.; break;
     }
     o[k] = r;

@@ -9,7 +9,9 @@
 // None of this is bit-exact w.r.t. libm; all of it stays far inside the 1e-10 parity bar
 // (measured: tests/test_gpu_math.py, tests/test_gpu_golden.py).
 #pragma once
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "ab_fastmath.hpp"
 
@@ -19,11 +21,24 @@ namespace ab {
 // paths use the hardware transcendentals and need nothing.  Must run before any early return of the kernel.
 template <class R> __device__ __forceinline__ void math_tables_init()
 {
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
     if constexpr (sizeof(R) == 8) {
         fm::lds_tables_init();
         __syncthreads();
     }
+#endif
 }
+
+// Pointers to a lane's own LDS slots, typed with the LDS address space: volatile accesses through a generic pointer stay
+// flat_load/flat_store with a 64-bit address pair each (InferAddressSpaces leaves volatile operations alone); through these
+// they are ds_read/ds_write on one 32-bit base with immediate offsets.
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+template <class R> using lds_vptr = volatile R __attribute__((address_space(3))) *;
+template <class R> using lds_cvptr = const volatile R __attribute__((address_space(3))) *;
+#else
+template <class R> using lds_vptr = volatile R *;
+template <class R> using lds_cvptr = const volatile R *;
+#endif
 
 template <class R> struct Mth;
 
@@ -40,6 +55,7 @@ template <> struct Mth<double> {
     static __device__ __forceinline__ R sqrt_pos(R x) { return fm::qsqrt_pos(x); }  // x > 0 strictly
     static __device__ __forceinline__ R cbrt(R x) { return fm::qcbrt(x); }        // x >= 0
     static __device__ __forceinline__ R rcbrt(R x) { return fm::qrcbrt_mid(x); }  // 2^-100 < x < 2^100
+    static __device__ __forceinline__ R rqrt(R x) { return fm::qrqrt_mid(x); }    // x^(-1/4), 2^-100 < x < 2^100
     static __device__ __forceinline__ R div(R a, R b) { return fm::qdiv(a, b); }
     static __device__ __forceinline__ R rcp(R b) { return fm::qrcp(b); }
     static __device__ __forceinline__ R abs(R x) { return __builtin_fabs(x); }
@@ -51,19 +67,20 @@ template <> struct Mth<double> {
 // v_sqrt_f32, all ~1 ulp) and nothing else — no IEEE division/sqrt fix-up sequences, no library cbrt/atan.
 template <> struct Mth<float> {
     using R = float;
-    static __device__ __forceinline__ R log2(R x) { return __builtin_amdgcn_logf(x); }
-    static __device__ __forceinline__ R exp2(R x) { return __builtin_amdgcn_exp2f(x); }
+    static __device__ __forceinline__ R log2(R x) { return fm::p_log2f(x); }
+    static __device__ __forceinline__ R exp2(R x) { return fm::p_exp2f(x); }
     static __device__ __forceinline__ R log(R x) { return log2(x) * 0.6931471805599453f; }
     static __device__ __forceinline__ R log10(R x) { return log2(x) * 0.3010299956639812f; }
     static __device__ __forceinline__ R exp(R x) { return exp2(x * 1.4426950408889634f); }
     static __device__ __forceinline__ R exp10(R x) { return exp2(x * 3.321928094887362f); }
-    static __device__ __forceinline__ R rcp(R b) { return __builtin_amdgcn_rcpf(b); }
-    static __device__ __forceinline__ R div(R a, R b) { return a * __builtin_amdgcn_rcpf(b); }
-    static __device__ __forceinline__ R sqrt(R x) { return __builtin_amdgcn_sqrtf(x); }
-    static __device__ __forceinline__ R sqrt_pos(R x) { return __builtin_amdgcn_sqrtf(x); }
-    static __device__ __forceinline__ R rsqrt_pos(R x) { return __builtin_amdgcn_rsqf(x); }
+    static __device__ __forceinline__ R rcp(R b) { return fm::f_rcp(b); }
+    static __device__ __forceinline__ R div(R a, R b) { return a * fm::f_rcp(b); }
+    static __device__ __forceinline__ R sqrt(R x) { return fm::f_sqrt(x); }
+    static __device__ __forceinline__ R sqrt_pos(R x) { return fm::f_sqrt(x); }
+    static __device__ __forceinline__ R rsqrt_pos(R x) { return fm::f_rsq(x); }
     static __device__ __forceinline__ R cbrt(R x) { return x > 0.f ? exp2(log2(x) * 0.33333334f) : 0.f; }
     static __device__ __forceinline__ R rcbrt(R x) { return exp2(log2(x) * -0.33333334f); }
+    static __device__ __forceinline__ R rqrt(R x) { return exp2(log2(x) * -0.25f); }
     static __device__ __forceinline__ R abs(R x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ R floor(R x) { return __builtin_floorf(x); }
     static __device__ __forceinline__ R copysign(R a, R b) { return __builtin_copysignf(a, b); }

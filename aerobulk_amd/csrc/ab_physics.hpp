@@ -17,6 +17,11 @@
 #pragma once
 #include "ab_math.hpp"
 
+// code-region marks for the host cost model (tools/costmodel.cpp); nothing in the kernels
+#ifndef AB_REGION
+#define AB_REGION(name)
+#endif
+
 namespace ab {
 
 template <class R> struct K {  // constants, mod_const.f90:38-114
@@ -94,6 +99,7 @@ template <int N> __device__ __forceinline__ float horner_tab(const double *tab, 
 }
 template <class R> __device__ __forceinline__ R e_sat(R pTa)
 {
+    AB_REGION("e_sat");
     using M = Mth<R>;
     const R zta = vmax(pTa, R(180.));
     R e;
@@ -111,6 +117,7 @@ template <class R> __device__ __forceinline__ R e_sat(R pTa)
 // q_sat_sclr :881-904
 template <class R> __device__ __forceinline__ R q_sat(R pTa, R pslp)
 {
+    AB_REGION("q_sat");
     const R ze_s = e_sat(pTa);
     return Mth<R>::div(K<R>::reps0 * ze_s, pslp - K<R>::one_m_reps0 * ze_s);
 }
@@ -163,6 +170,7 @@ template <class R> __device__ __forceinline__ R visc_air(R pTa)
 // One_on_L_sclr :666-693
 template <class R> __device__ __forceinline__ R one_on_l(R pThta, R pqa, R pus, R pts, R pqs)
 {
+    AB_REGION("one_on_l");
     const R zqa = R(1.) + K<R>::rctv0 * pqa;
     const R r = Mth<R>::div(K<R>::grav * K<R>::vkarmn * (pts * zqa + K<R>::rctv0 * pThta * pqs),
                             vmax(pus * pus * pThta * zqa, R(1.E-9)));
@@ -171,6 +179,7 @@ template <class R> __device__ __forceinline__ R one_on_l(R pThta, R pqa, R pus, 
 // Ri_bulk_sclr :712-747 (layer arguments are never passed on this path)
 template <class R> __device__ __forceinline__ R ri_bulk(R pz, R psst, R pThta, R pssq, R pqa, R pub)
 {
+    AB_REGION("ri_bulk");
     const R zsstv = virt_temp(psst, pssq);
     const R zdthv = virt_temp(pThta, pqa) - zsstv;
     const R ztv = R(0.5) * (zsstv + virt_temp(pThta - K<R>::rgamma_dry * pz, pqa));
@@ -200,6 +209,7 @@ template <class R>
 __device__ __forceinline__ void update_qnsol_tau(R pzu, R pts, R pqs, R pThta, R pqa, R pust, R ptst, R pqst,
                                                  R pwnd, R pUb, R pslp, R prlw, R &pQns, R &pTau, R &pQlat)
 {
+    AB_REGION("update_qnsol_tau");
     using M = Mth<R>;
     const R dth = pThta - pts, dq = pqa - pqs;
     const R zz0 = M::div(pust, pUb);
@@ -222,6 +232,7 @@ __device__ __forceinline__ void update_qnsol_tau(R pzu, R pts, R pqs, R pThta, R
 // alpha_sw_sclr :1267-1280
 template <class R> __device__ __forceinline__ R alpha_sw(R psst)
 {
+    AB_REGION("alpha_sw");
     return R(2.1e-5) * pow_pos(vmax(psst - K<R>::rt0 + R(3.2), R(0.)), R(0.79));
 }
 
@@ -231,25 +242,29 @@ template <class R> __device__ __forceinline__ R alpha_sw(R psst)
 // palpha = alpha_sw(SST) is hoisted by the caller.
 template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R pQnsol, R pustar, R palpha, R pQlat)
 {
+    AB_REGION("cool_skin");
     using M = Mth<R>;
     const R c0 = COARE ? R(0.137) : R(0.065);
     // invariants of the five delta evaluations
     const R zusw = vmax(pustar, R(1.E-4)) * K<R>::sq_radrw;
     const R ziu = M::rcp(zusw);
     const R ziu2 = ziu * ziu;
-    const R zA = palpha * K<R>::rcst_cs * (ziu2 * ziu2);
+    // delta_skin_layer_sclr mod_phymbl.f90:2030-2044 forms zQd = Qd + 0.026 MIN(Qlat,0) Cp_w/Lv/alpha and x = alpha rcst_cs/u*w^4 zQd;
+    // here x = (rcst_cs/u*w^4) (alpha Qd + 0.026 MIN(Qlat,0) Cp_w/Lv): the same number without the division (alpha > 0: same sign)
+    const R zB = K<R>::rcst_cs * (ziu2 * ziu2);
     const R ztmp = K<R>::rnu0_w * ziu;
-    const R zql = COARE ? M::div(R(0.026) * vmin(pQlat, R(0.)) * R(4190. / 2.46e+6), palpha) : R(0.);
+    const R zql = COARE ? R(0.026 * 4190. / 2.46e+6) * vmin(pQlat, R(0.)) : R(0.);
     const R zdwarm = vmin(R(6.) * ztmp, R(0.007));
     const R ziz6 = zusw * R(1. / (6. * 1.e-6));                     // 1/(6 nu/u*w), K<R>::rnu0_w = 1e-6
     // delta and, for the absorption profile below, 1/delta = (1 + x^0.75)^(1/3) / (6 nu/u*w) = y rcbrt(y)^2 u*w/(6 nu): no division
     R zidelta;
     auto delta = [&](R pQd) -> R {
-        const R zQd = pQd + zql;
+        const R zQd = palpha * pQd + zql;                           // alpha (Qd + zql/alpha)
         if (nonneg(zQd)) { zidelta = M::rcp(zdwarm); return zdwarm; }   // warming of the viscous layer (rare)
-        const R x = vmax(zA * zQd, R(1.E-280));                     // floor 0 -> tiny: 1 + x^0.75 is unchanged
-        const R sx = M::sqrt_pos(x);
-        const R y = R(1.) + sx * M::sqrt_pos(sx);
+        // x^0.75 = x x^(-1/4), the fourth root from an fp32 seed and one cubic step.  The reference's floor of x at 0 becomes 1e-30
+        // (fp32 range of the seed): below it x^0.75 < 6e-23 and 1 + x^0.75 is 1 either way
+        const R x = vmax(zB * zQd, R(1.E-30));
+        const R y = R(1.) + x * M::rqrt(x);
         const R rc = M::rcbrt(y);
         zidelta = (y * rc) * (rc * ziz6);
         return R(6.) * rc * ztmp;                                   // 6 (1 + x^0.75)^(-1/3) nu/u*w
@@ -288,6 +303,7 @@ template <class R> __device__ __forceinline__ R wl_absorb(R zHwl)
 template <class R>
 __device__ __forceinline__ void wl_coare(R (&st)[4], const WlCoareCell<R> &c, R pQsw, R pQnsol, R pTau, bool commit)
 {
+    AB_REGION("wl_coare");
     using M = Mth<R>;
     const R Hwl_max = R(20.);
     R zdTwl = st[0];
@@ -346,6 +362,7 @@ template <class R> __device__ __forceinline__ R phi_takaya(R z)
 // WL_ECMWF mod_skin_ecmwf.f90:113-230 (no Stokes drift).  Advances dT_wl on EVERY call (:228).
 template <class R> __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, R pQsw, R pQnsol, R pustar, R zalpha)
 {
+    AB_REGION("wl_ecmwf");
     using M = Mth<R>;
     const R zRhoCp_w = K<R>::rho0_w * K<R>::rCp0_w;
     const R rNuwl0 = R(0.5);
@@ -403,6 +420,7 @@ template <class R> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
 // psi_m_coare_sclr :217-254 and psi_h_coare_sclr :305-344 at the same zeta
 template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
 {
+    AB_REGION("psi_coare");
     using M = Mth<R>;
     if (nonneg(z)) {  // stable: Beljaars & Holtslag (1991)
         const R zc = vmin(R(50.), R(0.35) * z);
@@ -457,6 +475,7 @@ __device__ __forceinline__ void first_guess_coare(const Heights<R> &h, R psst, R
                                                   R pcharn, R &pus, R &pts, R &pqs, R &t_zu, R &q_zu, R &Ubzu,
                                                   R &pz0)
 {
+    AB_REGION("first_guess_coare");
     using M = Mth<R>;
     const R vk = K<R>::vkarmn;
     t_zu = vmax(t_zt, R(180.));
@@ -523,7 +542,7 @@ constexpr int kSkinCS = 1, kSkinWL = 2, kSkinBoth = 3;
 // do not hold ten VGPRs across the rest of the iteration (the COARE + skin kernels sit at the 128-VGPR limit).
 template <class R, bool V36, int SKIN, bool DIAG = false>
 __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
-                                           bool dawn, CellOut<R> &o, volatile R *park = nullptr, int pstride = 0)
+                                           bool dawn, CellOut<R> &o, lds_vptr<R> park = nullptr, int pstride = 0)
 {
     using M = Mth<R>;
     const R vk = K<R>::vkarmn;
@@ -655,6 +674,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
 // psi_m_ecmwf_scl :441-477, psi_h_ecmwf_scl :498-533, cap_zeta :551-564
 template <class R> __device__ __forceinline__ void psi_ecmwf(R pz, R *pm, R *ph)
 {
+    AB_REGION("psi_ecmwf");
     using M = Mth<R>;
     const R zc = R(5. / 0.35);
     const R z = vmin(vmax(pz, R(-50.)), R(5.));
@@ -805,6 +825,7 @@ template <class R> __device__ __forceinline__ R cd_n10_ncar(R zw)
 // psi_m_ncar_sclr :333-363 / psi_h_ncar_sclr :379-407
 template <class R> __device__ __forceinline__ void psi_ncar(R z, R *pm, R *ph)
 {
+    AB_REGION("psi_ncar");
     using M = Mth<R>;
     if (nonneg(z)) {
         if (pm) *pm = R(-5.) * z;
@@ -889,6 +910,7 @@ __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &
 // psi_m_andreas :307-360 — Paulson unstable, Grachev et al. (2007) stable
 template <class R> __device__ __forceinline__ R psi_m_andreas(R pz)
 {
+    AB_REGION("psi_m_andreas");
     using M = Mth<R>;
     const R z = vmin(pz, R(15.));
     if (nonneg(z)) {
@@ -911,6 +933,7 @@ template <class R> __device__ __forceinline__ R psi_m_andreas(R pz)
 // psi_h_andreas :363-410
 template <class R> __device__ __forceinline__ R psi_h_andreas(R pz)
 {
+    AB_REGION("psi_h_andreas");
     using M = Mth<R>;
     const R z = vmin(pz, R(15.));
     if (nonneg(z)) {
@@ -927,6 +950,7 @@ template <class R> __device__ __forceinline__ R psi_h_andreas(R pz)
 // z0tq_LKB mod_phymbl.f90:1635-1701 (Liu, Katsaros & Businger 1979): both z0t (iflag 1) and z0q (iflag 2)
 template <class R> __device__ __forceinline__ void z0tq_lkb(R zrr, R pz0, R &z0t, R &z0q)
 {
+    AB_REGION("z0tq_lkb");
     using M = Mth<R>;
     R rt = R(-999.), rq = R(-999.);
     if ((zrr > R(0.)) && (zrr < R(1000.))) {

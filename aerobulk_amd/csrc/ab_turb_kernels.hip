@@ -28,7 +28,7 @@ template <class R> struct TurbArgs {
 // the OPTIONAL outputs and the warm-layer state are written straight to global memory at cell k.
 template <class R, int ALGO, int SKIN>
 __device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, const Heights<R> &hh, int nb_iter, long k, const CellIn<R> &in, R (&res)[8],
-                                          volatile R *park = nullptr, int pstride = 0)
+                                          lds_vptr<R> park = nullptr, int pstride = 0)
 {
     constexpr bool WL = (SKIN & kSkinWL) != 0;
     R wl[4] = {R(0.), R(0.), R(0.), R(0.)};
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const Tur
         in.rlw = ANYSKIN ? s_f[ANYSKIN ? 7 : 0][j] : R(0.);
         R res[8];
         // the cell's inputs are in registers now: its tile slots serve turb_coare as scratch words (ab_physics.hpp)
-        turb_cell<R, ALGO, SKIN>(a, hh, nb_iter, k, in, res, ((SKIN & kSkinWL) && sizeof(R) == 8) ? &s_f[0][j] : nullptr, T::kCells);
+        turb_cell<R, ALGO, SKIN>(a, hh, nb_iter, k, in, res, ((SKIN & kSkinWL) && sizeof(R) == 8) ? (lds_vptr<R>)&s_f[0][j] : (lds_vptr<R>)nullptr, T::kCells);
 #pragma unroll
         for (int i = 0; i < (ANYSKIN ? 8 : 6); ++i) s_f[i][j] = res[i];    // the slot is read by this lane only: reuse it
     }

@@ -45,6 +45,8 @@ int main()
     sweep("rcp", [](double x) { return qrcp(x); }, [](long double x) { return 1.0L / x; }, 1e-200, 1e200, true);
     sweep("cbrt", [](double x) { return qcbrt(x); }, [](long double x) { return std::cbrt(x); }, 1e-25, 1e25, true);
     sweep("rcbrt", [](double x) { return qrcbrt_mid(x); }, [](long double x) { return 1.0L / std::cbrt(x); }, 1e-25, 1e25, true);
+    sweep("rqrt", [](double x) { return qrqrt_mid(x); }, [](long double x) { return 1.0L / std::sqrt(std::sqrt(x)); }, 1e-30, 1e30, true);
+    sweep("rqrt_used", [](double x) { return qrqrt_mid(x); }, [](long double x) { return 1.0L / std::sqrt(std::sqrt(x)); }, 1e-15, 1e5, true);
     {   // division on pairs
         std::mt19937_64 rng(7);
         std::uniform_real_distribution<double> U(-300.0, 300.0);

@@ -6,7 +6,7 @@ import subprocess
 from conftest import ROOT
 
 LIMITS = {"log_wide": 2.5, "log_near1": 2.5, "log10": 4.0, "exp": 1.5, "exp_small": 1.5, "exp10": 2.0, "exp10_small": 2.0,
-          "atan": 2.5, "atan_wide": 2.5, "sqrt": 0.51, "rcp": 0.51, "div": 0.51, "cbrt": 8.0, "rcbrt": 4.0}
+          "atan": 2.5, "atan_wide": 2.5, "sqrt": 0.51, "rcp": 0.51, "div": 0.51, "cbrt": 8.0, "rcbrt": 4.0, "rqrt": 4.0, "rqrt_used": 1.5}
 
 
 def test_fastmath_algorithms_on_host(tmp_path):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-OPS = {"div": 0, "rcp": 1, "sqrt": 2, "log": 3, "log10": 4, "exp": 5, "exp10": 6, "atan": 7, "cbrt": 8, "rcbrt": 9, "e_sat": 10, "pow": 11}
+OPS = {"div": 0, "rcp": 1, "sqrt": 2, "log": 3, "log10": 4, "exp": 5, "exp10": 6, "atan": 7, "cbrt": 8, "rcbrt": 9, "e_sat": 10, "pow": 11, "rqrt": 12}
 
 
 def run(op, x, y=None):
@@ -46,6 +46,8 @@ CASES = [  # (op, sampler, reference(longdouble), max ulp)
     ("rcp", lambda: np.exp(RNG.uniform(-400, 400, N)), lambda v: 1 / v, 0.51),
     ("cbrt", lambda: np.exp(RNG.uniform(-55, 55, N)), np.cbrt, 8.0),
     ("rcbrt", lambda: np.exp(RNG.uniform(-55, 55, N)), lambda v: 1 / np.cbrt(v), 4.0),
+    ("rqrt", lambda: np.exp(RNG.uniform(-69, 69, N)), lambda v: 1 / np.sqrt(np.sqrt(v)), 4.0),   # 1e-30 .. 1e30: seed error grows with |log2 x|
+    ("rqrt", lambda: np.exp(RNG.uniform(-35, 12, N)), lambda v: 1 / np.sqrt(np.sqrt(v)), 1.5),   # where 1 + x^0.75 differs from 1 at all
 ]
 
 
