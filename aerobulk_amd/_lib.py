@@ -49,8 +49,11 @@ SYMBOLS = {
     "ab_device_count": (C.c_int, []),
     "ab_session_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ab_session_destroy": (C.c_int, [vp]),
-    "ab_session_init": (C.c_int, [vp] + [vp] * 8 + [C.c_int, C.POINTER(InitReport)]),
-    "ab_session_init_stats": (C.c_int, [vp] + [vp] * 8 + [C.c_int, dp]),
+    "ab_session_create_sharded": (C.c_int, [C.POINTER(vp), C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "ab_session_shard_count": (C.c_int, [vp]),
+    "ab_session_shard_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)]),
+    "ab_session_init": (C.c_int, [vp] + [vp] * 8 + [C.c_int, vp, C.POINTER(InitReport)]),
+    "ab_session_init_stats": (C.c_int, [vp] + [vp] * 8 + [C.c_int, vp, dp]),
     "ab_session_init_apply": (C.c_int, [vp, dp, C.c_int, C.POINTER(InitReport)]),
     "ab_session_set_humidity": (C.c_int, [vp, C.c_int]),
     "ab_session_set_diagnostics": (C.c_int, [vp, C.POINTER(Diag), C.c_int]),
@@ -65,7 +68,7 @@ SYMBOLS = {
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),
     "ab_session_check": (C.c_int, [vp]),
     "ab_session_set_regroup": (C.c_int, [vp, C.c_int]),
-    "ab_session_set_solar_time": (C.c_int, [vp, C.c_int, vp, C.c_int]),
+    "ab_session_set_solar_time": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     "ab_session_get_wl_state": (C.c_int, [vp, dp]),
     "ab_session_last_kernel_ms": (C.c_double, [vp]),
     "ab_synth_fields_device": (C.c_int, [vp] * 8 + [C.c_long, C.c_long, C.c_long, C.c_int, vp]),

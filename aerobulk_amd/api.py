@@ -65,10 +65,19 @@ def _ptr(x, dtype, n):
     return a.ctypes.data, a
 
 
-class Session:
-    """One aerobulk_model() time loop (jt = 1..Nt) on one MI355X.
+def _stream_of(x, stream):
+    """hipStream_t for device fields: the caller's, else torch's current stream (the one their producers ran on)."""
+    if stream is None and x is not None and _is_torch(x):
+        import torch
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+    return C.c_void_p(stream or 0)
 
-    Replaces the reference's module-global state by an explicit handle."""
+
+class Session:
+    """One aerobulk_model() time loop (jt = 1..Nt) on one MI355X, or sharded by row blocks over several.
+
+    Replaces the reference's module-global state by an explicit handle.  `device`: a HIP ordinal (-1 = current),
+    "all" (one j-block per visible GPU) or a list of ordinals (one j-block each; an ordinal may repeat)."""
 
     def __init__(self, calgo, Ni, Nj=1, Nt=1, l_use_skin=False, precision="f64", device=-1):
         self._lib = _lib.load()
@@ -80,19 +89,36 @@ class Session:
         self.n = self.Ni * self.Nj
         self.l_use_skin = bool(l_use_skin)
         self.dtype = np.float64 if precision == "f64" else np.float32
-        rc = self._lib.ab_session_create(C.byref(self._h), algo, self.Ni, self.Nj, self.Nt, int(self.l_use_skin),
-                                         AB_F64 if precision == "f64" else AB_F32, device)
+        prec = AB_F64 if precision == "f64" else AB_F32
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*[int(d) for d in device])
+            rc = self._lib.ab_session_create_sharded(C.byref(self._h), algo, self.Ni, self.Nj, self.Nt, int(self.l_use_skin),
+                                                     prec, devs, len(device))
+        else:
+            rc = self._lib.ab_session_create(C.byref(self._h), algo, self.Ni, self.Nj, self.Nt, int(self.l_use_skin), prec,
+                                             -2 if device == "all" else int(device))
         if rc:
             _raise(rc)
         self.hum_type = "sh"
 
+    def shards(self):
+        """[(j0, nj_local, device)] of the row blocks (one entry for an ordinary session)."""
+        out = []
+        for r in range(self._lib.ab_session_shard_count(self._h)):
+            j0, njl, dev = C.c_long(), C.c_long(), C.c_int()
+            rc = self._lib.ab_session_shard_info(self._h, r, C.byref(j0), C.byref(njl), C.byref(dev))
+            if rc:
+                _raise(rc)
+            out.append((j0.value, njl.value, dev.value))
+        return out
+
     # -- AEROBULK_INIT (mod_aerobulk.f90:24-160)
-    def init(self, sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw=None, rad_lw=None):
+    def init(self, sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw=None, rad_lw=None, stream=None):
         fields = [sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw, rad_lw]
         dev = _is_torch(sst)
         ptrs, keep = zip(*[_ptr(f, self.dtype, self.n) for f in fields])
         rep = _lib.InitReport()
-        rc = self._lib.ab_session_init(self._h, *ptrs, AB_MEM_DEVICE if dev else AB_MEM_HOST, C.byref(rep))
+        rc = self._lib.ab_session_init(self._h, *ptrs, AB_MEM_DEVICE if dev else AB_MEM_HOST, _stream_of(sst, stream), C.byref(rep))
         report = dict(n_cells=rep.n_cells, n_masked=rep.n_masked, hum_type=HUM_TYPES.get(rep.hum_type),
                       bad_field=rep.bad_field, bad_min=rep.bad_min, bad_max=rep.bad_max, bad_mean=rep.bad_mean)
         if rc:
@@ -101,13 +127,13 @@ class Session:
         return report
 
     # -- AEROBULK_INIT for a sharded grid: local statistics, then decisions on the combined statistics
-    def init_stats(self, sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw=None, rad_lw=None):
+    def init_stats(self, sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw=None, rad_lw=None, stream=None):
         """29 doubles: [0:11] combine by SUM, [11:20] by MIN, [20:29] by MAX (include/aerobulk_amd.h)."""
         fields = [sst, t_zt, hum_zt, U_zu, V_zu, slp, rad_sw, rad_lw]
         ptrs, keep = zip(*[_ptr(f, self.dtype, self.n) for f in fields])
         st = np.empty(29)
         rc = self._lib.ab_session_init_stats(self._h, *ptrs, AB_MEM_DEVICE if _is_torch(sst) else AB_MEM_HOST,
-                                             st.ctypes.data_as(_lib.dp))
+                                             _stream_of(sst, stream), st.ctypes.data_as(_lib.dp))
         if rc:
             _raise(rc)
         return st
@@ -161,10 +187,11 @@ class Session:
         if rc:
             _raise(rc)
 
-    def set_solar_time(self, isecday_utc, lon=None):
+    def set_solar_time(self, isecday_utc, lon=None, stream=None):
         p, keep = _ptr(lon, self.dtype, self.n)
         rc = self._lib.ab_session_set_solar_time(self._h, int(isecday_utc), p,
-                                                 AB_MEM_DEVICE if (lon is not None and _is_torch(lon)) else AB_MEM_HOST)
+                                                 AB_MEM_DEVICE if (lon is not None and _is_torch(lon)) else AB_MEM_HOST,
+                                                 _stream_of(lon, stream))
         if rc:
             _raise(rc)
 
@@ -304,6 +331,11 @@ def aerobulk_model(jt, Nt, calgo, zt, zu, sst, t_zt, hum_zt, U_zu, V_zu, slp, Ni
     if jt == 1:
         res["init_report"] = dict(n_masked=rep.n_masked, hum_type=HUM_TYPES.get(rep.hum_type))
     return res
+
+
+def device_count():
+    """Usable gfx950 devices (ab_device_count)."""
+    return int(_lib.load().ab_device_count())
 
 
 def synth_fields_device(Ni, Nj, j0=0, nj_local=None, precision="f64", device="cuda", with_rad=True):

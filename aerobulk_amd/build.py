@@ -40,7 +40,7 @@ def _run(cmd, **kw):
 
 
 def build_engine(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_ice_kernels.hip", "ab_runtime.hip", "ab_cxx.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_ice_kernels.hip", "ab_runtime.hip", "ab_sharded.hip", "ab_cxx.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [
         os.path.join(ROOT, "include", "aerobulk_amd.h"), os.path.join(ROOT, "include", "aerobulk.hpp"), os.path.abspath(__file__)]
     if not force and not _newer(LIB, deps):

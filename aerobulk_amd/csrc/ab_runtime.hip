@@ -6,6 +6,7 @@
 // AB_ERR_HIP (with a message) when none is usable.
 #include "../../include/aerobulk_amd.h"
 #include "ab_kernels.hpp"
+#include "ab_session.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -64,36 +65,17 @@ struct Range {
     ~Range() { if (on) tx().pop(); }
 };
 
+}  // namespace
+namespace ab {
+void set_last_error(const std::string &msg) { g_err = msg; }
+}  // namespace ab
+namespace {
+
 const char *kAlgoNames[6] = {"other", "coare3p0", "coare3p6", "ncar", "ecmwf", "andreas"};
 
 bool algo_has_skin(int algo) { return algo == AB_ALGO_COARE3P0 || algo == AB_ALGO_COARE3P6 || algo == AB_ALGO_ECMWF; }
 
 }  // namespace
-
-struct ab_session {
-    int algo = 0, nt = 1, use_skin = 0, f32 = 0, device = 0;
-    long ni = 0, nj = 0, n = 0;
-    size_t esz = 8;
-    int hum_type = AB_HUM_SH;
-    int last_jt = 0;
-    int isecday = 12;                 // mod_aerobulk_compute.f90:136,146
-    int regroup = 1;                  // lane regrouping of flux_kernel (ab_session_set_regroup)
-    void *d_lon = nullptr;            // optional longitude field (device, session-owned copy)
-    void *wl[4] = {nullptr, nullptr, nullptr, nullptr};
-    int *d_flags = nullptr;
-    double *d_partials = nullptr;
-    void *stage_in[8] = {nullptr};    // device staging for AB_MEM_HOST callers
-    void *stage_out[6] = {nullptr};
-    void *diag_user[16] = {nullptr};  // caller's diagnostic arrays (ab_session_set_diagnostics), host or device
-    void *diag_dev[16] = {nullptr};   // device staging when the caller's arrays are host memory
-    int diag_mem = AB_MEM_DEVICE;
-    bool diag_on = false;
-    hipStream_t stream = nullptr;     // session stream for host-mem calls (kernels)
-    hipStream_t s_h2d = nullptr, s_d2h = nullptr;  // copy streams of the pipelined host path
-    hipStream_t last_stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-};
 
 extern "C" {
 
@@ -150,6 +132,10 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(AB_ERR_HIP, "no HIP device visible: this engine has no CPU fallback");
+    if (device == AB_DEVICE_ALL) {   // row blocks over every visible device (one device: an ordinary session)
+        if (ndev > 1 && nj >= ndev) return ab::sharded_create(out, algo, ni, nj, nt, use_skin, precision, nullptr, ndev);
+        device = 0;
+    }
     if (device < 0) AB_HIP(hipGetDevice(&device));
     if (device >= ndev) return fail(AB_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
     AB_HIP(hipSetDevice(device));
@@ -179,10 +165,36 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     return AB_OK;
 }
 
+int ab_session_create_sharded(ab_session **out, int algo, long ni, long nj, int nt, int use_skin, int precision,
+                              const int *devices, int nshards)
+{
+    if (!out) return fail(AB_ERR_ARG, "ab_session_create_sharded: out == NULL");
+    *out = nullptr;
+    if (nshards < 1 || !devices) return fail(AB_ERR_ARG, "ab_session_create_sharded: no device list");
+    if (nshards > nj) return fail(AB_ERR_ARG, "ab_session_create_sharded: %d shards for %ld rows", nshards, nj);
+    return ab::sharded_create(out, algo, ni, nj, nt, use_skin, precision, devices, nshards);
+}
+
+int ab_session_shard_count(const ab_session *s) { return s ? (s->sharded() ? (int)s->shards.size() : 1) : 0; }
+
+int ab_session_shard_info(const ab_session *s, int shard, long *j0, long *nj_local, int *device)
+{
+    if (!s || shard < 0 || shard >= ab_session_shard_count(s)) return fail(AB_ERR_ARG, "ab_session_shard_info: bad shard %d", shard);
+    const bool sh = s->sharded();
+    if (j0) *j0 = sh ? s->shard_j0[shard] : 0;
+    if (nj_local) *nj_local = sh ? s->shard_njl[shard] : s->nj;
+    if (device) *device = sh ? s->shards[shard]->device : s->device;
+    return AB_OK;
+}
+
 int ab_session_destroy(ab_session *s)
 {
     if (!s) return AB_OK;
+    if (s->sharded()) return ab::sharded_destroy(s);
     (void)hipSetDevice(s->device);
+    // device-mode calls run on the caller's stream and use session-owned buffers (WL state, flags, lon, diagnostics staging):
+    // drain it before they are freed
+    if (s->last_stream) (void)hipStreamSynchronize(s->last_stream);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &p : s->wl) if (p) (void)hipFree(p);
     for (auto &p : s->stage_in) if (p) (void)hipFree(p);
@@ -302,12 +314,14 @@ int ab_session_set_humidity(ab_session *s, int hum_type)
     if (!s) return fail(AB_ERR_ARG, "NULL session");
     if (hum_type < AB_HUM_SH || hum_type > AB_HUM_RH) return fail(AB_ERR_HUM_TYPE, "humidty type %d is unknown!!!", hum_type);
     s->hum_type = hum_type;
+    for (ab_session *c : s->shards) c->hum_type = hum_type;
     return AB_OK;
 }
 
 int ab_session_set_diagnostics(ab_session *s, const ab_diag *d, int mem)
 {
     if (!s) return fail(AB_ERR_ARG, "NULL session");
+    if (s->sharded()) return ab::sharded_set_diagnostics(s, d, mem);
     s->diag_on = false;
     for (auto &p : s->diag_user) p = nullptr;
     if (!d) return AB_OK;
@@ -325,12 +339,14 @@ int ab_session_set_regroup(ab_session *s, int on)
 {
     if (!s) return fail(AB_ERR_ARG, "NULL session");
     s->regroup = on ? 1 : 0;
+    for (ab_session *c : s->shards) c->regroup = s->regroup;
     return AB_OK;
 }
 
-int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int mem)
+int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int mem, void *stream)
 {
     if (!s) return fail(AB_ERR_ARG, "NULL session");
+    if (s->sharded()) return ab::sharded_set_solar_time(s, isecday_utc, lon, mem, stream);
     AB_HIP(hipSetDevice(s->device));
     s->isecday = isecday_utc;
     if (!lon) {
@@ -339,19 +355,28 @@ int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, i
     }
     const size_t bytes = s->esz * (size_t)s->n;
     if (!s->d_lon) AB_HIP(hipMalloc(&s->d_lon, bytes));
-    AB_HIP(hipMemcpy(s->d_lon, lon, bytes, mem == AB_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    // a device `lon` may still be being written on the caller's stream: the copy is ordered behind it, then drained (the
+    // session keeps its own copy, so the caller may reuse the array at once)
+    hipStream_t st = (mem == AB_MEM_DEVICE) ? (hipStream_t)stream : s->stream;
+    AB_HIP(hipMemcpyAsync(s->d_lon, lon, bytes, mem == AB_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    AB_HIP(hipStreamSynchronize(st));
     return AB_OK;
 }
 
 int ab_session_init_stats(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt, const void *u_zu,
                           const void *v_zu, const void *slp, const void *rad_sw, const void *rad_lw, int mem,
-                          double stats[AB_INIT_NSTATS])
+                          void *stream, double stats[AB_INIT_NSTATS])
 {
     Range trace_("ab_session_init_stats");
     if (!s || !stats) return fail(AB_ERR_ARG, "NULL argument");
     if (!sst || !t_zt || !hum_zt || !u_zu || !v_zu || !slp) return fail(AB_ERR_ARG, "ab_session_init: NULL input field");
-    AB_HIP(hipSetDevice(s->device));
     const void *host[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw};
+    if (s->sharded()) return ab::sharded_init_stats(s, host, mem, stream, stats);
+    AB_HIP(hipSetDevice(s->device));
+    // device arrays: the reduction runs on the CALLER's stream, behind whatever is still producing the fields there (the
+    // session's own stream is non-blocking and ordered with nothing)
+    hipStream_t st = (mem == AB_MEM_DEVICE) ? (hipStream_t)stream : s->stream;
+    for (auto &p : s->staged_from) p = nullptr;
     const void *dev[8];
     if (mem == AB_MEM_HOST) {
         // rad_sw == rad_lw is the reference's own call pattern (mod_aerobulk.f90:248): stage once
@@ -359,15 +384,16 @@ int ab_session_init_stats(ab_session *s, const void *sst, const void *t_zt, cons
         int rc = stage_inputs(s, host, dev);
         if (rc) return rc;
         if (rad_sw && rad_sw == rad_lw) dev[6] = dev[7];
+        for (int i = 0; i < 8; ++i) s->staged_from[i] = host[i];   // what each staging buffer now holds (ab_model reuses it)
     } else {
         for (int i = 0; i < 8; ++i) dev[i] = host[i];
     }
     const bool rad = dev[6] && dev[7];
     AB_HIP(ab::launch_init_stats(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], rad ? dev[6] : nullptr,
-                                 rad ? dev[7] : nullptr, s->n, s->f32, s->d_partials, s->stream));
+                                 rad ? dev[7] : nullptr, s->n, s->f32, s->d_partials, st));
     std::vector<double> part((size_t)ab::kStatBlocks * ab::kStatStride);
-    AB_HIP(hipMemcpyAsync(part.data(), s->d_partials, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    AB_HIP(hipStreamSynchronize(s->stream));
+    AB_HIP(hipMemcpyAsync(part.data(), s->d_partials, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    AB_HIP(hipStreamSynchronize(st));
 
     // fold the per-block rows into [count, n_cells | 9 sums | 9 mins | 9 maxs] (layout of AB_INIT_NSTATS, see header)
     double *sum = stats + 2, *mn = stats + 2 + ab::kStatFields, *mx = stats + 2 + 2 * ab::kStatFields;
@@ -415,6 +441,7 @@ int ab_session_init_apply(ab_session *s, const double stats[AB_INIT_NSTATS], int
                     "     * mean = %g\n     * min  = %g\n     * max  = %g", hmean, hmin, hmax);
     }
     s->hum_type = rep.hum_type;
+    for (ab_session *c : s->shards) c->hum_type = rep.hum_type;
 
     // check_unit_consistency x7(+2), mod_aerobulk.f90:143-153 ; ranges mod_phymbl.f90:1885-1940
     static const char *names[9] = {"sst", "t_air", "slp", "u10", "v10", "wnd", "hum", "rad_sw", "rad_lw"};
@@ -439,10 +466,10 @@ int ab_session_init_apply(ab_session *s, const double stats[AB_INIT_NSTATS], int
 
 int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt, const void *u_zu,
                     const void *v_zu, const void *slp, const void *rad_sw, const void *rad_lw, int mem,
-                    ab_init_report *report)
+                    void *stream, ab_init_report *report)
 {
     double stats[AB_INIT_NSTATS];
-    int rc = ab_session_init_stats(s, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, mem, stats);
+    int rc = ab_session_init_stats(s, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, mem, stream, stats);
     if (rc) return rc;
     return ab_session_init_apply(s, stats, (rad_sw && rad_lw) ? 1 : 0, report);
 }
@@ -461,6 +488,11 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     if (s->use_skin && (!rad_sw || !rad_lw))
         return fail(AB_ERR_SKIN_NORAD, " AEROBULK_INIT => provide SW and LW rad. input if you want to use skin schemes");
     if (niter < 0) return fail(AB_ERR_ARG, "niter < 0");
+    if (s->sharded()) {
+        const void *in8[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw};
+        void *out6[6] = {ql, qh, tau_x, tau_y, evap, t_s};
+        return ab::sharded_compute(s, jt, zt, zu, niter, in8, out6, mem, stream);
+    }
     if (s->use_skin && s->nt > 1 && jt > 1 && s->last_jt != jt - 1 && s->last_jt != jt)
         return fail(AB_ERR_STATE, "warm-layer state: record jt=%d requested after jt=%d", jt, s->last_jt);
     AB_HIP(hipSetDevice(s->device));
@@ -470,21 +502,28 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
                               s->use_skin ? rad_lw : nullptr};
     const void *din[8];
     void *hout[6] = {ql, qh, tau_x, tau_y, evap, t_s};
+    if (mem != AB_MEM_HOST) s->reuse_staged = false;
     void *dout[6];
     const size_t bytes = s->esz * (size_t)s->n;
     const bool pipelined = (mem == AB_MEM_HOST) && (s->n >= kPipeThreshold) && !s->diag_on;
     if (mem == AB_MEM_HOST) {
-        if (pipelined) {   // staging buffers only; the copies are issued chunk by chunk below
-            for (int i = 0; i < 8; ++i) {
-                din[i] = nullptr;
-                if (!host_in[i]) continue;
-                if (!s->stage_in[i]) AB_HIP(hipMalloc(&s->stage_in[i], bytes));
-                din[i] = s->stage_in[i];
-            }
-        } else {
-            int rc = stage_inputs(s, host_in, din);
-            if (rc) return rc;
+        // AEROBULK_MODEL at jt == 1: the fields AEROBULK_INIT has just staged (ab_model marks them) do not cross PCIe again
+        const void *copy_in[8];
+        for (int i = 0; i < 8; ++i) {
+            const bool resident = s->reuse_staged && host_in[i] && s->stage_in[i] && s->staged_from[i] == host_in[i];
+            copy_in[i] = resident ? nullptr : host_in[i];
         }
+        s->reuse_staged = false;
+        for (auto &p : s->staged_from) p = nullptr;
+        for (int i = 0; i < 8; ++i) {
+            din[i] = nullptr;
+            if (!host_in[i]) continue;
+            if (!s->stage_in[i]) AB_HIP(hipMalloc(&s->stage_in[i], bytes));
+            din[i] = s->stage_in[i];
+            if (!pipelined && copy_in[i])   // the pipelined path issues its copies chunk by chunk below
+                AB_HIP(hipMemcpyAsync(s->stage_in[i], copy_in[i], bytes, hipMemcpyHostToDevice, s->stream));
+        }
+        for (int i = 0; i < 8; ++i) host_in[i] = copy_in[i];   // from here on: the fields that still have to be copied
         for (int i = 0; i < 6; ++i) {
             dout[i] = nullptr;
             if (!hout[i]) continue;
@@ -560,6 +599,7 @@ int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int
         return fail(AB_ERR_SKIN_ALGO, "TURB_%s has no cool-skin / warm-layer scheme", ab_algo_name(s->algo));
     if (skin && (!f->Qsw || !f->rad_lw || !f->slp))   // mod_blk_coare3p6.f90:263-269
         return fail(AB_ERR_SKIN_NORAD, "you need to provide Qsw, rad_lw & slp to use cool-skin / warm-layer param!");
+    if (s->sharded()) return ab::sharded_turb(s, kt, zt, zu, use_cs, use_wl, nb_iter, f, mem, stream);
     AB_HIP(hipSetDevice(s->device));
     const size_t bytes = s->esz * (size_t)s->n;
     if (use_wl) {
@@ -630,6 +670,7 @@ int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int
 int ab_session_check(ab_session *s)
 {
     if (!s) return fail(AB_ERR_ARG, "NULL session");
+    if (s->sharded()) return ab::sharded_check(s);
     AB_HIP(hipSetDevice(s->device));
     hipStream_t st = s->last_stream;
     int flags = 0;
@@ -646,6 +687,7 @@ int ab_session_check(ab_session *s)
 int ab_session_get_wl_state(ab_session *s, double *state4n)
 {
     if (!s || !state4n) return fail(AB_ERR_ARG, "NULL argument");
+    if (s->sharded()) return ab::sharded_get_wl_state(s, state4n);
     if (!s->wl[0]) return fail(AB_ERR_STATE, "session keeps no persistent warm-layer state (no skin scheme or nt == 1)");
     AB_HIP(hipSetDevice(s->device));
     AB_HIP(hipDeviceSynchronize());
@@ -666,6 +708,7 @@ int ab_session_get_wl_state(ab_session *s, double *state4n)
 
 double ab_session_last_kernel_ms(ab_session *s)
 {
+    if (s && s->sharded()) return ab::sharded_last_kernel_ms(s);
     if (!s || !s->timed) return -1.;
     if (hipSetDevice(s->device) != hipSuccess) return -1.;
     if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.;
@@ -707,6 +750,30 @@ int ab_test_math(int op, const double *x, const double *y, double *out, long n)
 static ab_session *g_sess = nullptr;
 static int g_nb_iter = 5;  // mod_const.f90:33 ; sticky once set through Niter (mod_aerobulk.f90:236)
 
+// The process-global session of AEROBULK_MODEL.  AEROBULK_AMD_DEVICES (unset: the current device) spreads it over several
+// GPUs by row blocks without a change to the calling Fortran / C++ code: "all", a count ("4": devices 0..3) or a list
+// ("0,2,5"; a device may repeat: several shards on it).
+static int create_model_session(ab_session **out, int algo, long ni, long nj, int nt, int use_skin)
+{
+    const char *e = getenv("AEROBULK_AMD_DEVICES");
+    if (!e || !*e) return ab_session_create(out, algo, ni, nj, nt, use_skin, AB_F64, -1);
+    if (strcmp(e, "all") == 0) return ab_session_create(out, algo, ni, nj, nt, use_skin, AB_F64, AB_DEVICE_ALL);
+    std::vector<int> devs;
+    if (strchr(e, ',')) {
+        for (const char *p = e; *p;) {
+            devs.push_back(atoi(p));
+            const char *c = strchr(p, ',');
+            if (!c) break;
+            p = c + 1;
+        }
+    } else {
+        for (int d = 0; d < atoi(e); ++d) devs.push_back(d);
+    }
+    if (devs.empty()) return fail(AB_ERR_ARG, "AEROBULK_AMD_DEVICES=%s: no device", e);
+    if (devs.size() == 1) return ab_session_create(out, algo, ni, nj, nt, use_skin, AB_F64, devs[0]);
+    return ab_session_create_sharded(out, algo, ni, nj, nt, use_skin, AB_F64, devs.data(), (int)devs.size());
+}
+
 int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double zu, const double *sst,
              const double *t_zt, const double *hum_zt, const double *u_zu, const double *v_zu, const double *slp,
              double *ql, double *qh, double *tau_x, double *tau_y, double *evap, int niter, int use_skin,
@@ -729,18 +796,26 @@ int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double
                            g_sess->use_skin == (use_skin ? 1 : 0) && !g_sess->f32;
         if (!reuse) {
             if (g_sess) { ab_session_destroy(g_sess); g_sess = nullptr; }
-            int rc = ab_session_create(&g_sess, algo, ni, nj, nt, use_skin, AB_F64, -1);
+            int rc = create_model_session(&g_sess, algo, ni, nj, nt, use_skin);
             if (rc) return rc;
         }
         g_sess->last_jt = 0;
+        for (ab_session *c : g_sess->shards) c->last_jt = 0;
         // the reference hands rad_lw to BOTH prsw and prlw (mod_aerobulk.f90:248)
         int rc = ab_session_init(g_sess, sst, t_zt, hum_zt, u_zu, v_zu, slp, lsrad ? rad_lw : nullptr,
-                                 lsrad ? rad_lw : nullptr, AB_MEM_HOST, report);
+                                 lsrad ? rad_lw : nullptr, AB_MEM_HOST, nullptr, report);
         if (rc) return rc;
+        // aerobulk_compute reads the very arrays AEROBULK_INIT has just staged in HBM: one PCIe crossing, not two
+        g_sess->reuse_staged = true;
+        for (ab_session *c : g_sess->shards) c->reuse_staged = true;
     } else {
         if (!g_sess) return fail(AB_ERR_STATE, "AEROBULK_MODEL called with jt=%d before jt=1", jt);
-        if (g_sess->algo != algo || g_sess->n != ni * nj)
-            return fail(AB_ERR_STATE, "AEROBULK_MODEL: algorithm or shape changed between time records");
+        // the reference keeps using the settings of jt == 1 silently; a caller that changes them mid-loop has a bug
+        if (g_sess->algo != algo || g_sess->ni != ni || g_sess->nj != nj || g_sess->nt != nt ||
+            g_sess->use_skin != (use_skin ? 1 : 0))
+            return fail(AB_ERR_STATE, "AEROBULK_MODEL: algorithm, shape, Nt or l_use_skin changed between time records "
+                                      "(jt=%d: %s %ldx%ld Nt=%d skin=%d, session: %s %ldx%ld Nt=%d skin=%d)", jt, ab_algo_name(algo), ni, nj,
+                        nt, use_skin ? 1 : 0, ab_algo_name(g_sess->algo), g_sess->ni, g_sess->nj, g_sess->nt, g_sess->use_skin);
     }
     // rad present but l_use_skin false => no skin, T_s = sst (mod_aerobulk_compute.f90:132,206)
     return ab_session_compute(g_sess, jt, zt, zu, g_nb_iter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, ql, qh,
@@ -766,7 +841,7 @@ int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int 
         int rc = ab_session_create(&s, algo, ni, nj, 1, 0, AB_F64, -1);
         if (rc) return rc;
     }
-    int rc = ab_session_set_solar_time(s, isecday_utc, (use_wl && algo != AB_ALGO_ECMWF) ? lon : nullptr, AB_MEM_HOST);
+    int rc = ab_session_set_solar_time(s, isecday_utc, (use_wl && algo != AB_ALGO_ECMWF) ? lon : nullptr, AB_MEM_HOST, nullptr);
     if (rc) return rc;
     ab_diag d;
     memset(&d, 0, sizeof d);

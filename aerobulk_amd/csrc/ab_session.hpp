@@ -1,0 +1,63 @@
+// ab_session.hpp — the session object behind the opaque `ab_session` of include/aerobulk_amd.h, shared by the leaf runtime
+// (ab_runtime.hip: one device) and the row-block sharding layer (ab_sharded.hip: several devices, or several shards of one).
+// Internal; not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/aerobulk_amd.h"
+
+struct ab_session {
+    int algo = 0, nt = 1, use_skin = 0, f32 = 0, device = 0;
+    long ni = 0, nj = 0, n = 0;
+    size_t esz = 8;
+    int hum_type = AB_HUM_SH;
+    int last_jt = 0;
+    int isecday = 12;                 // mod_aerobulk_compute.f90:136,146
+    int regroup = 1;                  // lane regrouping of flux_kernel (ab_session_set_regroup)
+    void *d_lon = nullptr;            // optional longitude field (device, session-owned copy)
+    void *wl[4] = {nullptr, nullptr, nullptr, nullptr};
+    int *d_flags = nullptr;
+    double *d_partials = nullptr;
+    void *stage_in[8] = {nullptr};    // device staging for AB_MEM_HOST callers
+    void *stage_out[6] = {nullptr};
+    void *diag_user[16] = {nullptr};  // caller's diagnostic arrays (ab_session_set_diagnostics), host or device
+    void *diag_dev[16] = {nullptr};   // device staging when the caller's arrays are host memory
+    int diag_mem = AB_MEM_DEVICE;
+    bool diag_on = false;
+    hipStream_t stream = nullptr;     // session stream for host-mem calls (kernels)
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;  // copy streams of the pipelined host path
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // AEROBULK_MODEL at jt == 1 (ab_model): the fields AEROBULK_INIT staged in HBM are the ones aerobulk_compute reads next.
+    // staged_from[i] = the host array stage_in[i] was last filled from; reuse_staged = honour it in the next host compute
+    const void *staged_from[8] = {nullptr};
+    bool reuse_staged = false;
+    // ---- row-block sharding: a parent session owns no device state, its shards do.  Shard r covers the rows
+    // [shard_j0[r], shard_j0[r] + shard_njl[r]) of the (ni, nj) grid = the cells [ni*j0, ni*(j0+njl)) of every flat field.
+    std::vector<ab_session *> shards;
+    std::vector<long> shard_j0, shard_njl;
+    bool sharded() const { return !shards.empty(); }
+};
+
+namespace ab {
+// last-error plumbing across the worker threads of the sharding layer (ab_last_error() is per thread)
+void set_last_error(const std::string &msg);
+// Row-block sharding layer (ab_sharded.hip); each function mirrors the public entry point of the same name and is what that
+// entry point calls for a session with shards.
+int sharded_create(ab_session **out, int algo, long ni, long nj, int nt, int use_skin, int precision, const int *devices, int nshards);
+int sharded_destroy(ab_session *s);
+int sharded_init_stats(ab_session *s, const void *const in[8], int mem, void *stream, double stats[AB_INIT_NSTATS]);
+int sharded_compute(ab_session *s, int jt, double zt, double zu, int niter, const void *const in[8], void *const out[6], int mem,
+                    void *stream);
+int sharded_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int use_wl, int nb_iter, const ab_turb_fields *f, int mem,
+                 void *stream);
+int sharded_check(ab_session *s);
+int sharded_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int mem, void *stream);
+int sharded_set_diagnostics(ab_session *s, const ab_diag *d, int mem);
+int sharded_get_wl_state(ab_session *s, double *state4n);
+double sharded_last_kernel_ms(ab_session *s);
+}  // namespace ab

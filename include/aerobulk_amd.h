@@ -73,22 +73,37 @@ const char *ab_last_error(void);
 /* Number of usable gfx950 devices (0 if none / HIP unavailable). */
 int ab_device_count(void);
 
-/* ---- session: one aerobulk_model() time loop jt = 1..nt on one GPU ----------------------- */
+/* ---- session: one aerobulk_model() time loop jt = 1..nt on one GPU, or sharded over several --- */
 /* Replaces the module-global state of the reference (nitend, l_use_skin_schemes, ctype_humidity,
  * nb_iter: mod_const.f90:22-33; warm-layer arrays mod_skin_coare.f90:31-36, mod_skin_ecmwf.f90:52-55)
- * with per-handle state.  `device` is the HIP device ordinal (-1: current device). */
+ * with per-handle state.  `device` is the HIP device ordinal (-1: current device), or AB_DEVICE_ALL: the grid is cut into
+ * contiguous blocks of rows (j-blocks), one per visible GPU — see ab_session_create_sharded. */
+#define AB_DEVICE_ALL (-2)
 int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int use_skin,
                       int precision, int device);
 int ab_session_destroy(ab_session *s);
+/* Row-block sharding inside the library, for the callers of AEROBULK_MODEL (mod_aerobulk.f90:250-262: whole (Ni,Nj) host
+ * arrays): shard r owns the rows [j0_r, j0_r + nj_r) on devices[r], with its own streams, pinned-free staging and warm-layer
+ * state.  Every entry point below takes such a session like any other: host arrays are cut by rows and the shards run
+ * concurrently (each device moves its rows over its own PCIe link); AEROBULK_INIT's statistics — the one exchange of the
+ * path — are reduced per shard and combined on the host; no other data crosses between devices (pointwise path, no halo).
+ * Results are bit-identical to one unsharded session.  A device may appear several times (several shards on it).
+ * AB_MEM_DEVICE arrays are accepted only if every shard lives on the device that holds them: a GPU-resident model owns one
+ * session per GPU instead.  Process-global AEROBULK_MODEL / aerobulk_cxx_*: environment AEROBULK_AMD_DEVICES = all | N | list. */
+int ab_session_create_sharded(ab_session **out, int algo, long ni, long nj, int nt, int use_skin,
+                              int precision, const int *devices, int nshards);
+int ab_session_shard_count(const ab_session *s);    /* 1 for an ordinary session */
+int ab_session_shard_info(const ab_session *s, int shard, long *j0, long *nj_local, int *device);
 
 /* AEROBULK_INIT (mod_aerobulk.f90:24-160) minus its banner: builds the sanity mask, detects the
  * humidity type, runs check_unit_consistency on every input.  rad_sw/rad_lw may be NULL.
  * NB the reference passes prsw=rad_lw (mod_aerobulk.f90:248) so rad_sw is never range-checked:
  * callers that want identical behaviour pass rad_lw for both (the Fortran/C++ hosts do).
- * Global reductions run on the GPU (one pass over the inputs). */
+ * Global reductions run on the GPU (one pass over the inputs).  AB_MEM_DEVICE: the reduction is enqueued on `stream`
+ * (hipStream_t, NULL = default stream) behind whatever still produces the fields there, and the call returns when it is done. */
 int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt,
                     const void *u_zu, const void *v_zu, const void *slp,
-                    const void *rad_sw, const void *rad_lw, int mem, ab_init_report *report);
+                    const void *rad_sw, const void *rad_lw, int mem, void *stream, ab_init_report *report);
 /* The same in two steps, for a grid sharded over several GPUs/processes (AEROBULK_INIT's statistics are the one global
  * exchange of the path): every rank reduces its own cells with ab_session_init_stats(), the ranks combine
  * the AB_INIT_NSTATS doubles — stats[0..10] by SUM (count of unmasked cells, number of cells, 9 masked sums),
@@ -97,7 +112,7 @@ int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void
 #define AB_INIT_NSTATS 29
 int ab_session_init_stats(ab_session *s, const void *sst, const void *t_zt, const void *hum_zt,
                           const void *u_zu, const void *v_zu, const void *slp,
-                          const void *rad_sw, const void *rad_lw, int mem, double stats[AB_INIT_NSTATS]);
+                          const void *rad_sw, const void *rad_lw, int mem, void *stream, double stats[AB_INIT_NSTATS]);
 int ab_session_init_apply(ab_session *s, const double stats[AB_INIT_NSTATS], int have_rad, ab_init_report *report);
 /* Skip the detection and force the humidity type (device-resident callers that already know). */
 int ab_session_set_humidity(ab_session *s, int hum_type);
@@ -127,8 +142,9 @@ int ab_session_set_regroup(ab_session *s, int on);
 /* Warm-layer solar-time inputs for the next ab_session_compute calls.  aerobulk_compute
  * hard-wires isecday_utc=12 and longitude 0 (mod_aerobulk_compute.f90:126,136,146), which is
  * the default; TURB_COARE3Px callers with real time/longitude (tests/test_aerobulk_buoy_series_oce.f90
- * :345-377) set them here.  `lon` (degrees East, same layout/mem/precision as the fields) may be NULL. */
-int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int mem);
+ * :345-377) set them here.  `lon` (degrees East, same layout/mem/precision as the fields) may be NULL; the session keeps its
+ * own copy (a device `lon` is copied on `stream`, behind its producer; the call returns when the copy is done). */
+int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int mem, void *stream);
 
 /* Optional per-cell diagnostics: what the TURB_* routines return besides the fluxes — their mandatory outputs Cd, Ch, Ce,
  * t_zu, q_zu, Ubzu and their OPTIONAL ones CdN, ChN, CeN, xz0, xu_star, xL, xUN10, pdT_cs, pdT_wl, pHz_wl
@@ -228,7 +244,7 @@ int ab_synth_fields_device(void *sst, void *t_zt, void *q_zt, void *u_zu, void *
                            void *stream);
 
 /* Test hook: apply the engine's fp64 device math function `op` elementwise to host arrays (y may be NULL):
- * 0 div 1 rcp 2 sqrt 3 log 4 log10 5 exp 6 exp10 7 atan 8 cbrt 9 rcbrt 10 e_sat 11 pow.  tests/test_gpu_math.py */
+ * 0 div 1 rcp 2 sqrt 3 log 4 log10 5 exp 6 exp10 7 atan 8 cbrt 9 rcbrt 10 e_sat 11 pow 12 x^(-1/4).  tests/test_gpu_math.py */
 int ab_test_math(int op, const double *x, const double *y, double *out, long n);
 
 /* ---- the reference's own entry points --------------------------------------------------- */

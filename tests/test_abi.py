@@ -60,6 +60,18 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.ab_strerror(8).startswith(b"wind stress")
 
 
+def test_sharded_session_arguments_need_no_gpu(lib):
+    h = C.c_void_p()
+    devs = (C.c_int * 3)(0, 0, 0)
+    assert lib.ab_session_create_sharded(C.byref(h), 2, 10, 2, 1, 0, 0, devs, 3) == 10     # more shards than rows: AB_ERR_ARG
+    assert lib.ab_session_create_sharded(C.byref(h), 2, 10, 8, 1, 0, 0, None, 2) == 10     # no device list
+    assert lib.ab_session_shard_count(None) == 0
+    if lib.ab_device_count() == 0:   # no GPU: the shards cannot be created, and the failure is loud
+        assert lib.ab_session_create_sharded(C.byref(h), 2, 10, 8, 1, 0, 0, devs, 3) == 9
+        assert lib.ab_session_create(C.byref(h), 2, 10, 8, 1, 0, 0, -2) == 9                # AB_DEVICE_ALL
+        assert not h.value
+
+
 def test_no_cpu_fallback(lib):
     """Without a visible GPU the product path must fail loudly (AB_ERR_HIP), never compute on the host."""
     if lib.ab_device_count() > 0:

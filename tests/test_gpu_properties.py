@@ -242,3 +242,34 @@ def test_device_generator_reproduces_the_host_generator_bits(oracle):
     for kd, kh in (("sst", "sst"), ("t_zt", "t_zt"), ("U_zu", "u_zu"), ("V_zu", "v_zu"), ("slp", "slp"), ("rad_sw", "rad_sw"), ("rad_lw", "rad_lw")):
         np.testing.assert_array_equal(fd[kd].cpu().numpy(), fh[kh], err_msg=kd)
     np.testing.assert_allclose(fd["hum_zt"].cpu().numpy(), fh["hum_zt"], rtol=1e-14, atol=0)   # e_sat surrogate: <= 6e-15
+
+
+def test_init_is_ordered_behind_the_producer_of_device_fields(torch_mod):
+    """AEROBULK_INIT on device arrays runs on the CALLER's stream: called right after the kernels that are still writing the
+    fields (here on a side stream, into memory holding values that would fail every sanity range), it must see the finished
+    fields.  Same for the longitude copy of ab_session_set_solar_time."""
+    import aerobulk_amd as ab
+    torch = torch_mod
+    ni, nj = 4320, 900
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        junk = {k: torch.full((ni * nj,), -1.0e30, dtype=torch.float64, device="cuda") for k in ab.api.IN_NAMES}
+        lon = torch.full((ni * nj,), 75.0, dtype=torch.float64, device="cuda")      # 05:00 local solar time at 00:00 UTC: dawn window
+        torch.cuda.synchronize()
+        with ab.Session("coare3p6", ni, nj, 2, True) as s:
+            with torch.cuda.stream(side):
+                burn = torch.randn(4096, 4096, device="cuda")
+                for _ in range(20):                                   # keep the side stream busy ahead of the producers
+                    burn = burn @ burn * 1e-3
+                f = ab.synth_fields_device(ni, nj)                    # written on the side stream (torch's current stream)
+                for k in junk:
+                    junk[k].copy_(f[k])
+                lon.fill_(0.0)
+                rep = s.init(*[junk[k] for k in IN6], rad_sw=junk["rad_lw"], rad_lw=junk["rad_lw"])
+                s.set_solar_time(12, lon)
+                o = s.compute(1, 2.0, 10.0, *[junk[k] for k in IN6], Niter=5, rad_sw=junk["rad_sw"], rad_lw=junk["rad_lw"])
+            assert rep["hum_type"] == "sh" and rep["n_masked"] == 0, rep
+            with ab.Session("coare3p6", ni, nj, 2, True) as s2:
+                ref = s2.compute(1, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+            for k in o:
+                assert torch.equal(o[k], ref[k]), k

@@ -1,0 +1,233 @@
+"""GPU: row-block sharding INSIDE the library (ab_session_create_sharded / AB_DEVICE_ALL / AEROBULK_AMD_DEVICES), exercised on
+one GPU with k shards on it: every result must be bit-identical to the unsharded session (pointwise path), the
+AEROBULK_INIT statistics — the one exchange of the path — must combine to the global report, errors must come through."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+IN6 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")
+OUT = ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")
+
+
+def _run(ab, f, device, algo="coare3p6", skin=True, nt=3, ni=360, nj=181, niter=5, to_device=False):
+    import torch
+    conv = (lambda a: torch.from_numpy(a).cuda()) if to_device else (lambda a: a)
+    ins = [conv(f[k]) for k in IN6]
+    rs, rl = (conv(f["rad_sw"]), conv(f["rad_lw"])) if skin else (None, None)
+    recs = []
+    with ab.Session(algo, ni, nj, nt, skin, device=device) as s:
+        rep = s.init(*ins, rad_sw=rl, rad_lw=rl)
+        for jt in range(1, nt + 1):
+            o = s.compute(jt, 2.0, 10.0, *ins, Niter=niter, rad_sw=rs, rad_lw=rl)
+            recs.append({k: (v.cpu().numpy() if to_device else np.array(v)) for k, v in o.items()})
+        wl = s.wl_state() if (skin and nt > 1) else None
+        shards = s.shards()
+    return rep, recs, wl, shards
+
+
+@pytest.mark.parametrize("to_device", [False, True], ids=["host-arrays", "device-arrays"])
+@pytest.mark.parametrize("algo,skin", [("coare3p6", True), ("ecmwf", True), ("ncar", False)])
+def test_k_shards_on_one_gpu_are_bit_identical(oracle, algo, skin, to_device):
+    import aerobulk_amd as ab
+    ni, nj = 360, 181                                   # 181 rows over 3 shards: 61 + 60 + 60
+    f = oracle.synth_fields(ni, nj)
+    nt = 3 if skin else 1
+    rep1, one, wl1, sh1 = _run(ab, f, 0, algo, skin, nt, ni, nj, to_device=to_device)
+    repk, many, wlk, shk = _run(ab, f, [0, 0, 0], algo, skin, nt, ni, nj, to_device=to_device)
+    assert sh1 == [(0, nj, 0)] and shk == [(0, 61, 0), (61, 60, 0), (121, 60, 0)]
+    assert rep1 == repk and rep1["hum_type"] == "sh" and rep1["n_masked"] == 0
+    for jt, (a, b) in enumerate(zip(one, many), 1):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{algo} jt={jt} {k}")
+    if wl1 is not None:
+        for k in wl1:
+            np.testing.assert_array_equal(wl1[k], wlk[k], err_msg=k)
+
+
+def test_sharded_pipelined_host_path_large_grid(oracle):
+    """Each shard >= 4 Mi cells: every shard takes the chunk-pipelined host path (its own three streams + drain thread),
+    concurrently with the others; AB_DEVICE_ALL on a one-GPU box is an ordinary session."""
+    import aerobulk_amd as ab
+    ni, nj = 2200, 4003                                  # 8.8 M cells, two shards of 2002 / 2001 rows
+    f = oracle.synth_fields(ni, nj)
+    ins = [f[k] for k in IN6]
+    with ab.Session("coare3p6", ni, nj, 1, True, device="all") as s:
+        assert len(s.shards()) == max(1, ab.device_count())
+        one = s.compute(1, 2.0, 10.0, *ins, Niter=4, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+    with ab.Session("coare3p6", ni, nj, 1, True, device=[0, 0]) as s:
+        two = s.compute(1, 2.0, 10.0, *ins, Niter=4, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+        assert s.last_kernel_ms() > 0
+    for k in one:
+        np.testing.assert_array_equal(one[k], two[k], err_msg=k)
+
+
+def test_sharded_init_conditions_and_errors(oracle):
+    """AEROBULK_INIT decisions on the combined statistics: a masked cell in ONE shard is counted once, a humidity field that only
+    looks like 'rh' in one shard is judged on the whole domain, a 10 N/m2 cell in one shard fails the record."""
+    import aerobulk_amd as ab
+    ni, nj = 128, 66
+    f = oracle.synth_fields(ni, nj)
+    n = ni * nj
+    ins = {k: f[k].copy() for k in IN6}
+    ins["sst"][n - 5] = 400.0                            # silly cell in the last shard: masked, not an error
+    with ab.Session("ncar", ni, nj, 1, False, device=[0, 0, 0]) as s:
+        rep = s.init(*[ins[k] for k in IN6])
+        assert rep["n_masked"] == 1 and rep["hum_type"] == "sh"
+    bad = {k: f[k].copy() for k in IN6}
+    bad["hum_zt"][: n // 2] = 500.0                      # neither sh, dp nor rh once the halves are combined
+    with ab.Session("ncar", ni, nj, 1, False, device=[0, 0]) as s:
+        with pytest.raises(ab.AerobulkError) as e:
+            s.init(*[bad[k] for k in IN6])
+        assert e.value.status == 6
+    wild = {k: f[k].copy() for k in IN6}
+    wild["u_zu"][3] = 49.0; wild["v_zu"][3] = 0.0; wild["t_zt"][3] = wild["sst"][3] - 12.0   # first shard only
+    with ab.Session("coare3p6", ni, nj, 1, False, device=[0, 0, 0]) as s:
+        try:
+            s.compute(1, 2.0, 10.0, *[wild[k] for k in IN6], Niter=5)
+            tripped = False
+        except ab.AerobulkError as e:
+            tripped = e.status == 8
+    with ab.Session("coare3p6", ni, nj, 1, False) as s:
+        try:
+            s.compute(1, 2.0, 10.0, *[wild[k] for k in IN6], Niter=5)
+            tripped1 = False
+        except ab.AerobulkError as e:
+            tripped1 = e.status == 8
+    assert tripped == tripped1
+
+
+def test_device_arrays_on_another_gpu_are_refused():
+    import torch
+    import aerobulk_amd as ab
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ni, nj = 64, 8
+    f = ab.synth_fields_device(ni, nj, device=torch.device("cuda", 0))
+    with ab.Session("ncar", ni, nj, 1, False, device=[0, 1]) as s:
+        with pytest.raises(ab.AerobulkError) as e:
+            s.compute(1, 2.0, 10.0, *[f[k] for k in ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp")])
+        assert e.value.status == 10
+
+
+def test_aerobulk_model_over_shards_through_the_environment(oracle, tmp_path):
+    """AEROBULK_MODEL (process-global session, the reference's calling convention) spread over shards by AEROBULK_AMD_DEVICES,
+    no change to the caller: same results as unset, warm-layer state carried per shard over jt = 1..3."""
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import aerobulk_amd as ab
+from oracle import pyoracle as po
+ni, nj = 96, 50
+f = po.synth_fields(ni, nj)
+F = {k: v.reshape((ni, nj), order="F") for k, v in f.items()}
+args = [F[k] for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")]
+out = []
+for jt in (1, 2, 3):
+    r = ab.aerobulk_model(jt, 3, "coare3p6", 2.0, 10.0, *args, Niter=5, l_use_skin=True, rad_sw=F["rad_sw"], rad_lw=F["rad_lw"])
+    out.append(np.stack([r[k] for k in ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")]))
+np.save(sys.argv[2], np.stack(out))
+'''
+    res = {}
+    for tag, env in (("one", None), ("three", "0,0,0"), ("count", "1")):
+        e = dict(os.environ)
+        e.pop("AEROBULK_AMD_DEVICES", None)
+        if env:
+            e["AEROBULK_AMD_DEVICES"] = env
+        out = str(tmp_path / f"{tag}.npy")
+        pr = subprocess.run([sys.executable, "-c", script, ROOT, out], env=e, capture_output=True, text=True, timeout=600)
+        assert pr.returncode == 0, pr.stdout + pr.stderr
+        res[tag] = np.load(out)
+    np.testing.assert_array_equal(res["one"], res["three"])
+    np.testing.assert_array_equal(res["one"], res["count"])
+    assert np.abs(res["one"][0, 5] - res["one"][2, 5]).max() > 1e-6      # the warm layer did evolve
+
+
+def test_sharded_turb_and_diagnostics(oracle):
+    """TURB_COARE3P6 with both skin schemes and the OPTIONAL outputs through a sharded session: slices of the caller's arrays."""
+    import aerobulk_amd as ab
+    ni, nj = 200, 31
+    n = ni * nj
+    f = oracle.synth_fields(ni, nj)
+    theta = f["t_zt"] + 0.02
+    ssq = 0.98 * np.array([oracle.lib().abo_q_sat(t, p) for t, p in zip(f["sst"], f["slp"])])
+    qsw = 0.934 * f["rad_sw"]
+
+    def run(device):
+        with ab.Session("coare3p6", ni, nj, 1, False, device=device) as s:
+            d = s.set_diagnostics(["u_star", "dT_cs", "Hz_wl"])
+            T_s, q_s = f["sst"].copy(), ssq.copy()
+            o = s.turb(1, 2.0, 10.0, T_s, theta, q_s, f["hum_zt"], np.hypot(f["u_zu"], f["v_zu"]), True, True, qsw, f["rad_lw"], f["slp"], nb_iter=5)
+            return {**{k: np.array(v) for k, v in o.items()}, **{k: np.array(v) for k, v in d.items()}, "T_s": T_s, "q_s": q_s}
+
+    a, b = run(0), run([0, 0, 0, 0])
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert np.abs(a["T_s"] - f["sst"]).max() > 0.05
+
+
+def _rank_worker(rank, world, port, ni, nj, out_path):
+    """One rank of a 2-process run (gloo rendezvous, both ranks on the one GPU of the test box): its half of the rows goes through
+    a SHARDED session of two shards; AEROBULK_INIT's statistics are all-reduced between the ranks (SUM / MIN / MAX)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import aerobulk_amd as ab
+    from oracle import pyoracle as po
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = -(-nj // world)
+    j0 = rank * per
+    njl = min(per, nj - j0)
+    f = po.synth_fields(ni, nj, j0, njl)
+    ins = [f[k] for k in IN6]
+    with ab.Session("coare3p6", ni, njl, 2, True, device=[0, 0]) as s:
+        st = torch.from_numpy(s.init_stats(*ins, rad_sw=f["rad_lw"], rad_lw=f["rad_lw"]))
+        a, b, c = st[0:11].clone(), st[11:20].clone(), st[20:29].clone()
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        dist.all_reduce(b, op=dist.ReduceOp.MIN)
+        dist.all_reduce(c, op=dist.ReduceOp.MAX)
+        rep = s.init_apply(torch.cat([a, b, c]).numpy(), have_rad=True)
+        assert rep["n_cells"] == ni * nj and rep["hum_type"] == "sh", rep
+        recs = []
+        for jt in (1, 2):
+            o = s.compute(jt, 2.0, 10.0, *ins, Niter=5, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+            recs.append(np.stack([o[k] for k in OUT]))
+    mine = torch.from_numpy(np.stack(recs))                       # [2, 6, n_local]
+    pad = torch.zeros((2, 6, ni * per), dtype=torch.float64)
+    pad[:, :, :ni * njl] = mine
+    gl = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, gl, dst=0)
+    if rank == 0:
+        parts = [gl[r][:, :, :ni * min(per, nj - r * per)].numpy() for r in range(world)]
+        np.save(out_path, np.concatenate(parts, axis=2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_each_with_a_sharded_session(oracle, tmp_path):
+    import torch.multiprocessing as mp
+    import aerobulk_amd as ab
+    ni, nj, world = 160, 45, 2
+    ctx = mp.get_context("spawn")
+    out = str(tmp_path / "glob.npy")
+    port = 23000 + (os.getpid() % 4000)
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, ni, nj, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    glob = np.load(out)
+    f = oracle.synth_fields(ni, nj)
+    with ab.Session("coare3p6", ni, nj, 2, True) as s:
+        for jt in (1, 2):
+            o = s.compute(jt, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+            for i, k in enumerate(OUT):
+                np.testing.assert_array_equal(glob[jt - 1, i], o[k], err_msg=f"jt={jt} {k}")
