@@ -16,10 +16,12 @@
 
 namespace ab {
 
-template <class R> struct FluxArgs {
-    const R *sst, *t_zt, *hum, *u, *v, *slp, *rad_sw, *rad_lw, *lon;
-    R *ql, *qh, *tau_x, *tau_y, *evap, *t_s;
-    R *wl0, *wl1, *wl2, *wl3;
+// R: arithmetic type of the cell; S: element type of the caller's arrays and of the warm-layer planes (S = float with
+// R = double is the AB_F32_STORAGE session: half the HBM traffic and footprint, full fp64 arithmetic)
+template <class R, class S = R> struct FluxArgs {
+    const S *sst, *t_zt, *hum, *u, *v, *slp, *rad_sw, *rad_lw, *lon;
+    S *ql, *qh, *tau_x, *tau_y, *evap, *t_s;
+    S *wl0, *wl1, *wl2, *wl3;
     int *flags;
     long n;
     Heights<R> h;
@@ -29,8 +31,8 @@ template <class R> struct FluxArgs {
 };
 
 // optional per-cell diagnostics of TURB_* (ab_session_set_diagnostics); read only by the DIAG instantiations
-template <class R> struct DiagArgs {
-    R *p[16];   // Cd Ch Ce t_zu q_zu Ubzu | CdN ChN CeN z0 u_star L UN10 | dT_cs dT_wl Hz_wl ; nullptr = not wanted
+template <class S> struct DiagArgs {
+    S *p[16];   // Cd Ch Ce t_zu q_zu Ubzu | CdN ChN CeN z0 u_star L UN10 | dT_cs dT_wl Hz_wl ; nullptr = not wanted
 };
 
 // ---- lane regrouping ---------------------------------------------------------------------------------------------
@@ -48,8 +50,8 @@ template <class R> struct DiagArgs {
 // loads and stores stay coalesced and each field is still read once and written once.
 // One cell from its pre-processed inputs to the six outputs of aerobulk_compute: TURB_<algo> (mod_aerobulk_compute.f90
 // :129-176), BULK_FORMULA and the stress vector (:184-194).  k: global cell index (warm-layer state, diagnostics, longitude).
-template <class R, int ALGO, bool SKIN, bool DIAG, bool TILED = false>
-__device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArgs<R> &dg, const Heights<R> &hh, int nb_iter, long k, R sst,
+template <class R, int ALGO, bool SKIN, bool DIAG, bool TILED = false, class S = R>
+__device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const DiagArgs<S> &dg, const Heights<R> &hh, int nb_iter, long k, R sst,
                                              R theta_zt, R q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
                                              R &zEvap, R &T_s, lds_cvptr<R> pu = nullptr, lds_cvptr<R> pv = nullptr,
                                              lds_vptr<R> park = nullptr, int pstride = 0)
@@ -75,7 +77,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
         } else {  // COARE3Px_INIT mod_blk_coare3p6.f90:84-87 ; ECMWF_INIT mod_blk_ecmwf.f90:403-404
             wl[1] = (ALGO == 4) ? R(3.) : R(20.);
         }
-        if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>(a.lon[k], a.isecday) : (a.dawn_uniform != 0);
+        if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>((R)a.lon[k], a.isecday) : (a.dawn_uniform != 0);
     }
 
     CellOut<R> o;
@@ -90,12 +92,12 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
                          o.dT_cs, o.dT_wl, o.Hz_wl};
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (dg.p[i]) dg.p[i][k] = d[i];
+            if (dg.p[i]) dg.p[i][k] = (S)d[i];
     }
     if (SKIN && a.wl_store) {
-        a.wl0[k] = wl[0];
-        a.wl1[k] = wl[1];
-        if (ALGO != 4) { a.wl2[k] = wl[2]; a.wl3[k] = wl[3]; }
+        a.wl0[k] = (S)wl[0];
+        a.wl1[k] = (S)wl[1];
+        if (ALGO != 4) { a.wl2[k] = (S)wl[2]; a.wl3[k] = (S)wl[3]; }
     }
 
     R zTaum;
@@ -117,27 +119,27 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R> &a, const DiagArg
     T_s = o.T_s;
 }
 
-template <class R, int ALGO, bool SKIN, bool DIAG>
-__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R> a, const DiagArgs<R> dg)
+template <class R, int ALGO, bool SKIN, bool DIAG, class S = R>
+__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R, S> a, const DiagArgs<S> dg)
 {
     math_tables_init<R>();
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
         if (k >= a.n) return;
-        const R slp = a.slp[k], t_zt = a.t_zt[k], hum = a.hum[k];
+        const R slp = (R)a.slp[k], t_zt = (R)a.t_zt[k], hum = (R)a.hum[k];
         R q_zt;
         if (a.hum_type == 0) q_zt = hum;
         else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));
         else q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));
         R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG>(a, dg, a.h, a.nb_iter, k, a.sst[k], theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt), q_zt, a.u[k],
-                                          a.v[k], slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
-        a.ql[k] = QL;
-        a.qh[k] = QH;
-        a.tau_x[k] = tx;
-        a.tau_y[k] = ty;
-        if (a.evap) a.evap[k] = zEvap;
-        if (a.t_s) a.t_s[k] = T_s;
+        compute_cell<R, ALGO, SKIN, DIAG, false, S>(a, dg, a.h, a.nb_iter, k, (R)a.sst[k], theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt), q_zt,
+                                                    (R)a.u[k], (R)a.v[k], slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
+        a.ql[k] = (S)QL;
+        a.qh[k] = (S)QH;
+        a.tau_x[k] = (S)tx;
+        a.tau_y[k] = (S)ty;
+        if (a.evap) a.evap[k] = (S)zEvap;
+        if (a.t_s) a.t_s[k] = (S)T_s;
         return;
     }
     using T = Tile<R, ALGO, SKIN>;
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         const long k = tile0 + j;
         int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
         if (k < a.n) {
-            const R sst = a.sst[k], t_zt = a.t_zt[k], hum = a.hum[k], uu = a.u[k], vv = a.v[k], slp = a.slp[k];
+            const R sst = (R)a.sst[k], t_zt = (R)a.t_zt[k], hum = (R)a.hum[k], uu = (R)a.u[k], vv = (R)a.v[k], slp = (R)a.slp[k];
             R q_zt;
             if (a.hum_type == 0) q_zt = hum;                                        // 'sh'
             else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));   // 'dp' :103
@@ -167,8 +169,8 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
             s_f[0][j] = sst; s_f[1][j] = theta; s_f[2][j] = q_zt; s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
             R qsw = R(0.), rlw = R(0.);
             if (SKIN) {
-                qsw = (R(1.) - K<R>::roce_alb0) * a.rad_sw[k];                      // :135,146,161
-                rlw = a.rad_lw[k];
+                qsw = (R(1.) - K<R>::roce_alb0) * (R)a.rad_sw[k];                   // :135,146,161
+                rlw = (R)a.rad_lw[k];
                 s_f[SKIN ? 6 : 0][j] = qsw; s_f[SKIN ? 7 : 0][j] = rlw;
             }
             if (a.regroup) {
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         if (k >= a.n) continue;
 
         R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG, true>(a, dg, hh, nb_iter, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
+        compute_cell<R, ALGO, SKIN, DIAG, true, S>(a, dg, hh, nb_iter, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
                                           SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
                                           ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
                                           // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare
@@ -223,27 +225,27 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
         const int j = r * kBlock + tid;
         const long k = tile0 + j;
         if (k >= a.n) break;
-        a.ql[k] = s_f[0][j];
-        a.qh[k] = s_f[1][j];
-        a.tau_x[k] = s_f[2][j];
-        a.tau_y[k] = s_f[3][j];
-        if (a.evap) a.evap[k] = s_f[4][j];                                         // :208
-        if (a.t_s) a.t_s[k] = s_f[5][j];                                           // :206
+        a.ql[k] = (S)s_f[0][j];
+        a.qh[k] = (S)s_f[1][j];
+        a.tau_x[k] = (S)s_f[2][j];
+        a.tau_y[k] = (S)s_f[3][j];
+        if (a.evap) a.evap[k] = (S)s_f[4][j];                                      // :208
+        if (a.t_s) a.t_s[k] = (S)s_f[5][j];                                        // :206
     }
 }
 
-template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
+template <class R, int ALGO, bool SKIN, class S = R> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
 {
-    DiagArgs<R> dg;
+    DiagArgs<S> dg;
     bool diag = false;
-    for (int i = 0; i < 16; ++i) { dg.p[i] = (R *)c.diag[i]; diag = diag || (c.diag[i] != nullptr); }
-    FluxArgs<R> a;
-    a.sst = (const R *)c.sst; a.t_zt = (const R *)c.t_zt; a.hum = (const R *)c.hum;
-    a.u = (const R *)c.u; a.v = (const R *)c.v; a.slp = (const R *)c.slp;
-    a.rad_sw = (const R *)c.rad_sw; a.rad_lw = (const R *)c.rad_lw; a.lon = (const R *)c.lon;
-    a.ql = (R *)c.ql; a.qh = (R *)c.qh; a.tau_x = (R *)c.tau_x; a.tau_y = (R *)c.tau_y;
-    a.evap = (R *)c.evap; a.t_s = (R *)c.t_s;
-    a.wl0 = (R *)c.wl[0]; a.wl1 = (R *)c.wl[1]; a.wl2 = (R *)c.wl[2]; a.wl3 = (R *)c.wl[3];
+    for (int i = 0; i < 16; ++i) { dg.p[i] = (S *)c.diag[i]; diag = diag || (c.diag[i] != nullptr); }
+    FluxArgs<R, S> a;
+    a.sst = (const S *)c.sst; a.t_zt = (const S *)c.t_zt; a.hum = (const S *)c.hum;
+    a.u = (const S *)c.u; a.v = (const S *)c.v; a.slp = (const S *)c.slp;
+    a.rad_sw = (const S *)c.rad_sw; a.rad_lw = (const S *)c.rad_lw; a.lon = (const S *)c.lon;
+    a.ql = (S *)c.ql; a.qh = (S *)c.qh; a.tau_x = (S *)c.tau_x; a.tau_y = (S *)c.tau_y;
+    a.evap = (S *)c.evap; a.t_s = (S *)c.t_s;
+    a.wl0 = (S *)c.wl[0]; a.wl1 = (S *)c.wl[1]; a.wl2 = (S *)c.wl[2]; a.wl3 = (S *)c.wl[3];
     a.flags = c.flags;
     a.n = c.n;
     a.h = make_heights<R>(c.zt, c.zu);
@@ -256,25 +258,26 @@ template <class R, int ALGO, bool SKIN> static hipError_t launch_t(const FluxCal
     const long tile = (ALGO == 3) ? kBlock : rounds * kBlock;
     const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;
-    if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
-    else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
+    if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true, S>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
+    else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false, S>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     return hipGetLastError();
 }
 
-template <class R> static hipError_t launch_r(const FluxCall &c, hipStream_t s)
+template <class R, class S = R> static hipError_t launch_r(const FluxCall &c, hipStream_t s)
 {
     switch (c.algo) {
-    case 1: return c.skin ? launch_t<R, 1, true>(c, s) : launch_t<R, 1, false>(c, s);
-    case 2: return c.skin ? launch_t<R, 2, true>(c, s) : launch_t<R, 2, false>(c, s);
-    case 3: return launch_t<R, 3, false>(c, s);
-    case 4: return c.skin ? launch_t<R, 4, true>(c, s) : launch_t<R, 4, false>(c, s);
-    case 5: return launch_t<R, 5, false>(c, s);
+    case 1: return c.skin ? launch_t<R, 1, true, S>(c, s) : launch_t<R, 1, false, S>(c, s);
+    case 2: return c.skin ? launch_t<R, 2, true, S>(c, s) : launch_t<R, 2, false, S>(c, s);
+    case 3: return launch_t<R, 3, false, S>(c, s);
+    case 4: return c.skin ? launch_t<R, 4, true, S>(c, s) : launch_t<R, 4, false, S>(c, s);
+    case 5: return launch_t<R, 5, false, S>(c, s);
     default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_flux(const FluxCall &c, hipStream_t stream)
 {
+    if (c.f32 && c.compute64) return launch_r<double, float>(c, stream);   // AB_F32_STORAGE
     return c.f32 ? launch_r<float>(c, stream) : launch_r<double>(c, stream);
 }
 

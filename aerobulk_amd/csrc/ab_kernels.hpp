@@ -19,7 +19,8 @@ struct FluxCall {
     double zt, zu;
     int algo;       // enum ab_algo
     int skin;       // cool-skin + warm-layer
-    int f32;        // element type
+    int f32;        // element type of the arrays
+    int compute64;  // with f32: fp64 arithmetic on fp32 arrays (AB_F32_STORAGE)
     int nb_iter;
     int hum_type;   // enum ab_hum
     int wl_load;    // jt > 1: read state ; else initial values

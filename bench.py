@@ -6,13 +6,20 @@ cool-skin/warm-layer on the 4320x3600 ORCA12 grid, fp64, inputs resident in HBM 
 region starts.  A "step" = one pass of the hot path over the whole grid (+ the RCCL gather of the
 output fields to rank 0 when N > 1; the grid is j-block sharded across ranks: strong scaling).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--algo coare3p6] [--no-skin] [--niter 5]
-                    [--grid 4320x3600] [--precision f64] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--algo ..] [--no-skin] [--niter 5]
+                    [--grid 4320x3600] [--precision f64] [--resident] [--no-cpu-baseline]
 
+--config picks a BASELINE.json configuration (default 3 = the headline):
+   2  COARE3p6, no skin, 1440x1080, nb_iter=8
+   3  COARE3p6 + cool-skin/warm-layer, 4320x3600, nb_iter=5
+   4  all five algorithms back-to-back on 4320x3600 (no skin scheme for any: one consistent setting; --skin adds
+      the scheme for the three algorithms that have one); a step = the five passes; value = 5 x cells per step
+   5  ECMWF + cool-skin/warm-layer, fp32 path, 12960x10800
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,8 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TF = 78.6   # fp64 vector (VALU) peak, same guide: half the 157.3 TFLOP/s fp32 vector rate
 IN6 = ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp")
+SKIN_ALGOS = ("coare3p0", "coare3p6", "ecmwf")
+ALL_ALGOS = ("coare3p0", "coare3p6", "ncar", "ecmwf", "andreas")
+PMC_JSON = os.path.join(ROOT, "profiles", "r2_pmc.json")
 
 
 def algorithmic_bytes_per_cell(skin, esz):
@@ -31,23 +42,37 @@ def algorithmic_bytes_per_cell(skin, esz):
     return (8 + 6) * esz if skin else (6 + 5) * esz
 
 
+def kernel_source_hash():
+    """Identity of the device code the committed PMC profile was taken with: the kernel sources and the compile flags
+    (aerobulk_amd/build.py rebuilds libaerobulk_amd.so whenever one of them changes)."""
+    from aerobulk_amd import build as b
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "aerobulk_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(fh.read())
+    h.update(" ".join(b.HIPFLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def committed_pmc(algo, skin, ni, nj, niter, precision):
-    """PMC figures of the committed rocprofv3 run for exactly this workload (profiles/r1_pmc.json), or None.
-    bench.py cannot collect hardware counters itself; the numbers are measured by tools/prof_quick.sh on the same command."""
+    """Hardware-counter figures of the committed rocprofv3 run of exactly this workload (profiles/r2_pmc.json, written by
+    tools/update_pmc.py from a tools/prof_quick.sh run), or None.  bench.py cannot collect counters itself.  They are only
+    quoted when the profile was taken with the device code that is running now (source hash), and every figure derived from
+    them uses the PROFILE's own kernel duration, never a live timing."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc.json")) as fh:
+        with open(PMC_JSON) as fh:
             p = json.load(fh)
         c = p["config"]
-        if (c["algo"], c["skin"], list(c["grid"]), c["nb_iter"], c["precision"]) == (algo, skin, [ni, nj], niter, precision):
-            return p
+        if (c["algo"], c["skin"], list(c["grid"]), c["nb_iter"], c["precision"]) != (algo, skin, [ni, nj], niter, precision):
+            return None
+        if p.get("source_hash") != kernel_source_hash():
+            return {"stale": True, "source": p.get("source")}
+        return p
     except Exception:
-        pass
-    return None
-
-
-def fp64_flops(pmc):
-    f = pmc["fp64_insts_per_launch"]
-    return 64.0 * (2.0 * f["fma"] + f["mul"] + f["add"] + f["trans"])
+        return None
 
 
 def shard_rows(nj, world, rank):
@@ -106,18 +131,46 @@ def cpu_baseline(algo, skin, niter, zt, zu):
                       f"same synthetic fields (slowest {max(secs):.1f} s); one process alone on {ni}x{nj}: {dt1:.1f} s"}
 
 
+def resolve_config(a):
+    """(passes, grid, precision, niter, label): passes = [(algo, skin)] run back-to-back in one step."""
+    explicit_grid = a.grid is not None
+    if a.config == 2:
+        passes, grid, prec, niter = [("coare3p6", False)], "1440x1080", "f64", 8
+    elif a.config == 4:
+        passes = [(al, bool(a.skin) and al in SKIN_ALGOS) for al in ALL_ALGOS]
+        grid, prec, niter = "4320x3600", "f64", 5
+    elif a.config == 5:
+        passes, grid, prec, niter = [("ecmwf", True)], "12960x10800", "f32", 5
+    else:
+        skin = (not a.no_skin) and a.algo in SKIN_ALGOS
+        passes, grid, prec, niter = [(a.algo, skin)], "4320x3600", "f64", 5
+    if explicit_grid:
+        grid = a.grid
+    if a.precision is not None:
+        prec = a.precision
+    if a.niter is not None:
+        niter = a.niter
+    return passes, grid, prec, niter
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5], help="BASELINE.json configuration (see the module docstring)")
     ap.add_argument("--algo", default="coare3p6")
     ap.add_argument("--no-skin", action="store_true")
-    ap.add_argument("--niter", type=int, default=5)
-    ap.add_argument("--grid", default="4320x3600")
-    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--skin", action="store_true", help="config 4: switch the skin scheme on for the three algorithms that have one")
+    ap.add_argument("--niter", type=int, default=None)
+    ap.add_argument("--grid", default=None)
+    ap.add_argument("--precision", default=None, choices=["f64", "f32", "f32_storage"],
+                    help="f32_storage: fp32 arrays with fp64 arithmetic (AB_F32_STORAGE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather (kernel-only scaling)")
+    ap.add_argument("--resident", "--no-gather", dest="resident", action="store_true",
+                    help="N>1: the fluxes stay on the GPU that computed them (what a GPU-resident ocean model consumes): no gather "
+                         "in the timed region.  Without this flag the gathered run is the headline and the resident rate is "
+                         "measured after it and reported as `resident`")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 collective backend; gloo (outputs staged through host memory) exists only so that the sharded "
                          "path can be exercised on a box with fewer GPUs than ranks")
@@ -129,8 +182,8 @@ def main():
                     help="N>1 with the gather: rows owned by each of the ranks 1..N-1 (rank 0, the gather's destination, owns the "
                          "rest).  0 = measured: link rate and kernel rate are timed during set-up and the split balances rank 0's "
                          "compute against its peers' compute + transfer; -1 = equal split")
-    ap.add_argument("--no-early-gather", action="store_true", help="N>1, RCCL: rank 0 joins the gather of chunk c after computing its "
-                                                                    "own chunk c (instead of before)")
+    ap.add_argument("--no-early-gather", action="store_true", help="N>1: rank 0 joins the gather of a chunk after computing its "
+                                                                    "own chunk (instead of before)")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row sub-blocks per rank (gather of one overlaps compute of the next)")
     a = ap.parse_args()
 
@@ -147,6 +200,7 @@ def main():
     dev_index = local_rank if a.backend == "nccl" else local_rank % max(ngpu, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")     # where collective payloads live
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -156,15 +210,19 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    ni, nj = (int(x) for x in a.grid.lower().split("x"))
-    skin = (not a.no_skin) and a.algo in ("coare3p0", "coare3p6", "ecmwf")
+    passes, grid, precision, niter = resolve_config(a)
+    ni, nj = (int(x) for x in grid.lower().split("x"))
+    npass = len(passes)
+    any_skin = any(sk for _, sk in passes)
     zt, zu = 2.0, 10.0
-    esz = 8 if a.precision == "f64" else 4
-    tdt = torch.float64 if a.precision == "f64" else torch.float32
-    nout = 6 if skin else 5
+    esz = 8 if precision == "f64" else 4
+    tdt = torch.float64 if precision == "f64" else torch.float32
+    dtype_label = {"f64": "f64", "f32": "f32", "f32_storage": "f32 arrays / f64 arithmetic"}[precision]
+    nout = 6 if any_skin else 5
     names = ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")[:nout]
     ngat = nout if a.gather_ts else 5            # fields that travel to rank 0
-    gathered = world > 1 and not a.no_gather
+    gathered = world > 1 and not a.resident
+    head_algo, head_skin = passes[0]
 
     # ---- sharding.  Without a gather: equal j-blocks.  With it: rank 0 (the destination) owns more rows than its peers
     # (shard_rows_root_heavy); how many is measured here unless --peer-rows says otherwise.
@@ -174,7 +232,7 @@ def main():
         if a.peer_rows == 0:
             # (1) what one link delivers when all peers send at once: a few gathers of 32 MB per rank
             nb = 4 * 1024 * 1024
-            tb = torch.zeros(nb, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            tb = torch.zeros(nb, dtype=torch.float64, device=cdev)
             tl = [torch.empty_like(tb) for _ in range(world)] if rank == 0 else None
             for _ in range(2):
                 dist.gather(tb, tl, dst=0)
@@ -187,24 +245,26 @@ def main():
             dist.barrier()
             t_gather = (time.perf_counter() - t0) / 5
             del tb, tl
-            decision = torch.zeros(1, dtype=torch.int64, device=dev if a.backend == "nccl" else "cpu")
+            decision = torch.zeros(1, dtype=torch.int64, device=cdev)
             if rank == 0:
                 try:
-                    # (2) what one GPU computes: the same kernel on ~1 M cells of the same fields
+                    # (2) what one GPU computes: the same kernels on ~1 M cells of the same fields
                     rs = max(1, min(nj, (1 << 20) // ni))
-                    fs = ab.synth_fields_device(ni, nj, 0, rs, precision=a.precision, device=dev, with_rad=True)
-                    with ab.Session(a.algo, ni, rs, 1, skin, precision=a.precision, device=dev_index) as ss:
-                        ss.set_humidity("sh")
-                        best = 1e9
-                        for it in range(40):
-                            ss.compute(1, zt, zu, *[fs[k] for k in IN6], Niter=a.niter, rad_sw=fs["rad_sw"] if skin else None,
-                                       rad_lw=fs["rad_lw"] if skin else None, want_T_s=skin, check=False)
-                            if it >= 30:
-                                best = min(best, ss.last_kernel_ms())
-                    t_cell = best * 1e-3 / (ni * rs)
+                    fs = ab.synth_fields_device(ni, nj, 0, rs, precision=precision, device=dev, with_rad=True)
+                    t_cell = 0.0
+                    for algo, skin in passes:
+                        with ab.Session(algo, ni, rs, 1, skin, precision=precision, device=dev_index) as ss:
+                            ss.set_humidity("sh")
+                            best = 1e9
+                            for it in range(40):
+                                ss.compute(1, zt, zu, *[fs[k] for k in IN6], Niter=niter, rad_sw=fs["rad_sw"] if skin else None,
+                                           rad_lw=fs["rad_lw"] if skin else None, want_T_s=skin, check=False)
+                                if it >= 30:
+                                    best = min(best, ss.last_kernel_ms())
+                        t_cell += best * 1e-3 / (ni * rs)
                     link = nb * 8 / t_gather
-                    rows_peer = balanced_peer_rows(nj, world, t_cell, ngat * esz, link)
-                    tune = {"link_GBps": round(link / 1e9, 1), "kernel_Mcell_per_s": round(1e-6 / t_cell, 1)}
+                    rows_peer = balanced_peer_rows(nj, world, t_cell, npass * ngat * esz, link)
+                    tune = {"link_GBps": round(link / 1e9, 1), "kernel_Mcell_per_s": round(npass * 1e-6 / t_cell, 1)}
                 except Exception as e:      # never lose the run to the tuning: equal split
                     tune = {"failed": str(e)}
                 decision[0] = rows_peer
@@ -226,16 +286,18 @@ def main():
     n_cpad = ni * cr
     n_gpad = ni * cr_peer                        # cells per gathered chunk
 
-    # synthetic inputs generated straight into HBM; outputs packed [chunk, field, cell] for ONE gather per chunk
-    f = ab.synth_fields_device(ni, nj, j0, max(njl, 1), precision=a.precision, device=dev, with_rad=True)
-    outbuf = torch.zeros((chunks, nout, n_cpad), dtype=tdt, device=dev)
+    # synthetic inputs generated straight into HBM; outputs packed [chunk, pass, field, cell]: ONE gather per
+    # chunk and pass
+    f = ab.synth_fields_device(ni, nj, j0, max(njl, 1), precision=precision, device=dev, with_rad=True)
+    outbuf = torch.zeros((chunks, npass, nout, n_cpad), dtype=tdt, device=dev)
     gather_lists = None
     send0 = None
     if gathered and rank == 0:     # rank 0's rows stay where they are; it joins the collective with an empty payload
-        gather_lists = [[torch.empty((ngat, n_gpad), dtype=tdt, device=dev) for _ in range(world)] for _ in range(chunks)]
-        send0 = torch.zeros((ngat, n_gpad), dtype=tdt, device=dev)
+        gather_lists = [[[torch.empty((ngat, n_gpad), dtype=tdt, device=cdev) for _ in range(world)] for _ in range(npass)]
+                        for _ in range(chunks)]
+        send0 = torch.zeros((ngat, n_gpad), dtype=tdt, device=cdev)
 
-    work = []  # (session, inputs, rad, out) per non-empty chunk
+    work = []  # per chunk: None (no rows) or the list over passes of (session, inputs, rad, out, skin)
     for c in range(chunks):
         r0 = min(c * cr, njl)
         rows = max(min(cr, njl - r0), 0)
@@ -243,41 +305,47 @@ def main():
             work.append(None)
             continue
         lo, hi = r0 * ni, (r0 + rows) * ni
-        sess = ab.Session(a.algo, ni, rows, 1, skin, precision=a.precision, device=dev_index)
-        sess.set_humidity("sh")
         ins = [f[k][lo:hi] for k in IN6]
-        rad = (f["rad_sw"][lo:hi], f["rad_lw"][lo:hi]) if skin else (None, None)
-        out = {k: outbuf[c, i, :rows * ni] for i, k in enumerate(names)}
-        work.append((sess, ins, rad, out))
+        per_pass = []
+        for p, (algo, skin) in enumerate(passes):
+            sess = ab.Session(algo, ni, rows, 1, skin, precision=precision, device=dev_index)
+            sess.set_humidity("sh")
+            rad = (f["rad_sw"][lo:hi], f["rad_lw"][lo:hi]) if skin else (None, None)
+            out = {k: outbuf[c, p, i, :rows * ni] for i, k in enumerate(names) if (k != "T_s" or skin)}
+            per_pass.append((sess, ins, rad, out, skin))
+        work.append(per_pass)
 
     # Rank 0 contributes nothing to the gather (its rows stay where they are) but is the destination of every peer, and it owns
-    # the largest block.  With RCCL it therefore joins the gather of chunk c BEFORE computing its own chunk c (the collective
-    # then only waits for rank 0's chunk c-1): a peer's chunk lands while rank 0 is still computing, and the last gather of a
-    # step overlaps rank 0's last chunk instead of following it.
-    early = gathered and rank == 0 and a.backend == "nccl" and not a.no_early_gather
+    # the largest block.  It therefore joins the gather of (chunk c, pass p) BEFORE computing its own (c, p) — the collective
+    # then only waits for the peers: a peer's chunk lands while rank 0 is still computing, and the last gather of a step
+    # overlaps rank 0's last kernel instead of following it.  The order of operations is the same for RCCL and for the gloo
+    # stand-in (which moves host copies of the payloads): post / compute / wait.
+    early = gathered and rank == 0 and not a.no_early_gather
 
-    def step():
+    def compute(c, p):
+        w = work[c]
+        if w is not None:
+            sess, ins, rad, out, skin = w[p]
+            sess.compute(1, zt, zu, *ins, Niter=niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
+
+    def step(with_gather=True):
         pending = []
         for c in range(chunks):
-            if early:
-                pending.append(dist.gather(send0, gather_lists[c], dst=0, async_op=True))
-            w = work[c]
-            if w is not None:
-                sess, ins, rad, out = w
-                sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
-            if gathered and not early:
-                payload = send0 if rank == 0 else outbuf[c, :ngat]
-                if a.backend == "nccl":
-                    pending.append(dist.gather(payload, gather_lists[c] if rank == 0 else None, dst=0, async_op=True))
-                else:  # test-only path: gloo gathers host tensors
-                    host = payload.cpu()
-                    gl = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                    dist.gather(host, gl, dst=0)
+            for p in range(npass):
+                g = gathered and with_gather
+                if g and early:
+                    pending.append(dist.gather(send0, gather_lists[c][p], dst=0, async_op=True))
+                compute(c, p)
+                if g and not early:
                     if rank == 0:
-                        for r in range(world):
-                            gather_lists[c][r].copy_(gl[r])
-        for p in pending:
-            p.wait()      # stream-level wait (does not block the host)
+                        pending.append(dist.gather(send0, gather_lists[c][p], dst=0, async_op=True))
+                    else:
+                        payload = outbuf[c, p, :ngat]
+                        if a.backend != "nccl":          # gloo moves host memory: the copy waits for the kernel
+                            payload = payload.cpu()
+                        pending.append(dist.gather(payload, None, dst=0, async_op=True))
+        for w_ in pending:
+            w_.wait()      # RCCL: stream-level wait (does not block the host); gloo: host wait
 
     def sync():
         torch.cuda.synchronize()
@@ -285,67 +353,75 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def assemble():
-        """rank 0: global fields [ngat, ni*nj]: its own block (never gathered) + the peers' gathered chunk buffers."""
+    def timed(nsteps, with_gather):
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step(with_gather)
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def assemble(p):
+        """rank 0: global fields [ngat, ni*nj] of pass p: its own block (never gathered) + the peers' gathered chunk buffers."""
         glob = torch.empty((ngat, ni * nj), dtype=tdt, device=dev)
         for c in range(chunks):                                   # own rows
             r0 = min(c * cr, njl)
             rows = max(min(cr, njl - r0), 0)
             if rows:
-                glob[:, r0 * ni:(r0 + rows) * ni] = outbuf[c, :ngat, :rows * ni]
+                glob[:, r0 * ni:(r0 + rows) * ni] = outbuf[c, p, :ngat, :rows * ni]
         for r in range(1, world):
             rj0, rnjl, _ = shard_rows_root_heavy(nj, world, r, rows_peer)
             for c in range(chunks):
                 r0 = min(c * cr_peer, rnjl)
                 rows = max(min(cr_peer, rnjl - r0), 0)
                 if rows:
-                    glob[:, (rj0 + r0) * ni:(rj0 + r0 + rows) * ni] = gather_lists[c][r][:, :rows * ni]
+                    glob[:, (rj0 + r0) * ni:(rj0 + r0 + rows) * ni] = gather_lists[c][p][r][:, :rows * ni].to(dev)
         return glob
 
     # pre-roll, part of the setup: the GPU raises its clocks during the first ~100 ms of sustained work (the first
     # configuration measured after start-up runs 5-8 % slow otherwise, profiles/r1_notes.md); then the W warm-up steps
-    for _ in range(40):          # the same count on every rank (step() contains the gather)
+    for _ in range(max(4, 40 // npass) if ni * nj <= 4320 * 3600 else 4):          # the same count on every rank (step() contains the gather)
         step()
     sync()
     for _ in range(a.warmup):
         step()
     sync()
     # timed region: EXACTLY K steps, no host sync inside
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(a.steps, True)
     for w in work:
         if w is not None:
-            w[0].check()
+            for t in w:
+                t[0].check()
+    # second number of a gathered run: the same K steps with the fluxes left where they were computed
+    elapsed_resident = timed(a.steps, False) if gathered else None
 
     # per-launch kernel duration: HIP events recorded by the library around each launch, on the launch stream.
     # Reading an event pair synchronises, so this is a separate pass over the same inputs (not in `elapsed`).
-    kdur = []
-    for _ in range(min(a.steps, 10)):
-        tot = 0.0
+    kms = [0.0] * npass
+    nrep = min(a.steps, 10)
+    for _ in range(nrep):
         for w in work:
             if w is not None:
-                sess, ins, rad, out = w
-                sess.compute(1, zt, zu, *ins, Niter=a.niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
-                tot += sess.last_kernel_ms()
-        kdur.append(tot)
-    k_ms = sum(kdur) / max(len(kdur), 1)
+                for p, (sess, ins, rad, out, skin) in enumerate(w):
+                    sess.compute(1, zt, zu, *ins, Niter=niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
+                    kms[p] += sess.last_kernel_ms() / nrep
+    k_ms = kms[0]
 
     verify_msg = None
     if a.verify and gathered and rank == 0:
-        glob = assemble()
-        ff = ab.synth_fields_device(ni, nj, precision=a.precision, device=dev, with_rad=True)
-        with ab.Session(a.algo, ni, nj, 1, skin, precision=a.precision, device=dev_index) as s1:
-            s1.set_humidity("sh")
-            one = s1.compute(1, zt, zu, *[ff[k] for k in IN6], Niter=a.niter, rad_sw=ff["rad_sw"] if skin else None,
-                             rad_lw=ff["rad_lw"] if skin else None, want_T_s=skin)
-        bad = [k for i, k in enumerate(names[:ngat]) if not torch.equal(glob[i], one[k])]
+        ff = ab.synth_fields_device(ni, nj, precision=precision, device=dev, with_rad=True)
+        bad = []
+        for p, (algo, skin) in enumerate(passes):
+            glob = assemble(p)
+            with ab.Session(algo, ni, nj, 1, skin, precision=precision, device=dev_index) as s1:
+                s1.set_humidity("sh")
+                one = s1.compute(1, zt, zu, *[ff[k] for k in IN6], Niter=niter, rad_sw=ff["rad_sw"] if skin else None,
+                                 rad_lw=ff["rad_lw"] if skin else None, want_T_s=skin)
+            bad += [f"{algo}:{k}" for i, k in enumerate(names[:ngat]) if k in one and not torch.equal(glob[i], one[k])]
         verify_msg = "gathered == single-GPU (bit-identical)" if not bad else f"MISMATCH in {bad}"
         if bad:
             raise SystemExit("verify failed: " + verify_msg)
@@ -353,50 +429,72 @@ def main():
     if rank == 0:
         cells = ni * nj
         ms_per_step = elapsed / a.steps * 1e3
-        value = cells * a.steps / elapsed / 1e6
-        bpc = algorithmic_bytes_per_cell(skin, esz)
+        value = npass * cells * a.steps / elapsed / 1e6
+        bpc = algorithmic_bytes_per_cell(head_skin, esz)
         achieved = bpc * n_local / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        pmc = committed_pmc(a.algo, skin, ni, nj, a.niter, a.precision) if world == 1 else None
+        pmc = committed_pmc(head_algo, head_skin, ni, nj, niter, precision) if world == 1 else None
+        fresh = bool(pmc) and not pmc.get("stale")
+        headline = (a.config == 3 and head_algo == "coare3p6" and head_skin and (ni, nj) == (4320, 3600))
+        what = " + ".join(f"{al}{' + cool-skin/warm-layer' if sk else ''}" for al, sk in passes)
+        prof = None
+        if fresh:
+            fl = pmc["fp64_insts_per_launch"]
+            t_prof = pmc["kernel_us_pmc_pass"] * 1e-6
+            tf = 64.0 * (2.0 * fl["fma"] + fl["mul"] + fl["add"] + fl["trans"]) / t_prof / 1e12
+            prof = {"source": pmc["source"], "source_hash": pmc["source_hash"], "kernel_ms_in_profile": round(t_prof * 1e3, 4),
+                    "hbm_traffic_bytes": round(pmc["traffic_bytes_per_launch"]),
+                    "valu_insts_per_cell": round(pmc["valu_insts_per_cell"]), "valu_issue_frac": round(pmc["valu_busy"], 3),
+                    "fp64_tflops": round(tf, 2), "fp64_peak_tflops": FP64_VECTOR_PEAK_TF, "fp64_frac": round(tf / FP64_VECTOR_PEAK_TF, 3)}
         res = {
-            "metric": "Mcell/s COARE3p6+cool-skin on 4320x3600 grid" if (a.algo == "coare3p6" and skin and (ni, nj) == (4320, 3600))
-                      else f"Mcell/s {a.algo}{'+skin' if skin else ''} on {ni}x{nj} grid",
+            "metric": "Mcell/s COARE3p6+cool-skin on 4320x3600 grid" if headline else f"Mcell/s {what} on {ni}x{nj} grid",
             "value": round(value, 2), "unit": "Mcell/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"{a.algo}{' + cool-skin/warm-layer' if skin else ''}, {ni}x{nj} grid, nb_iter={a.niter}, "
-                                   f"zt=2 zu=10, one time record (jt=1=Nt), inputs/outputs resident in HBM",
-                       "grid": [ni, nj], "algo": a.algo, "skin": skin, "nb_iter": a.niter,
-                       "sharding": f"j-block x{world}" + ("" if not gathered else
-                                                            f": rank 0 owns {nj - (world - 1) * rows_peer} rows, ranks 1..{world - 1} {rows_peer} rows each "
-                                                            f"(rank 0 is the gather's destination; its compute is balanced against the peers' compute + transfer)"
-                                                            f" + RCCL gather of {', '.join(names[:ngat])} to rank 0, {chunks} overlapped row chunks per rank"),
+            "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
+            "config": {"workload": f"BASELINE config {a.config}: {what}, {ni}x{nj} grid, nb_iter={niter}, zt=2 zu=10, one time record "
+                                   f"(jt=1=Nt){' per algorithm, the ' + str(npass) + ' passes back-to-back' if npass > 1 else ''}, "
+                                   f"inputs/outputs resident in HBM",
+                       "grid": [ni, nj], "algo": head_algo if npass == 1 else list(ALL_ALGOS), "skin": head_skin if npass == 1 else any_skin,
+                       "nb_iter": niter,
+                       "sharding": f"j-block x{world}" + (", fluxes stay on the GPU that computed them (no gather)" if (world > 1 and not gathered) else "")
+                                   + ("" if not gathered else
+                                      f": rank 0 owns {nj - (world - 1) * rows_peer} rows, ranks 1..{world - 1} {rows_peer} rows each "
+                                      f"(rank 0 is the gather's destination; its compute is balanced against the peers' compute + transfer)"
+                                      f" + {'RCCL' if a.backend == 'nccl' else 'gloo (host-staged stand-in)'} gather of {', '.join(names[:ngat])} to rank 0, "
+                                      f"{chunks} overlapped row chunks per rank, rank 0 joins each gather {'before' if early else 'after'} computing its own chunk"),
                        **({"sharding_tuning": tune} if tune else {})},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # The kernel is bound by fp64 VALU issue (hundreds of transcendentals per cell), not by HBM and not by MFMA (no
+            # contraction on this path).  achieved/peak/frac are the HBM figures BASELINE.json asks for (algorithmic bytes over the
+            # live kernel duration); `profile` holds the hardware-counter view of the binding resource, quoted only when the
+            # committed profile was taken with this very device code.
+            "roofline": {"bound": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": round(pmc["traffic_bytes_per_launch"]) if pmc else None,
-                         "kernel": f"flux_kernel<{a.precision},{a.algo},{'skin' if skin else 'noskin'}>",
+                         "traffic": prof["hbm_traffic_bytes"] if prof else None,
+                         "kernel": f"flux_kernel<{precision},{head_algo},{'skin' if head_skin else 'noskin'}>",
                          "kernel_ms": round(k_ms, 4), "bytes_per_cell": bpc, "cells_per_launch": n_local,
-                         "binding_resource": "fp64 VALU issue" if a.precision == "f64" else "fp32 VALU issue",
-                         "valu_busy": round(pmc["valu_busy"], 3) if pmc else None,
-                         "valu_insts_per_cell": round(pmc["valu_insts_per_cell"]) if pmc else None,
-                         # fp64 arithmetic actually issued (PMC wave-instruction counts x 64 lanes, an FMA = 2 flops) over the
-                         # live kernel time, against the fp64 vector peak (MI355X_MICROARCH.md: 78.6 TFLOP/s)
-                         "fp64_tflops": round(fp64_flops(pmc) / (k_ms * 1e-3) / 1e12, 2) if (pmc and k_ms > 0) else None,
-                         "fp64_vector_peak_tflops": 78.6,
-                         "note": "the kernel is VALU-bound (hundreds of fp64 transcendentals per cell), not HBM-bound; traffic/valu_* are "
-                                 "rocprofv3 PMC figures of the committed profile of this same command (profiles/), DESIGN.md §3.1"},
+                         "fp64_frac": prof["fp64_frac"] if prof else None,
+                         "valu_issue_frac": prof["valu_issue_frac"] if prof else None,
+                         "profile": prof if prof else ({"stale": "committed profile was taken with other device code: not quoted"} if pmc else None)},
         }
+        if npass > 1:
+            res["per_algorithm"] = {f"{al}{'+skin' if sk else ''}": {"kernel_ms": round(kms[p], 4),
+                                                                        "Mcell_per_s": round(n_local / kms[p] / 1e3, 1) if kms[p] > 0 else None}
+                                    for p, (al, sk) in enumerate(passes)}
+        if elapsed_resident is not None:
+            res["resident"] = {"value": round(npass * cells * a.steps / elapsed_resident / 1e6, 2), "unit": "Mcell/s",
+                               "ms_per_step": round(elapsed_resident / a.steps * 1e3, 4),
+                               "note": "the same K steps with the fluxes left on the GPU that computed them (no gather)"}
         if verify_msg:
             res["verify"] = verify_msg
         if not a.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(a.algo, skin, a.niter, zt, zu)
+                res["cpu_baseline"] = cpu_baseline(head_algo, head_skin, niter, zt, zu)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"value": None, "unit": "Mcell/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)
     for w in work:
         if w is not None:
-            w[0].close()
+            for t in w:
+                t[0].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,7 +9,7 @@
  * Data layout: every field is a flat, contiguous array of `ni*nj` cells (Fortran column-major
  * (Ni,Nj), i fastest — exactly what the reference's C shim sees as an (m,1) array,
  * mod_aerobulk_cxx.f90:40-44).  Element type is `double` for an AB_F64 session and `float`
- * for an AB_F32 session.  `mem` says where the caller's arrays live: AB_MEM_HOST (the
+ * for an AB_F32 / AB_F32_STORAGE session.  `mem` says where the caller's arrays live: AB_MEM_HOST (the
  * reference's calling convention; the library stages H2D/D2H) or AB_MEM_DEVICE (arrays are
  * already resident in HBM; nothing is copied and the call is asynchronous on `stream`).
  */
@@ -30,7 +30,9 @@ enum ab_algo { AB_ALGO_OTHER = 0, AB_ALGO_COARE3P0 = 1, AB_ALGO_COARE3P6 = 2, AB
 /* ctype_humidity 'sh' | 'dp' | 'rh', mod_const.f90:27 */
 enum ab_hum { AB_HUM_SH = 0, AB_HUM_DP = 1, AB_HUM_RH = 2 };
 enum ab_mem { AB_MEM_HOST = 0, AB_MEM_DEVICE = 1 };
-enum ab_precision { AB_F64 = 0, AB_F32 = 1 };
+/* AB_F32: fp32 arrays AND fp32 arithmetic (fastest; tolerance restated).  AB_F32_STORAGE: fp32 arrays (half the
+ * HBM footprint and traffic) with the fp64 arithmetic of AB_F64: results = the fp64 path on the rounded inputs, rounded once. */
+enum ab_precision { AB_F64 = 0, AB_F32 = 1, AB_F32_STORAGE = 2 };
 
 /* Error codes.  The reference has none: it prints and STOPs (mod_const.f90:238-278).  Each code
  * below names the reference condition it replaces; the Fortran host turns a non-zero code

@@ -146,18 +146,22 @@ def test_init_checks_on_gpu_match_reference_conditions(oracle):
         assert s.init(*base, rad_sw=lw, rad_lw=lw)["n_masked"] == 4
 
 
-@pytest.mark.parametrize("world,extra", [(2, []), (2, ["--peer-rows", "-1"]), (3, ["--peer-rows", "40", "--gather-ts"]), (4, [])])
+@pytest.mark.parametrize("world,extra", [(2, []), (2, ["--peer-rows", "-1", "--no-early-gather"]), (3, ["--peer-rows", "40", "--gather-ts"]),
+                                         (4, []), (2, ["--config", "4"]), (3, ["--config", "4", "--skin", "--no-early-gather", "--peer-rows", "50"]),
+                                         (2, ["--config", "5"]), (2, ["--config", "5", "--no-early-gather", "--peer-rows", "-1"]),
+                                         (2, ["--config", "2", "--peer-rows", "100"])])
 def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
-    """bench.py's N>1 path (root-heavy j-block sharding measured or given, row chunks, packed gather, reassembly) run as
-    several ranks that share the one visible GPU, with the gloo backend standing in for RCCL (RCCL refuses two ranks per
-    device).  --verify makes rank 0 recompute the whole grid alone and demand bit-identical gathered fields."""
+    """bench.py's N>1 path (root-heavy j-block sharding measured or given, row chunks, packed gather joined by rank 0 before or
+    after its own compute, reassembly; BASELINE configs 2-5) run as several ranks that share the one visible GPU, with the gloo
+    backend standing in for RCCL (RCCL refuses two ranks per device) in the same post / compute / wait order.  --verify makes
+    rank 0 recompute the whole grid alone and demand bit-identical gathered fields, for every algorithm of the step."""
     import sys
     import torch
     if torch.cuda.device_count() < 1:
         pytest.skip("no GPU")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29533 + world + len(extra)), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
-           "--warmup", "1", "--grid", "720x333", "--backend", "gloo", "--verify", "--chunks", "3", "--no-cpu-baseline", *extra]
+           "--master-port", str(29533 + world + 7 * len(extra) + len("".join(extra))), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+           "--steps", "2", "--warmup", "1", "--grid", "720x333", "--backend", "gloo", "--verify", "--chunks", "3", "--no-cpu-baseline", *extra]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -165,6 +169,13 @@ def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
     assert res["n_gpus"] == world and res["verify"].startswith("gathered == single-GPU")
     assert res["scaling"] == "strong" and res["value"] > 0
     assert "rank 0 owns" in res["config"]["sharding"]
+    assert ("after computing" if "--no-early-gather" in extra else "before computing") in res["config"]["sharding"]
+    assert res["resident"]["value"] > 0                      # the second number: fluxes left distributed
+    assert res["roofline"]["bound"] == "valu_fp64"
+    if "--config" in extra and extra[extra.index("--config") + 1] == "4":
+        assert len(res["per_algorithm"]) == 5 and all(v["Mcell_per_s"] > 0 for v in res["per_algorithm"].values())
+    if "--config" in extra and extra[extra.index("--config") + 1] == "5":
+        assert res["dtype"] == "f32" and "ecmwf + cool-skin" in res["config"]["workload"]
     if not extra:
         assert "link_GBps" in res["config"]["sharding_tuning"], res["config"]
 

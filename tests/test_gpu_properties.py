@@ -129,23 +129,80 @@ def test_masked_silly_cells_do_not_poison_neighbours(oracle, torch_mod):
         np.testing.assert_array_equal(clean[k][keep], dirty[k][keep], err_msg=k)
 
 
-def test_fp32_variant_tracks_fp64_oracle(oracle, torch_mod):
-    """Config 5 (fp32, ECMWF + skin): no fp32 reference exists (wp=dp); tolerance restated vs the fp64 oracle:
-    |err| <= 2e-3*|x| + 2e-3*max|x| per field (fp32 eps 6e-8 amplified by dT = theta - T_s cancellation)."""
+FP32_FLOOR = {"QL": 1.0, "QH": 1.0, "Tau_x": 1e-3, "Tau_y": 1e-3, "Evap": 4e-7}   # 1 W/m2 and its equivalents
+
+
+def _fp32_errors(torch, got, ref):
+    """SURVEY §8d's proposal for config 5: relative error where |flux| exceeds the floor (1 W/m2), absolute (in floors) below."""
+    return {k: ((got[k].double() - ref[k]).abs() / ref[k].abs().clamp_min(fl)) for k, fl in FP32_FLOOR.items()}
+
+
+@pytest.mark.parametrize("algo", ["ecmwf", "coare3p6", "coare3p0"])
+def test_fp32_sessions_against_fp64_oracle(oracle, torch_mod, algo):
+    """Config 5 path (fp32 arrays).  No fp32 reference exists (wp = dp, mod_const.f90:10-12; the reference warns about single
+    precision itself, mod_blk_ecmwf.f90:556-561): the tolerance is restated against the fp64 ORACLE fed with the fp32-rounded
+    inputs (the numbers the session actually receives).
+      AB_F32_STORAGE (fp32 arrays, fp64 arithmetic): <= 1e-4 relative where |flux| > 1 W/m2, 1e-4 absolute below — SURVEY §8d's
+        bar; measured 6e-8 (one rounding of the result), asserted at 1e-6.  T_s within one fp32 ulp of 300 K.
+      AB_F32 (fp32 arithmetic too, 1.9x faster): theta - T_s and q - q_s are formed from fp32 numbers of O(300) / O(0.01);
+        measured p99 2.4e-4, p99.99 1.1e-3, max 1.8e-3 on this grid (tools/fp32_error.py, profiles/r2_fp32_error.txt); asserted."""
     import aerobulk_amd as ab
+    torch = torch_mod
     ni, nj = 360, 180
     f = oracle.synth_fields(ni, nj)
-    names = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")
-    o = oracle.OracleSession("ecmwf", ni * nj, 1, True).compute(1, 2.0, 10.0, 5, *[f[k] for k in names],
-                                                                rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
-    with ab.Session("ecmwf", ni, nj, 1, True, precision="f32") as s:
-        g = s.compute(1, 2.0, 10.0, *[f[k].astype(np.float32) for k in names], Niter=5,
-                      rad_sw=f["rad_sw"].astype(np.float32), rad_lw=f["rad_lw"].astype(np.float32))
-    for k, c in (("ql", "QL"), ("qh", "QH"), ("tau_x", "Tau_x"), ("t_s", "T_s")):
-        err = np.abs(g[c].astype(np.float64) - o[k])
-        bound = 2e-3 * np.abs(o[k]) + 2e-3 * np.max(np.abs(o[k]))
-        print(k, "fp32 max err/scale", float(np.max(err) / np.max(np.abs(o[k]))))
-        assert np.all(err <= bound), k
+    names = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")
+    f32 = {k: f[k].astype(np.float32) for k in names}
+    f64 = {k: f32[k].astype(np.float64) for k in names}
+    o = oracle.OracleSession(algo, ni * nj, 1, True).compute(1, 2.0, 10.0, 5, *[f64[k] for k in names[:6]], rad_sw=f64["rad_sw"], rad_lw=f64["rad_lw"])
+    ref = {c: torch.from_numpy(o[k]) for k, c in (("ql", "QL"), ("qh", "QH"), ("tau_x", "Tau_x"), ("tau_y", "Tau_y"), ("evap", "Evap"), ("t_s", "T_s"))}
+    for prec in ("f32_storage", "f32"):
+        with ab.Session(algo, ni, nj, 1, True, precision=prec) as s:
+            g = s.compute(1, 2.0, 10.0, *[f32[k] for k in names[:6]], Niter=5, rad_sw=f32["rad_sw"], rad_lw=f32["rad_lw"])
+        got = {k: torch.from_numpy(np.asarray(v)) for k, v in g.items()}
+        err = _fp32_errors(torch, got, ref)
+        dts = float((got["T_s"].double() - ref["T_s"]).abs().max())
+        worst = {k: float(e.max()) for k, e in err.items()}
+        print(algo, prec, "max error", worst, "T_s", dts)
+        if prec == "f32_storage":
+            assert max(worst.values()) <= 1e-6 and dts <= 2e-5, (worst, dts)
+        else:
+            for k, e in err.items():
+                assert float(torch.quantile(e, 0.99)) <= 6e-4 and float(torch.quantile(e, 0.9999)) <= 4e-3 and float(e.max()) <= 3e-2, (k, worst)
+            assert dts <= 5e-3
+
+
+def test_orca36_fp32_full_grid(torch_mod):
+    """BASELINE config 5 at its full size on ONE GPU (12960 x 10800 = 140 M cells, ECMWF + cool-skin/warm-layer, fp32 arrays:
+    7.8 GB): every cell against the fp64 path on the same numbers (15.7 GB more), and j-block invariance at that size."""
+    import aerobulk_amd as ab
+    torch = torch_mod
+    ni, nj = 12960, 10800
+    f = ab.synth_fields_device(ni, nj, precision="f32")
+    with ab.Session("ecmwf", ni, nj, 1, True) as s:
+        ref = s.compute(1, 2.0, 10.0, *[f[k].double() for k in IN6], Niter=5, rad_sw=f["rad_sw"].double(), rad_lw=f["rad_lw"].double())
+    for prec in ("f32_storage", "f32"):
+        with ab.Session("ecmwf", ni, nj, 1, True, precision=prec) as s:
+            got = s.compute(1, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+        for k in got:
+            assert bool(torch.isfinite(got[k]).all()), (prec, k)
+        err = _fp32_errors(torch, got, ref)
+        worst = {k: float(e.max()) for k, e in err.items()}
+        print(prec, "12960x10800 max error", worst)
+        if prec == "f32_storage":
+            assert max(worst.values()) <= 1e-6, worst
+        else:
+            for k, e in err.items():
+                sub = e[::37]                                       # 3.8 M cells for the quantile
+                assert float(torch.quantile(sub[:3_000_000], 0.999)) <= 2e-3 and float(e.max()) <= 0.2, (k, worst)
+        del err
+        # a j-block computed alone (what one of 8 ranks owns) is bit-identical to the same rows of the full launch
+        j0, njl = 4050, 1350
+        fs = ab.synth_fields_device(ni, nj, j0, njl, precision="f32")
+        with ab.Session("ecmwf", ni, njl, 1, True, precision=prec) as s:
+            part = s.compute(1, 2.0, 10.0, *[fs[k] for k in IN6], Niter=5, rad_sw=fs["rad_sw"], rad_lw=fs["rad_lw"])
+        for k in got:
+            assert torch.equal(got[k][j0 * ni:(j0 + njl) * ni], part[k]), (prec, k)
+        del got, part, fs
 
 
 def test_warm_layer_with_real_solar_time_and_longitude(oracle, torch_mod):

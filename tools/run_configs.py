@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run bench.py for every BASELINE.json configuration that fits one GPU and collect the JSON lines (SURVEY §8d "configs ->
-concrete runs"): writes gpurun_out/configs.jsonl (copy to profiles/r1_configs.jsonl)."""
+concrete runs"): writes gpurun_out/configs.jsonl (copy to profiles/r2_configs.jsonl)."""
 import json
 import os
 import subprocess
@@ -8,17 +8,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNS = [
-    ("config 2: coare3p6, no skin, 1440x1080, nb_iter=8", ["--algo", "coare3p6", "--no-skin", "--grid", "1440x1080", "--niter", "8"]),
+    ("config 2: coare3p6, no skin, 1440x1080, nb_iter=8", ["--config", "2"]),
     ("config 3: coare3p6 + skin, 4320x3600, nb_iter=5 (headline)", []),
     ("config 3: coare3p6 + skin, 4320x3600, nb_iter=8", ["--niter", "8"]),
-    ("config 4 (1 GPU): coare3p0 + skin", ["--algo", "coare3p0"]),
-    ("config 4 (1 GPU): ecmwf + skin", ["--algo", "ecmwf"]),
-    ("config 4 (1 GPU): coare3p0, no skin", ["--algo", "coare3p0", "--no-skin"]),
-    ("config 4 (1 GPU): coare3p6, no skin", ["--algo", "coare3p6", "--no-skin"]),
-    ("config 4 (1 GPU): ncar", ["--algo", "ncar"]),
-    ("config 4 (1 GPU): ecmwf, no skin", ["--algo", "ecmwf", "--no-skin"]),
-    ("config 4 (1 GPU): andreas", ["--algo", "andreas"]),
-    ("config 5 (1 GPU): ecmwf + skin, fp32, 12960x10800", ["--algo", "ecmwf", "--precision", "f32", "--grid", "12960x10800", "--steps", "5"]),
+    ("config 4 (1 GPU): five algorithms back-to-back, no skin", ["--config", "4"]),
+    ("config 4 (1 GPU): five algorithms back-to-back, skin where supported", ["--config", "4", "--skin"]),
+    ("config 5 (1 GPU): ecmwf + skin, fp32, 12960x10800", ["--config", "5", "--steps", "5"]),
+    ("config 5 path on the 4320x3600 grid", ["--config", "5", "--grid", "4320x3600"]),
+    ("config 5 (1 GPU) with fp64 arithmetic on the fp32 arrays (AB_F32_STORAGE)", ["--config", "5", "--precision", "f32_storage", "--steps", "5"]),
 ]
 
 
