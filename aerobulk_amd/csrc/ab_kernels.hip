@@ -350,14 +350,14 @@ __global__ void __launch_bounds__(kBlock) init_stats_kernel(const R *sst, const 
 
 hipError_t launch_init_stats(const void *sst, const void *t_air, const void *hum, const void *u, const void *v,
                              const void *slp, const void *rad_sw, const void *rad_lw, long n, int f32,
-                             double *partials, hipStream_t stream)
+                             double *partials, hipStream_t stream, int nblocks)
 {
     if (f32)
-        hipLaunchKernelGGL(init_stats_kernel<float>, dim3(kStatBlocks), dim3(kBlock), 0, stream, (const float *)sst,
+        hipLaunchKernelGGL(init_stats_kernel<float>, dim3(nblocks), dim3(kBlock), 0, stream, (const float *)sst,
                            (const float *)t_air, (const float *)hum, (const float *)u, (const float *)v,
                            (const float *)slp, (const float *)rad_sw, (const float *)rad_lw, n, partials);
     else
-        hipLaunchKernelGGL(init_stats_kernel<double>, dim3(kStatBlocks), dim3(kBlock), 0, stream, (const double *)sst,
+        hipLaunchKernelGGL(init_stats_kernel<double>, dim3(nblocks), dim3(kBlock), 0, stream, (const double *)sst,
                            (const double *)t_air, (const double *)hum, (const double *)u, (const double *)v,
                            (const double *)slp, (const double *)rad_sw, (const double *)rad_lw, n, partials);
     return hipGetLastError();

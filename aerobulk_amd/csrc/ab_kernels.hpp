@@ -71,7 +71,7 @@ constexpr int kStatStride = 1 + 3 * kStatFields;
 constexpr int kStatBlocks = 2048;
 hipError_t launch_init_stats(const void *sst, const void *t_air, const void *hum, const void *u, const void *v,
                              const void *slp, const void *rad_sw, const void *rad_lw, long n, int f32,
-                             double *partials /* kStatBlocks*kStatStride */, hipStream_t stream);
+                             double *partials /* nblocks*kStatStride */, hipStream_t stream, int nblocks = kStatBlocks);
 
 // Synthetic quasi-random fields of SURVEY.md §8d generated straight into HBM (bench utility):
 // rows j0 .. j0+nj_local-1 (0-based) of an ni-wide grid.

@@ -230,7 +230,44 @@ int stage_inputs(ab_session *s, const void *const host[8], const void *dev[8])
     return AB_OK;
 }
 
-struct FieldStat { double sum, mn, mx; };
+// fold per-block partial rows of init_stats_kernel into [count, n_cells | 9 sums | 9 mins | 9 maxs] (AB_INIT_NSTATS layout)
+void fold_partials(const double *part, int nrows, long ncells, double stats[AB_INIT_NSTATS])
+{
+    double *sum = stats + 2, *mn = stats + 2 + ab::kStatFields, *mx = stats + 2 + 2 * ab::kStatFields;
+    stats[0] = 0.;
+    stats[1] = (double)ncells;
+    for (int f = 0; f < ab::kStatFields; ++f) { sum[f] = 0.; mn[f] = 1.e300; mx[f] = -1.e300; }
+    for (int b = 0; b < nrows; ++b) {
+        const double *p = &part[(size_t)b * ab::kStatStride];
+        stats[0] += p[0];
+        for (int f = 0; f < ab::kStatFields; ++f) {
+            sum[f] += p[1 + 3 * f];
+            if (p[2 + 3 * f] < mn[f]) mn[f] = p[2 + 3 * f];
+            if (p[3 + 3 * f] > mx[f]) mx[f] = p[3 + 3 * f];
+        }
+    }
+}
+
+// type_of_humidity, mod_phymbl.f90:1984-2003; -1: not identifiable
+int classify_humidity(double hmean, double hmin, double hmax)
+{
+    if ((hmean >= 0.) && (hmean < 0.08) && (hmin >= 0.) && (hmax < 0.08)) return AB_HUM_SH;
+    if ((hmean >= 150.) && (hmean < 330.) && (hmin >= 150.) && (hmax < 330.)) return AB_HUM_DP;
+    if ((hmean >= 0.) && (hmean <= 100.) && (hmin >= 0.) && (hmax <= 100.)) return AB_HUM_RH;
+    return -1;
+}
+
+// AEROBULK_MODEL at jt == 1 on a large host grid: AEROBULK_INIT's statistics ride on the chunks of the pipelined pass below
+// (one PCIe crossing of the inputs, overlapped with the return of the outputs).  The kernels need the humidity type, which is
+// a GLOBAL decision (mod_aerobulk.f90:128-140) only known after the last chunk: they run with the type the FIRST chunk
+// indicates, and the record is recomputed from the resident inputs in the (pathological) case the whole domain says otherwise.
+struct FusedInit {
+    double *d_part = nullptr;     // nch x kFusedBlocks partial rows
+    int guess = AB_HUM_SH;
+    int have_rad = 0;
+    ab_init_report *report = nullptr;
+};
+constexpr int kFusedBlocks = 128;
 
 // Host calling convention for large grids: the record is cut into cell chunks and pipelined over three streams —
 // H2D of chunk c+1 (this thread), kernel of chunk c, D2H of chunk c-1 (helper thread) — so that both PCIe directions
@@ -238,7 +275,8 @@ struct FieldStat { double sum, mn, mx; };
 constexpr long kPipeChunk = 1L << 20;        // cells per chunk (8 MiB per fp64 field)
 constexpr long kPipeThreshold = 4L << 20;    // below this the plain path is as fast
 
-hipError_t compute_host_pipelined(ab_session *s, const ab::FluxCall &c, const void *const host_in[8], void *const host_out[6])
+hipError_t compute_host_pipelined(ab_session *s, const ab::FluxCall &c, const void *const host_in[8], void *const host_out[6],
+                                  FusedInit *fi = nullptr)
 {
     const long n = s->n;
     const int nch = (int)((n + kPipeChunk - 1) / kPipeChunk);
@@ -281,7 +319,24 @@ hipError_t compute_host_pipelined(ab_session *s, const ab::FluxCall &c, const vo
         if (err == hipSuccess) err = hipEventRecord(h2d[i], s->s_h2d);
         if (err == hipSuccess) err = hipStreamWaitEvent(s->stream, h2d[i], 0);
         if (err != hipSuccess) break;
+        if (fi) {   // AEROBULK_INIT statistics of this chunk (the reference checks rad_lw in both radiation slots, mod_aerobulk.f90:248)
+            auto at = [&](const void *p) -> const void * { return p ? (const char *)p + off * esz : nullptr; };
+            double *rows = fi->d_part + (size_t)i * kFusedBlocks * ab::kStatStride;
+            err = ab::launch_init_stats(at(c.sst), at(c.t_zt), at(c.hum), at(c.u), at(c.v), at(c.slp), at(c.rad_lw), at(c.rad_lw), cnt,
+                                        s->f32, rows, s->stream, kFusedBlocks);
+            if (err == hipSuccess && i == 0) {   // the first chunk's verdict on the humidity type is the working assumption
+                std::vector<double> part((size_t)kFusedBlocks * ab::kStatStride);
+                err = hipMemcpyAsync(part.data(), rows, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+                if (err == hipSuccess) err = hipStreamSynchronize(s->stream);
+                double st[AB_INIT_NSTATS];
+                fold_partials(part.data(), kFusedBlocks, cnt, st);
+                const int g = st[0] > 0. ? classify_humidity(st[2 + 6] / st[0], st[2 + ab::kStatFields + 6], st[2 + 2 * ab::kStatFields + 6]) : -1;
+                fi->guess = g >= 0 ? g : AB_HUM_SH;
+            }
+            if (err != hipSuccess) break;
+        }
         ab::FluxCall cc = c;
+        if (fi) cc.hum_type = fi->guess;
         auto adv = [&](const void *p) -> const void * { return p ? (const char *)p + off * esz : nullptr; };
         auto advw = [&](void *p) -> void * { return p ? (char *)p + off * esz : nullptr; };
         cc.sst = adv(c.sst); cc.t_zt = adv(c.t_zt); cc.hum = adv(c.hum); cc.u = adv(c.u); cc.v = adv(c.v); cc.slp = adv(c.slp);
@@ -395,20 +450,7 @@ int ab_session_init_stats(ab_session *s, const void *sst, const void *t_zt, cons
     AB_HIP(hipMemcpyAsync(part.data(), s->d_partials, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     AB_HIP(hipStreamSynchronize(st));
 
-    // fold the per-block rows into [count, n_cells | 9 sums | 9 mins | 9 maxs] (layout of AB_INIT_NSTATS, see header)
-    double *sum = stats + 2, *mn = stats + 2 + ab::kStatFields, *mx = stats + 2 + 2 * ab::kStatFields;
-    stats[0] = 0.;
-    stats[1] = (double)s->n;
-    for (int f = 0; f < ab::kStatFields; ++f) { sum[f] = 0.; mn[f] = 1.e300; mx[f] = -1.e300; }
-    for (int b = 0; b < ab::kStatBlocks; ++b) {
-        const double *p = &part[(size_t)b * ab::kStatStride];
-        stats[0] += p[0];
-        for (int f = 0; f < ab::kStatFields; ++f) {
-            sum[f] += p[1 + 3 * f];
-            if (p[2 + 3 * f] < mn[f]) mn[f] = p[2 + 3 * f];
-            if (p[3 + 3 * f] > mx[f]) mx[f] = p[3 + 3 * f];
-        }
-    }
+    fold_partials(part.data(), ab::kStatBlocks, s->n, stats);
     return AB_OK;
 }
 
@@ -430,9 +472,10 @@ int ab_session_init_apply(ab_session *s, const double stats[AB_INIT_NSTATS], int
     // type_of_humidity, mod_phymbl.f90:1984-2003
     const double hmean = sum[6] / cnt, hmin = mn[6], hmax = mx[6];
     double hlo, hhi;
-    if ((hmean >= 0.) && (hmean < 0.08) && (hmin >= 0.) && (hmax < 0.08)) { rep.hum_type = AB_HUM_SH; hlo = 0.; hhi = 0.08; }
-    else if ((hmean >= 150.) && (hmean < 330.) && (hmin >= 150.) && (hmax < 330.)) { rep.hum_type = AB_HUM_DP; hlo = 150.; hhi = 330.; }
-    else if ((hmean >= 0.) && (hmean <= 100.) && (hmin >= 0.) && (hmax <= 100.)) { rep.hum_type = AB_HUM_RH; hlo = 0.; hhi = 100.; }
+    rep.hum_type = classify_humidity(hmean, hmin, hmax);
+    if (rep.hum_type == AB_HUM_SH) { hlo = 0.; hhi = 0.08; }
+    else if (rep.hum_type == AB_HUM_DP) { hlo = 150.; hhi = 330.; }
+    else if (rep.hum_type == AB_HUM_RH) { hlo = 0.; hhi = 100.; }
     else {
         if (report) *report = rep;
         return fail(AB_ERR_HUM_TYPE,
@@ -474,10 +517,14 @@ int ab_session_init(ab_session *s, const void *sst, const void *t_zt, const void
     return ab_session_init_apply(s, stats, (rad_sw && rad_lw) ? 1 : 0, report);
 }
 
-int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, const void *sst, const void *t_zt,
-                       const void *hum_zt, const void *u_zu, const void *v_zu, const void *slp, const void *rad_sw,
-                       const void *rad_lw, void *ql, void *qh, void *tau_x, void *tau_y, void *evap, void *t_s,
-                       int mem, void *stream)
+}  // extern "C"
+
+// aerobulk_compute for one record; `fi` (AEROBULK_MODEL at jt == 1, large host grid, one device): AEROBULK_INIT's checks are
+// taken along in the same pipelined pass instead of a pass of their own
+static int compute_impl(ab_session *s, int jt, double zt, double zu, int niter, const void *sst, const void *t_zt,
+                        const void *hum_zt, const void *u_zu, const void *v_zu, const void *slp, const void *rad_sw,
+                        const void *rad_lw, void *ql, void *qh, void *tau_x, void *tau_y, void *evap, void *t_s,
+                        int mem, void *stream, FusedInit *fi)
 {
     Range trace_("ab_session_compute");
     if (!s) return fail(AB_ERR_ARG, "NULL session");
@@ -559,10 +606,34 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
     c.regroup = s->regroup;
 
     if (pipelined) {
-        AB_HIP(compute_host_pipelined(s, c, host_in, hout));
+        const int nch = (int)((s->n + kPipeChunk - 1) / kPipeChunk);
+        if (fi) AB_HIP(hipMalloc((void **)&fi->d_part, sizeof(double) * (size_t)nch * kFusedBlocks * ab::kStatStride));
+        hipError_t e = compute_host_pipelined(s, c, host_in, hout, fi);
         s->timed = true;
         s->last_stream = st;
         s->last_jt = jt;
+        if (fi) {
+            // the global verdict: fold every chunk's rows, take AEROBULK_INIT's decisions (mod_aerobulk.f90:105-153)
+            std::vector<double> part((size_t)nch * kFusedBlocks * ab::kStatStride);
+            if (e == hipSuccess) e = hipMemcpy(part.data(), fi->d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost);
+            (void)hipFree(fi->d_part);
+            fi->d_part = nullptr;
+            AB_HIP(e);
+            double stats[AB_INIT_NSTATS];
+            fold_partials(part.data(), nch * kFusedBlocks, s->n, stats);
+            int rc = ab_session_init_apply(s, stats, fi->have_rad, fi->report);
+            if (rc) return rc;
+            if (s->hum_type != fi->guess) {   // the first chunk misjudged the humidity type: redo the record from the resident inputs
+                c.hum_type = s->hum_type;
+                AB_HIP(hipMemsetAsync(s->d_flags, 0, sizeof(int), s->stream));   // whatever the misjudged pass flagged is void
+                AB_HIP(ab::launch_flux(c, s->stream));
+                for (int i = 0; i < 6; ++i)
+                    if (hout[i]) AB_HIP(hipMemcpyAsync(hout[i], dout[i], bytes, hipMemcpyDeviceToHost, s->stream));
+                AB_HIP(hipStreamSynchronize(s->stream));
+            }
+        } else {
+            AB_HIP(e);
+        }
         return ab_session_check(s);
     }
     AB_HIP(hipEventRecord(s->ev0, st));
@@ -583,6 +654,17 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, c
         return ab_session_check(s);
     }
     return AB_OK;
+}
+
+extern "C" {
+
+int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter, const void *sst, const void *t_zt,
+                       const void *hum_zt, const void *u_zu, const void *v_zu, const void *slp, const void *rad_sw,
+                       const void *rad_lw, void *ql, void *qh, void *tau_x, void *tau_y, void *evap, void *t_s,
+                       int mem, void *stream)
+{
+    return compute_impl(s, jt, zt, zu, niter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, ql, qh, tau_x, tau_y, evap, t_s, mem,
+                        stream, nullptr);
 }
 
 int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int use_wl, int nb_iter,
@@ -802,6 +884,17 @@ int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double
         }
         g_sess->last_jt = 0;
         for (ab_session *c : g_sess->shards) c->last_jt = 0;
+        // Large grid on one device: AEROBULK_INIT's statistics ride on the pipelined pass of aerobulk_compute (inputs cross PCIe
+        // once, overlapped with the outputs coming back).  The record is complete when the checks are: an error is still an error.
+        if (!g_sess->sharded() && g_sess->n >= kPipeThreshold && !g_sess->diag_on && (!lsrad || use_skin) &&
+            !getenv("AEROBULK_AMD_NO_FUSED_INIT")) {
+            FusedInit fi;
+            fi.have_rad = lsrad ? 1 : 0;
+            fi.report = report;
+            // rad present but l_use_skin false => no skin, T_s = sst (mod_aerobulk_compute.f90:132,206): handled by compute
+            return compute_impl(g_sess, jt, zt, zu, g_nb_iter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, ql, qh, tau_x, tau_y,
+                                evap, lsrad ? t_s : nullptr, AB_MEM_HOST, nullptr, &fi);
+        }
         // the reference hands rad_lw to BOTH prsw and prlw (mod_aerobulk.f90:248)
         int rc = ab_session_init(g_sess, sst, t_zt, hum_zt, u_zu, v_zu, slp, lsrad ? rad_lw : nullptr,
                                  lsrad ? rad_lw : nullptr, AB_MEM_HOST, nullptr, report);

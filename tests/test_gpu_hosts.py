@@ -203,3 +203,37 @@ def test_sharded_init_statistics_match_global_init(oracle):
         got = s.init_apply(st, have_rad=True)
         assert (got["n_cells"], got["n_masked"], got["hum_type"]) == (want["n_cells"], want["n_masked"], want["hum_type"]) == (n, 8, "sh")
         s.close()
+
+
+def test_model_first_record_with_fused_init_equals_two_pass(oracle):
+    """AEROBULK_MODEL at jt == 1 on a grid large enough for the chunk pipeline: AEROBULK_INIT's statistics ride on the pipelined
+    pass (kernels start on the FIRST chunk's verdict about the humidity type).  Same results and same report as statistics in a
+    pass of their own; a domain whose first chunk looks like specific humidity but which is relative humidity as a whole is
+    recomputed with the global verdict; an all-masked domain is still an error."""
+    import aerobulk_amd as ab
+    ni, nj = 2200, 2001                                   # 4.4 M cells: 5 chunks
+    f = oracle.synth_fields(ni, nj)
+    F = {k: v.reshape((ni, nj), order="F") for k, v in f.items()}
+    rh = 30.0 + 60.0 * f["rad_sw"] / 900.0               # 30 .. 90 %
+    rh[: 1 << 20] = 0.05                                  # the first chunk alone reads as 'sh' (all < 0.08): the domain is 'rh'
+    cases = {"sh": F["hum_zt"], "rh-behind-sh": rh.reshape((ni, nj), order="F")}
+    for name, hum in cases.items():
+        res = {}
+        for mode in ("fused", "two-pass"):
+            if mode == "two-pass":
+                os.environ["AEROBULK_AMD_NO_FUSED_INIT"] = "1"
+            else:
+                os.environ.pop("AEROBULK_AMD_NO_FUSED_INIT", None)
+            try:
+                r = ab.aerobulk_model(1, 1, "coare3p6", 2.0, 10.0, F["sst"], F["t_zt"], hum, F["u_zu"], F["v_zu"], F["slp"], Niter=4,
+                                      l_use_skin=True, rad_sw=F["rad_sw"], rad_lw=F["rad_lw"])
+            finally:
+                os.environ.pop("AEROBULK_AMD_NO_FUSED_INIT", None)
+            res[mode] = r
+        a, b = res["fused"], res["two-pass"]
+        assert a["init_report"] == b["init_report"] and a["init_report"]["hum_type"] == ("sh" if name == "sh" else "rh"), a["init_report"]
+        for k in ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{name} {k}")
+    with pytest.raises(ab.AerobulkError) as e:            # Celsius SST: the whole domain is masked
+        ab.aerobulk_model(1, 1, "coare3p6", 2.0, 10.0, F["sst"] - 273.15, F["t_zt"], F["hum_zt"], F["u_zu"], F["v_zu"], F["slp"], Niter=4)
+    assert e.value.status == 5
