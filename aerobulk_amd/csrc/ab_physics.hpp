@@ -352,47 +352,65 @@ template <class R> __device__ __forceinline__ bool wl_coare_dawn(R plon, int isd
 }
 
 // ---------------------------------------------------------------- warm layer, ECMWF (Zeng & Beljaars 2005 / Takaya 2010)
-// PHI mod_skin_ecmwf.f90:233-253
-template <class R> __device__ __forceinline__ R phi_takaya(R z)
+// PHI mod_skin_ecmwf.f90:233-253: only its zeta >= 0 branch is reachable from WL_ECMWF (both stability parameters are >= 0)
+// WL_ECMWF mod_skin_ecmwf.f90:113-230 (no Stokes drift).  Advances dT_wl on EVERY call (:228).
+// The layer depth is fixed in this scheme (Hz_wl is only ever read, :136): what depends on it alone — the absorbed fraction of
+// the solar flux with its three exponentials (:152) and 1/Hz_wl — is evaluated once per record by the caller (WlEcmwfCell),
+// not once per Monin-Obukhov iteration.
+template <class R> struct WlEcmwfCell {
+    R zfr, zih;
+};
+template <class R> __device__ __forceinline__ WlEcmwfCell<R> wl_ecmwf_cell(R zHwl)
 {
     using M = Mth<R>;
-    if (nonneg(z)) return R(1.) + M::div(R(5.) * z + R(4.) * z * z, R(1.) + R(3.) * z + R(0.25) * z * z);
-    return M::rcp(M::sqrt_pos(R(1.) - R(16.) * (-M::abs(z))));
+    WlEcmwfCell<R> c;
+    c.zfr = R(1.) - R(0.28) * M::exp(R(-71.5) * zHwl) - R(0.27) * M::exp(R(-2.8) * zHwl) - R(0.45) * M::exp(R(-0.07) * zHwl);
+    c.zih = M::rcp(zHwl);
+    return c;
 }
-// WL_ECMWF mod_skin_ecmwf.f90:113-230 (no Stokes drift).  Advances dT_wl on EVERY call (:228).
-template <class R> __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, R pQsw, R pQnsol, R pustar, R zalpha)
+template <class R>
+__device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, const WlEcmwfCell<R> &wc, R pQsw, R pQnsol, R pustar, R zalpha)
 {
     AB_REGION("wl_ecmwf");
     using M = Mth<R>;
     const R zRhoCp_w = K<R>::rho0_w * K<R>::rCp0_w;
     const R rNuwl0 = R(0.5);
-    const R zih = M::rcp(zHwl);
+    const R zih = wc.zih;
     const bool deep = !nonneg(K<R>::gdept1 - zHwl);       // warm layer deeper than the bulk-SST depth (always: 3 m vs 1 m)
     const R ztcorr = deep ? K<R>::gdept1 * zih : R(1.);
     const R zdTwl_b = vmax(deep ? dT_wl * zHwl : dT_wl, R(0.));   // dT_wl / ztcorr, gdept1 == 1
-    const R zfr = R(1.) - R(0.28) * M::exp(R(-71.5) * zHwl) - R(0.27) * M::exp(R(-2.8) * zHwl)
-                  - R(0.45) * M::exp(R(-0.07) * zHwl);
-    const R zQabs = zfr * pQsw + pQnsol;
+    const R zQabs = wc.zfr * pQsw + pQnsol;
     const R zusw = vmax(pustar, R(1.E-4)) * K<R>::sq_radrw;
     const R zusw2 = zusw * zusw;
     const R zfLa = R(2.231443166940565);  // MAX(0.3**(-2/3), 1) :185
     const bool zwf = nonneg(zQabs);
     const R zcst1 = K<R>::vkarmn * K<R>::grav * zalpha;
     const R ziu2 = M::rcp(zusw2);
-    const R zL2 = zcst1 * zQabs * ziu2 * M::rcp(zRhoCp_w * zusw);
     const R zcst2 = zcst1 * R(0.2) * zih * ziu2;
     const R zcst0 = K<R>::rdt * (rNuwl0 + R(1.)) * zih;
     const R zA = zcst0 * zQabs * R(1. / (0.5 * 1025. * 4190.));
     const R zcst3 = -zcst0 * K<R>::vkarmn * zusw * zfLa;
+    // zB = zcst3 / PHI(zeta), zeta >= 0 on both branches (:212-217): PHI = 1 + (5z + 4z^2)/(1 + 3z + z^2/4) = (D + N)/D, so
+    // zB = zcst3 D / (D + N): one division instead of two
+    auto zB_of = [&](R z) -> R {
+        const R zD = R(1.) + R(3.) * z + R(0.25) * z * z;
+        return M::div(zcst3 * zD, zD + R(5.) * z + R(4.) * z * z);
+    };
     R zdTwl_n = zdTwl_b;
-    // when zQabs >= 0 the stability parameter does not depend on the iterate: PHI is loop-invariant
-    const R zB_warm = M::div(zcst3, phi_takaya(zHwl * zL2));
+    if (zwf) {   // heating: the stability parameter zHwl/L, L from zQabs (:198), does not depend on the iterate
+        const R zB = zB_of(zHwl * (zcst1 * zQabs * ziu2 * M::rcp(zRhoCp_w * zusw)));
 #pragma unroll 1
-    for (int jc = 0; jc < 10; ++jc) {
-        zdTwl_n = R(0.5) * (zdTwl_n + zdTwl_b);
-        R zB = zB_warm;
-        if (!zwf) zB = M::div(zcst3, phi_takaya(zHwl * M::sqrt(zdTwl_n * zcst2)));
-        zdTwl_n = vmax(zdTwl_b + zA + zB * zdTwl_n, R(0.));
+        for (int jc = 0; jc < 10; ++jc) {
+            zdTwl_n = R(0.5) * (zdTwl_n + zdTwl_b);
+            zdTwl_n = vmax(zdTwl_b + zA + zB * zdTwl_n, R(0.));
+        }
+    } else {
+#pragma unroll 1
+        for (int jc = 0; jc < 10; ++jc) {
+            zdTwl_n = R(0.5) * (zdTwl_n + zdTwl_b);
+            const R zB = zB_of(zHwl * M::sqrt(zdTwl_n * zcst2));
+            zdTwl_n = vmax(zdTwl_b + zA + zB * zdTwl_n, R(0.));
+        }
     }
     dT_wl = zdTwl_n * ztcorr;
 }
@@ -733,6 +751,8 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
     R zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf<R>(zz0 * z1oL);   // :253
     R zFh = h.log_zu - zlog_z0t - zpsi_h_u + psi_h_ecmwf<R>(zz0t * z1oL); // :255
     R zlog_z0q = R(0.), zpsi_h_z0q = R(0.), zdT_cs = R(0.);
+    WlEcmwfCell<R> wlc{R(0.), R(0.)};
+    if (WL) wlc = wl_ecmwf_cell(wl[1]);
 
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
@@ -784,7 +804,7 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
             R zQns, zTau, zQlat;
             update_qnsol_tau(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
                              zQlat);                                    // :333-334
-            wl_ecmwf(wl[0], wl[1], in.qsw, zQns, zus, zalpha);          // :335
+            wl_ecmwf(wl[0], wl[1], wlc, in.qsw, zQns, zus, zalpha);     // :335
             zT_s = zSST + wl[0];
             if (CS) zT_s = zT_s + zdT_cs;
             zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);

@@ -150,8 +150,6 @@ CD goff_poly(CD x);
 template <int N> CD horner_tab(const double *tab, CD x);
 template <int N> CD horner_tab(const double *tab, Prod x) { return horner_tab<N>(tab, CD(x)); }
 inline CD goff_poly(Prod x) { return goff_poly(CD(x)); }
-template <class R> R phi_takaya(R z);
-inline CD phi_takaya(Prod z) { return phi_takaya<CD>(CD(z)); }
 
 }  // namespace ab
 
