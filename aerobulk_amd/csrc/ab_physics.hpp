@@ -715,6 +715,32 @@ template <class R> __device__ __forceinline__ void psi_ecmwf(R pz, R *pm, R *ph)
 }
 template <class R> __device__ __forceinline__ R psi_m_ecmwf(R z) { R m; psi_ecmwf<R>(z, &m, nullptr); return m; }
 template <class R> __device__ __forceinline__ R psi_h_ecmwf(R z) { R v; psi_ecmwf<R>(z, nullptr, &v); return v; }
+// The same functions at the roughness heights: turb_ecmwf evaluates psi_m(z0/L), psi_h(z0t/L), psi_h(z0q/L) in every iteration
+// (:276,290-292), arguments of 1e-6 .. 1e-4.  There the closed forms are O(1) terms cancelling to O(zeta) — two square roots,
+// a log, an atan with its division — for a number a degree-5/6 polynomial gives to 1e-18 absolute (each function is analytic
+// on its side of 0; fitted on |zeta| <= 1e-3 in t = 1000 zeta, tools/gen_psi_small.py).  Beyond 1e-3 the closed forms.
+AB_TAB double kPsiMU[fm::ab_pad4(7)] = {-6.094914512234566e-17, -0.003999999999999972, -1.9999999999555597e-05, -1.599999973300714e-07,
+                                        -1.5599923538873374e-09, -1.69615384228405e-11, -1.8975349598658237e-13};
+AB_TAB double kPsiHU[fm::ab_pad4(7)] = {9.367832564752625e-19, -0.007999999999999908, -4.799999999852992e-05, -4.266666578341352e-07,
+                                        -4.4799747034570265e-09, -5.1572336558726693e-11, -6.034358874849738e-13};
+AB_TAB double kPsiMS[fm::ab_pad4(6)] = {-2.6116088597091867e-26, -0.005, 8.166666666666666e-07, -1.0888888888879528e-10,
+                                        1.071874981948049e-14, -8.335200884605216e-19};
+AB_TAB double kPsiHS[fm::ab_pad4(6)] = {2.665432043173813e-25, -0.005, 6.500000000000002e-07, -9.037037037132576e-11,
+                                        6.089122213161426e-15, 7.078908223179431e-19};
+template <class R> __device__ __forceinline__ R psi_m_ecmwf_z0(R z)
+{
+    AB_REGION("psi_ecmwf_z0");
+    if (Mth<R>::abs(z) > R(1.e-3)) return psi_m_ecmwf<R>(z);
+    const R t = z * R(1000.);
+    return nonneg(z) ? horner_tab<6>(kPsiMS, t) : horner_tab<7>(kPsiMU, t);
+}
+template <class R> __device__ __forceinline__ R psi_h_ecmwf_z0(R z)
+{
+    AB_REGION("psi_ecmwf_z0");
+    if (Mth<R>::abs(z) > R(1.e-3)) return psi_h_ecmwf<R>(z);
+    const R t = z * R(1000.);
+    return nonneg(z) ? horner_tab<6>(kPsiHS, t) : horner_tab<7>(kPsiHU, t);
+}
 
 // turb_ecmwf :63-383
 template <class R, int SKIN, bool DIAG = false>
@@ -748,8 +774,8 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
     R zz0t = M::exp(zlog_z0t);
     R zpsi_m_u, zpsi_h_u;
     psi_ecmwf<R>(zzeta_u, &zpsi_m_u, &zpsi_h_u);
-    R zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf<R>(zz0 * z1oL);   // :253
-    R zFh = h.log_zu - zlog_z0t - zpsi_h_u + psi_h_ecmwf<R>(zz0t * z1oL); // :255
+    R zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf_z0<R>(zz0 * z1oL);   // :253
+    R zFh = h.log_zu - zlog_z0t - zpsi_h_u + psi_h_ecmwf_z0<R>(zz0t * z1oL); // :255
     R zlog_z0q = R(0.), zpsi_h_z0q = R(0.), zdT_cs = R(0.);
     WlEcmwfCell<R> wlc{R(0.), R(0.)};
     if (WL) wlc = wl_ecmwf_cell(wl[1]);
@@ -761,7 +787,7 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
         zzeta_u = h.zu * z1oL;
         psi_ecmwf<R>(zzeta_u, &zpsi_m_u, &zpsi_h_u);                    // :269-270
         const R zpsi_h_t = psi_h_ecmwf<R>(h.zt * z1oL);                 // :272-273
-        zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf<R>(zz0 * z1oL);  // :276
+        zFm = h.log_zu - zlog_z0 - zpsi_m_u + psi_m_ecmwf_z0<R>(zz0 * z1oL);  // :276
         zus = M::div(zUbzu * vk, zFm);                                  // :279
         const R zus2 = zus * zus;
         R ztmp0 = M::div(znu_a, zus);
@@ -772,9 +798,9 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
         const R zlog_nuus = M::log(M::abs(ztmp0));                      // z0t, z0q share ln(nu/u*) :287-288
         zlog_z0t = vmin(R(-0.916290731874155) + zlog_nuus, R(-6.907755278982137));
         zlog_z0q = vmin(R(-0.4780358009429998) + zlog_nuus, R(-6.907755278982137));
-        const R zpsi_m_z0 = psi_m_ecmwf<R>(zz0 * z1oL);                 // :290-292
-        const R zpsi_h_z0t = psi_h_ecmwf<R>(zz0t * z1oL);
-        zpsi_h_z0q = psi_h_ecmwf<R>(zz0q * z1oL);
+        const R zpsi_m_z0 = psi_m_ecmwf_z0<R>(zz0 * z1oL);              // :290-292
+        const R zpsi_h_z0t = psi_h_ecmwf_z0<R>(zz0t * z1oL);
+        zpsi_h_z0q = psi_h_ecmwf_z0<R>(zz0q * z1oL);
         // gustiness :296-298 (Beta0 = 1)
         const R zcb = M::cbrt(vmax(-zi0 * z1oL * K<R>::inv_vk, R(0.)));
         zUbzu = vmax(M::sqrt(zUzu * zUzu + zus2 * (zcb * zcb)), R(0.2));
