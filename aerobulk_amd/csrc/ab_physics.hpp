@@ -428,12 +428,62 @@ AB_TAB double kPsicG[fm::ab_pad4(21)] = {-1.1378018661248832, 1.2857142823699836
                                   4.569112576860545e-07, -6.688538104698402e-07, 2.9920447417445153e-07, -7.973350238907205e-08,
                                   4.974190761282226e-09, 9.732585524385644e-09, -5.605322344298673e-09, 7.426603654517993e-10,
                                   1.903681291004176e-10};
+// Round 2: the same convective term as a polynomial in ITS OWN log, L = LOG(y): psi_c is analytic in L (nearest singularities at
+// L = +-2 pi i), degree 24 on 0 <= L <= LMAX = LOG(1 + 34.15*50) reaches the rounding of its coefficients (3.8e-16 absolute on
+// values up to 6.6; tools/gen_poly.py section 7).  One log + 24 FMAs instead of a log, an exponential and the 20 FMAs of G.
+// Beyond LMAX (the unclamped zeta of the first guess on a very unstable cell) the form above.
+AB_TAB double kPsicL[fm::ab_pad4(25)] = {2.0150925272068325, 2.710495199372137, 0.5590871232010397, -0.16213149529306578,
+    0.002606559842464411, 0.02113263846338554, -0.00925777348479494, 0.00030099378954847087, 0.0016285542947419458,
+    -0.000813039719902679, 4.423480654812829e-05, 0.00015150397200069243, -8.181957400187386e-05, 5.998120165166443e-06,
+    1.5319367544130388e-05, -8.825168944553084e-06, 8.20341206092634e-07, 1.6890014539724033e-06, -1.0233606614380631e-06,
+    4.458163497401242e-08, 2.2237828297719965e-07, -7.86594884389353e-08, -1.6678750033618162e-08, 1.1728431071594043e-08,
+    -7.386244013567452e-10};
 template <class R> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
 {
     using M = Mth<R>;
     const R L = M::log(y);
+    if (L <= R(7.4433710715553465)) return horner_tab<25>(kPsicL, L * R(2. / 7.4433710715553465) - R(1.));
     const R w = M::exp(R(-.3333) * L);
     return R(.9999) * L + horner_tab<21>(kPsicG, R(2.) * w - R(1.));
+}
+// The Kansas / Paulson unstable profile functions (mod_common_coare.f90:235-238,326-328 with y = |1 - 15 zeta|;
+// mod_blk_ecmwf.f90:462-467,519-523, mod_blk_ncar.f90:350-362, mod_blk_andreas.f90:351-358,402-408 with y = |1 - 16 zeta|):
+//    x = y**.25 ,  psi_m = 2 LOG((1+x)/2) + LOG((1+x*x)/2) - 2 ATAN(x) + 0.5 rpi ,  psi_h = 2 LOG((1+x*x)/2)
+// as functions of s = LOG(y) >= 0 are analytic with the nearest singularities at s = +-2 pi i: degree-22 polynomials on
+// 0 <= s <= SMAX = LOG(801) (zeta >= -50 in every caller's loop; 2.4e-16 / 6e-16 absolute, tools/gen_poly.py section 6).  Where
+// both are wanted at the same zeta, one log + 44 FMAs replace two square roots, two logs and an atan with its division.
+AB_TAB double kPsikM[fm::ab_pad4(23)] = {1.4034487430788964, 1.962937441601374, 0.5076434534028326, -0.08242303636209851,
+    -0.01585625187589632, 0.013840242861725485, -0.0027640918265799284, -0.00102770535119103, 0.0008423134312859619,
+    -0.0001578935470667781, -8.491426762767567e-05, 6.264087047136019e-05, -9.793981616650793e-06, -7.69808272687432e-06,
+    5.017417775041783e-06, -5.999952584060396e-07, -7.342471370752919e-07, 4.273640809340661e-07, -1.8707465535729833e-08,
+    -8.047564473933404e-08, 2.6632819859124706e-08, 6.446912234869585e-09, -3.726709061508255e-09};
+AB_TAB double kPsikH[fm::ab_pad4(23)] = {2.301130474750617, 2.813982186689832, 0.3721127642150317, -0.14171504680039929,
+    0.01739997587482143, 0.01184423989106276, -0.006994448137656206, 0.0007967564933049481, 0.0008502866902825993,
+    -0.00047063994318174133, 3.683870886131965e-05, 7.017844419336646e-05, -3.5162680343753746e-05, 1.2423761509715752e-06,
+    6.150938246474367e-06, -2.8078363096058284e-06, -4.417408957567781e-08, 6.0652190760948e-07, -2.2353959952831894e-07,
+    -5.548391403673346e-08, 5.3152004586067324e-08, 4.251847861014437e-10, -5.020344151301874e-09};
+// psi_m and/or psi_h of the unstable Kansas / Paulson form at y = |1 - a zeta| >= 1.  psi_m (alone or with psi_h): through
+// s = LOG(y); psi_h alone: its closed form (a square root and a log) is cheaper than a log and a polynomial.
+template <class R> __device__ __forceinline__ void psik(R y, R *pm, R *ph)
+{
+    using M = Mth<R>;
+    if (pm) {
+        const R sl = M::log(y);
+        if (sl <= R(6.68586094706836)) {
+            const R t = sl * R(2. / 6.68586094706836) - R(1.);
+            *pm = horner_tab<23>(kPsikM, t);
+            if (ph) *ph = horner_tab<23>(kPsikH, t);
+            return;
+        }
+    }
+    // psi_h alone, or beyond zeta = -50 (first guess of a very unstable cell, ANDREAS which has no zeta clamp)
+    const R x2 = M::sqrt_pos(y);
+    if (pm) {
+        const R x = M::sqrt_pos(x2);
+        const R hx = R(0.5) * (R(1.) + x);
+        *pm = M::log(hx * hx * (R(0.5) * (R(1.) + x2))) - R(2.) * M::atan_ge1(x) + R(0.5) * K<R>::rpi;
+    }
+    if (ph) *ph = R(2.) * M::log(R(0.5) * (R(1.) + x2));
 }
 // psi_m_coare_sclr :217-254 and psi_h_coare_sclr :305-344 at the same zeta
 template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
@@ -451,20 +501,10 @@ template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
     } else {  // unstable: Kansas / free-convection blend
         R zf = z * z;
         zf = M::div(zf, R(1.) + zf);
-        if (pm) {
-            const R x2 = M::sqrt_pos(M::abs(R(1.) - R(15.) * z));
-            const R x = M::sqrt_pos(x2);
-            const R hx = R(0.5) * (R(1.) + x);
-            const R psik = M::log(hx * hx * (R(0.5) * (R(1.) + x2))) - R(2.) * M::atan_ge1(x) + R(0.5) * K<R>::rpi;
-            const R psic = psic_coare(M::abs(R(1.) - R(10.15) * z));
-            *pm = (R(1.) - zf) * psik + zf * psic;
-        }
-        if (ph) {
-            const R x2 = M::sqrt_pos(M::abs(R(1.) - R(15.) * z));
-            const R psik = R(2.) * M::log(R(0.5) * (R(1.) + x2));
-            const R psic = psic_coare(M::abs(R(1.) - R(34.15) * z));
-            *ph = (R(1.) - zf) * psik + zf * psic;
-        }
+        R psik_m = R(0.), psik_h = R(0.);
+        psik<R>(M::abs(R(1.) - R(15.) * z), pm ? &psik_m : nullptr, ph ? &psik_h : nullptr);
+        if (pm) *pm = (R(1.) - zf) * psik_m + zf * psic_coare(M::abs(R(1.) - R(10.15) * z));
+        if (ph) *ph = (R(1.) - zf) * psik_h + zf * psic_coare(M::abs(R(1.) - R(34.15) * z));
     }
 }
 template <class R> __device__ __forceinline__ R psi_h_coare(R z) { R h; psi_coare<R>(z, nullptr, &h); return h; }
@@ -704,13 +744,7 @@ template <class R> __device__ __forceinline__ void psi_ecmwf(R pz, R *pm, R *ph)
             *ph = t - a * M::sqrt_pos(a) - R(2. / 3.) * zc + R(1.);
         }
     } else {
-        const R x2 = M::sqrt_pos(M::abs(R(1.) - R(16.) * z));
-        if (pm) {
-            const R x = M::sqrt_pos(x2);
-            const R t = R(1.) + x;
-            *pm = M::log(R(0.125) * t * t * (R(1.) + x2)) - R(2.) * M::atan_ge1(x) + R(0.5) * K<R>::rpi;
-        }
-        if (ph) *ph = R(2.) * M::log(R(0.5) * (R(1.) + x2));
+        psik<R>(M::abs(R(1.) - R(16.) * z), pm, ph);
     }
 }
 template <class R> __device__ __forceinline__ R psi_m_ecmwf(R z) { R m; psi_ecmwf<R>(z, &m, nullptr); return m; }
@@ -876,14 +910,8 @@ template <class R> __device__ __forceinline__ void psi_ncar(R z, R *pm, R *ph)
     if (nonneg(z)) {
         if (pm) *pm = R(-5.) * z;
         if (ph) *ph = R(-5.) * z;
-    } else {
-        const R x2 = vmax(M::sqrt_pos(M::abs(R(1.) - R(16.) * z)), R(1.));
-        if (pm) {
-            const R x = M::sqrt_pos(x2);
-            const R hx = (R(1.) + x) * R(0.5);
-            *pm = M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan_ge1(x) + K<R>::rpi * R(0.5);
-        }
-        if (ph) *ph = R(2.) * M::log(R(0.5) * (R(1.) + x2));
+    } else {   // x2 = MAX(SQRT(ABS(1 - 16 zeta)), 1) (:350,395): the MAX never binds for zeta < 0
+        psik<R>(M::abs(R(1.) - R(16.) * z), pm, ph);
     }
 }
 // turb_ncar :57-240
@@ -971,10 +999,9 @@ template <class R> __device__ __forceinline__ R psi_m_andreas(R pz)
                         + R(2.) * zsr3 * (M::atan((R(2.) * x - zbbm) * R(1. / (1.7320508075688772 * 0.6694329500821695)))
                                           - R(0.8539936329836121)));  // ATAN((2-B_m)/(sqrt(3) B_m))
     }
-    const R x2 = vmax(M::sqrt_pos(M::abs(R(1.) - R(16.) * z)), R(1.));
-    const R x = M::sqrt_pos(x2);
-    const R hx = (R(1.) + x) * R(0.5);
-    return M::log(hx * hx * ((R(1.) + x2) * R(0.5))) - R(2.) * M::atan_ge1(x) + K<R>::rpi * R(0.5);
+    R m;
+    psik<R>(M::abs(R(1.) - R(16.) * z), &m, nullptr);      // x2 = MAX(SQRT(ABS(1 - 16 zeta)), 1): the MAX never binds for zeta < 0
+    return m;
 }
 // psi_h_andreas :363-410
 template <class R> __device__ __forceinline__ R psi_h_andreas(R pz)

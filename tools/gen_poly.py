@@ -119,3 +119,39 @@ for deg in (18, 20, 22, 24):
     print("psic G deg", deg, "abs err", err)
     if deg in (20, 22):
         show(f"PSIC_G{deg}: G(w), x = 2w-1", c)
+
+# 6) Round 2 — the Kansas/Paulson unstable profile functions as polynomials in s = ln(y), y = |1 - a zeta| >= 1
+#    (a = 15: mod_common_coare.f90:235-238,326-328; a = 16: mod_blk_ecmwf.f90:462-467,519-523, mod_blk_ncar.f90:350-362,
+#    mod_blk_andreas.f90:351-358,402-408), x = y**.25 = exp(s/4):
+#      psi_m = 2 ln((1+x)/2) + ln((1+x^2)/2) - 2 atan(x) + 0.5 rpi ,   psi_h = 2 ln((1+x^2)/2)
+#    Analytic in s with the nearest singularities at s = +-2 pi i: one log + 22 FMAs each instead of two square roots, a log
+#    and an atan with its division.  Fitted on s in [0, SMAX], SMAX = ln(1 + 16*50) (zeta >= -50 in every caller's loop);
+#    variable t = 2 s / SMAX - 1.
+RPI = mp.mpf(float("3.141592653589793"))      # rpi of the reference (mod_const.f90:39), as the double it is
+SMAX = mp.log(801)
+psik_m = lambda s: 2 * mp.log((1 + mp.exp(s / 4)) / 2) + mp.log((1 + mp.exp(s / 2)) / 2) - 2 * mp.atan(mp.exp(s / 4)) + RPI / 2
+psik_h = lambda s: 2 * mp.log((1 + mp.exp(s / 2)) / 2)
+print("SMAX =", repr(float(SMAX)))
+for name, f in (("PSIK_M", psik_m), ("PSIK_H", psik_h)):
+    for deg in (20, 22, 24):
+        c = cheb_fit(lambda t: f((t + 1) / 2 * SMAX), mp.mpf(-1), mp.mpf(1), deg)
+        err = max_err(lambda t: f((t + 1) / 2 * SMAX), c, mp.mpf(-1), mp.mpf(1), rel=False)
+        print(name, "deg", deg, "abs err", err)
+        if deg == 22:
+            show(f"{name}{deg}: t = 2 s / SMAX - 1", c)
+
+# 7) Round 2 — COARE convective psi (section 5) as a polynomial in ITS OWN log L = ln(y), y = |1 - a zeta| (a = 10.15 / 34.15):
+#    psi_c = 1.5 ln((1+c+c^2)/3) - 1.7320508 atan((1+2c)/1.7320508) + 1.813799447, c = exp(.3333 L): analytic in L, nearest
+#    singularities at L = +-2 pi i.  One log + 28 FMAs instead of a log, an exponential and the degree-20 G(w).
+#    L in [0, LMAX], LMAX = ln(1 + 34.15*50); t = 2 L / LMAX - 1.
+LMAX = mp.log(1 + mp.mpf("34.15") * 50)
+def psic_L(L):
+    c = mp.exp(mp.mpf("0.3333") * L)
+    return mp.mpf("1.5") * mp.log((1 + c + c * c) / 3) - S3 * mp.atan((1 + 2 * c) / S3) + mp.mpf("1.813799447")
+print("LMAX =", repr(float(LMAX)))
+for deg in (24, 26, 28, 30):
+    c = cheb_fit(lambda t: psic_L((t + 1) / 2 * LMAX), mp.mpf(-1), mp.mpf(1), deg)
+    err = max_err(lambda t: psic_L((t + 1) / 2 * LMAX), c, mp.mpf(-1), mp.mpf(1), rel=False)
+    print("PSIC_L deg", deg, "abs err", err)
+    if deg in (24, 26):
+        show(f"PSIC_L{deg}: t = 2 L / LMAX - 1", c)
