@@ -134,6 +134,17 @@ template <class R> __device__ __forceinline__ R q_air_dp(R da, R pslp)
     return Mth<R>::div(q * K<R>::reps0, vmax(pslp - K<R>::one_m_reps0 * q, R(1.)));
 }
 // Theta_from_z_P0_T_q :343-375 = Pz_from_P0_tz_qz_sclr :283-318 (3 barometric iterations) + Poisson :189-200
+// exp(x) for |x| <= 2.5e-3: the barometric exponent g M z/(R T) of a measurement height of 10 m or less (1.9e-3 at 200 K).  Degree-5
+// Taylor polynomial, truncation x^6/720 < 4e-19: five FMAs instead of the table-driven exponential (16 slots), four times per cell.
+template <class R> __device__ __forceinline__ R exp_tiny(R x)
+{
+    R p = R(1. / 120.);
+    p = p * x + R(1. / 24.);
+    p = p * x + R(1. / 6.);
+    p = p * x + R(0.5);
+    p = p * x + R(1.);
+    return p * x + R(1.);
+}
 template <class R> __device__ __forceinline__ R theta_from_z_p0_t_q(R pz, R pslp, R pTa, R pqa)
 {
     using M = Mth<R>;
@@ -141,6 +152,8 @@ template <class R> __device__ __forceinline__ R theta_from_z_p0_t_q(R pz, R pslp
     const R ze_s = e_sat(pTa);
     const R c = M::div(-K<R>::grav * pz, K<R>::R_gas * pTa);
     const R zi = M::rcp(K<R>::reps0 * ze_s);
+    // |c M| <= 9.8 * 0.029 * pz / (8.3145 * pTa): below 2.5e-3 for pz <= 10 m and pTa >= 137 K (pz is wave-uniform)
+    const bool tiny = (pz <= R(10.)) && (pTa >= R(137.));
     R zpa = pslp;
     R zarg = R(0.);
 #pragma unroll
@@ -148,10 +161,11 @@ template <class R> __device__ __forceinline__ R theta_from_z_p0_t_q(R pz, R pslp
         const R zf = pqa * ((zpa - K<R>::one_m_reps0 * ze_s) * zi);   // q / q_sat(T, p)
         const R zxm = (R(1.) - zf) * K<R>::rmm_dryair + zf * K<R>::rmm_water;
         zarg = c * zxm;
-        zpa = pslp * M::exp(zarg);
+        zpa = pslp * (tiny ? exp_tiny(zarg) : M::exp(zarg));
     }
     // T (P0/Pz)^kappa with P0/Pz = exp(-zarg): no log needed
-    return pTa * M::exp(-K<R>::rpoiss_dry * zarg);
+    const R za = -K<R>::rpoiss_dry * zarg;
+    return pTa * (tiny ? exp_tiny(za) : M::exp(za));
 }
 // virt_temp_sclr :247-269
 template <class R> __device__ __forceinline__ R virt_temp(R t, R q) { return t * (R(1.) + K<R>::rctv0 * q); }
