@@ -456,7 +456,8 @@ template <class R> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
 {
     using M = Mth<R>;
     const R L = M::log(y);
-    if (L <= R(7.4433710715553465)) return horner_tab<25>(kPsicL, L * R(2. / 7.4433710715553465) - R(1.));
+    // (fp64 only: in fp32 the hardware exponential costs two slots and a degree-24 polynomial is a loss)
+    if (sizeof(R) == 8 && L <= R(7.4433710715553465)) return horner_tab<25>(kPsicL, L * R(2. / 7.4433710715553465) - R(1.));
     const R w = M::exp(R(-.3333) * L);
     return R(.9999) * L + horner_tab<21>(kPsicG, R(2.) * w - R(1.));
 }
@@ -481,7 +482,7 @@ AB_TAB double kPsikH[fm::ab_pad4(23)] = {2.301130474750617, 2.813982186689832, 0
 template <class R> __device__ __forceinline__ void psik(R y, R *pm, R *ph)
 {
     using M = Mth<R>;
-    if (pm) {
+    if (pm && sizeof(R) == 8) {   // fp64 only: fp32 square roots, logs and atan are hardware instructions
         const R sl = M::log(y);
         if (sl <= R(6.68586094706836)) {
             const R t = sl * R(2. / 6.68586094706836) - R(1.);
@@ -780,6 +781,9 @@ template <class R> __device__ __forceinline__ R psi_m_ecmwf_z0(R z)
     AB_REGION("psi_ecmwf_z0");
     if (Mth<R>::abs(z) > R(1.e-3)) return psi_m_ecmwf<R>(z);
     const R t = z * R(1000.);
+    if (sizeof(R) == 4)   // fp32: the first three terms (the fourth is below 2e-9), literal coefficients
+        return nonneg(z) ? t * (R(-0.005) + t * (R(8.166666667e-07) + t * R(-1.0888889e-10)))
+                         : t * (R(-0.004) + t * (R(-2.0e-05) + t * R(-1.6e-07)));
     return nonneg(z) ? horner_tab<6>(kPsiMS, t) : horner_tab<7>(kPsiMU, t);
 }
 template <class R> __device__ __forceinline__ R psi_h_ecmwf_z0(R z)
@@ -787,6 +791,9 @@ template <class R> __device__ __forceinline__ R psi_h_ecmwf_z0(R z)
     AB_REGION("psi_ecmwf_z0");
     if (Mth<R>::abs(z) > R(1.e-3)) return psi_h_ecmwf<R>(z);
     const R t = z * R(1000.);
+    if (sizeof(R) == 4)
+        return nonneg(z) ? t * (R(-0.005) + t * (R(6.5e-07) + t * R(-9.037037e-11)))
+                         : t * (R(-0.008) + t * (R(-4.8e-05) + t * R(-4.2666667e-07)));
     return nonneg(z) ? horner_tab<6>(kPsiHS, t) : horner_tab<7>(kPsiHU, t);
 }
 
