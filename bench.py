@@ -10,6 +10,8 @@ output fields to rank 0 when N > 1; the grid is j-block sharded across ranks: st
                     [--grid 4320x3600] [--precision f64] [--resident] [--no-cpu-baseline]
 
 --config picks a BASELINE.json configuration (default 3 = the headline):
+   1  NCAR, no skin, 360x180, nb_iter=5: the reference's own CPU-runnable case; the GPU runs it (launch-bound: 65 k cells) and
+      the cpu_baseline leg times the unmodified reference on exactly this workload (the product itself has no CPU path)
    2  COARE3p6, no skin, 1440x1080, nb_iter=8
    3  COARE3p6 + cool-skin/warm-layer, 4320x3600, nb_iter=5
    4  all five algorithms back-to-back on 4320x3600 (no skin scheme for any: one consistent setting; --skin adds
@@ -101,6 +103,26 @@ def balanced_peer_rows(nj, world, t_cell, bytes_per_cell_on_link, link_bytes_per
     return max(1, min(int(round(f * nj)), max(nj // world, 1)))
 
 
+def cpu_baseline_config1(niter, zt, zu):
+    """BASELINE config 1 on the CPU, as the reference runs it: NCAR, 360x180, one aerobulk_model(jt=1,Nt=1) call incl.
+    AEROBULK_INIT, the unmodified reference (oracle/_ref) in one process; the C port if _ref did not travel."""
+    from oracle import pyoracle as po
+    ni, nj = 360, 180
+    if po.have_reference():
+        dt = min(po.run_reference_all_cores("ncar", False, niter, ni, nj, 1)[0] for _ in range(3))
+        kind = "reference"
+    else:
+        f = po.synth_fields(ni, nj)
+        s = po.OracleSession("ncar", ni * nj, 1, False)
+        t0 = time.perf_counter()
+        s.compute(1, zt, zu, niter, f["sst"], f["t_zt"], f["hum_zt"], f["u_zu"], f["v_zu"], f["slp"])
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": round(ni * nj / dt / 1e6, 4), "unit": "Mcell/s", "cores": 1, "kind": kind,
+            "sample": f"the whole of config 1: ncar nb_iter={niter} on the 360x180 synthetic grid, one aerobulk_model(jt=1,Nt=1) call "
+                      f"incl. AEROBULK_INIT, single process, {dt * 1e3:.1f} ms"}
+
+
 def cpu_baseline(algo, skin, niter, zt, zu):
     """Reference Fortran (oracle/_ref, unmodified AeroBulk compiled with amdflang) timed on the host cores on a bounded
     sample of the same synthetic workload: first on ONE core (the reference is single-threaded), then on all cores at
@@ -134,7 +156,9 @@ def cpu_baseline(algo, skin, niter, zt, zu):
 def resolve_config(a):
     """(passes, grid, precision, niter, label): passes = [(algo, skin)] run back-to-back in one step."""
     explicit_grid = a.grid is not None
-    if a.config == 2:
+    if a.config == 1:
+        passes, grid, prec, niter = [("ncar", False)], "360x180", "f64", 5
+    elif a.config == 2:
         passes, grid, prec, niter = [("coare3p6", False)], "1440x1080", "f64", 8
     elif a.config == 4:
         passes = [(al, bool(a.skin) and al in SKIN_ALGOS) for al in ALL_ALGOS]
@@ -158,7 +182,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5], help="BASELINE.json configuration (see the module docstring)")
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5], help="BASELINE.json configuration (see the module docstring)")
     ap.add_argument("--algo", default="coare3p6")
     ap.add_argument("--no-skin", action="store_true")
     ap.add_argument("--skin", action="store_true", help="config 4: switch the skin scheme on for the three algorithms that have one")
@@ -487,7 +511,7 @@ def main():
             res["verify"] = verify_msg
         if not a.no_cpu_baseline and world == 1:
             try:
-                res["cpu_baseline"] = cpu_baseline(head_algo, head_skin, niter, zt, zu)
+                res["cpu_baseline"] = cpu_baseline_config1(niter, zt, zu) if a.config == 1 else cpu_baseline(head_algo, head_skin, niter, zt, zu)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"value": None, "unit": "Mcell/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)

@@ -149,7 +149,7 @@ def test_init_checks_on_gpu_match_reference_conditions(oracle):
 @pytest.mark.parametrize("world,extra", [(2, []), (2, ["--peer-rows", "-1", "--no-early-gather"]), (3, ["--peer-rows", "40", "--gather-ts"]),
                                          (4, []), (2, ["--config", "4"]), (3, ["--config", "4", "--skin", "--no-early-gather", "--peer-rows", "50"]),
                                          (2, ["--config", "5"]), (2, ["--config", "5", "--no-early-gather", "--peer-rows", "-1"]),
-                                         (2, ["--config", "2", "--peer-rows", "100"])])
+                                         (2, ["--config", "2", "--peer-rows", "100"]), (2, ["--config", "1"])])
 def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
     """bench.py's N>1 path (root-heavy j-block sharding measured or given, row chunks, packed gather joined by rank 0 before or
     after its own compute, reassembly; BASELINE configs 2-5) run as several ranks that share the one visible GPU, with the gloo

@@ -8,6 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNS = [
+    ("config 1: ncar, no skin, 360x180, nb_iter=5 (the reference's CPU case; reference timed on the same workload)", ["--config", "1", "--with-cpu-baseline"]),
     ("config 2: coare3p6, no skin, 1440x1080, nb_iter=8", ["--config", "2"]),
     ("config 3: coare3p6 + skin, 4320x3600, nb_iter=5 (headline)", []),
     ("config 3: coare3p6 + skin, 4320x3600, nb_iter=8", ["--niter", "8"]),
@@ -24,7 +25,9 @@ def main():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as fh:
         for label, extra in RUNS:
-            pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", *extra], capture_output=True, text=True)
+            base = [] if "--with-cpu-baseline" in extra else ["--no-cpu-baseline"]
+            extra = [e for e in extra if e != "--with-cpu-baseline"]
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *base, *extra], capture_output=True, text=True)
             line = [l for l in pr.stdout.splitlines() if l.startswith("{")]
             if not line:
                 print(label, "FAILED", pr.stderr[-500:])
