@@ -34,7 +34,8 @@ SEEDS = list(range(100, 112))
 @pytest.mark.parametrize("algo,skin,zt,zu,niter", [("coare3p6", True, 2.0, 10.0, 5), ("coare3p6", False, 10.0, 10.0, 8),
                                                     ("coare3p0", True, 3.5, 17.0, 4), ("ecmwf", True, 2.0, 10.0, 6),
                                                     ("ecmwf", False, 2.0, 10.0, 5), ("ncar", False, 2.0, 10.0, 5),
-                                                    ("andreas", False, 8.0, 12.0, 7)])
+                                                    ("andreas", False, 8.0, 12.0, 7),
+                                                    ("coare3p6", True, 18.0, 25.0, 5), ("ncar", False, 30.0, 10.0, 6)])   # zt > 10 m
 def test_random_inputs_match_oracle(oracle, seed, algo, skin, zt, zu, niter):
     import aerobulk_amd as ab
     n = 60000 + 13 * seed                                  # ragged: not a multiple of any tile size

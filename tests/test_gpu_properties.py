@@ -171,6 +171,28 @@ def test_fp32_sessions_against_fp64_oracle(oracle, torch_mod, algo):
             assert dts <= 5e-3
 
 
+@pytest.mark.parametrize("algo", ["coare3p6", "ecmwf"])
+def test_fp32_storage_carries_the_warm_layer_over_records(oracle, algo):
+    """AB_F32_STORAGE over three records: the warm-layer planes are fp32 arrays too (one rounding per record on top of the fp64
+    arithmetic), fluxes stay within 1e-5 of the fp64 oracle run on the same rounded inputs."""
+    import aerobulk_amd as ab
+    ni, nj, nt = 200, 60, 3
+    f = oracle.synth_fields(ni, nj)
+    names = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")
+    f32 = {k: f[k].astype(np.float32) for k in names}
+    f64 = {k: f32[k].astype(np.float64) for k in names}
+    osess = oracle.OracleSession(algo, ni * nj, nt, True)
+    with ab.Session(algo, ni, nj, nt, True, precision="f32_storage") as s:
+        for jt in range(1, nt + 1):
+            o = osess.compute(jt, 2.0, 10.0, 5, *[f64[k] for k in names[:6]], rad_sw=f64["rad_sw"], rad_lw=f64["rad_lw"])
+            g = s.compute(jt, 2.0, 10.0, *[f32[k] for k in names[:6]], Niter=5, rad_sw=f32["rad_sw"], rad_lw=f32["rad_lw"])
+            for k, c, fl in (("ql", "QL", 1.0), ("qh", "QH", 1.0), ("tau_x", "Tau_x", 1e-3)):
+                e = np.abs(g[c].astype(np.float64) - o[k]) / np.maximum(np.abs(o[k]), fl)
+                assert e.max() <= 1e-5, (algo, jt, k, float(e.max()))
+            assert np.abs(g["T_s"].astype(np.float64) - o["t_s"]).max() <= 4e-5
+        assert g["T_s"].dtype == np.float32
+
+
 def test_orca36_fp32_full_grid(torch_mod):
     """BASELINE config 5 at its full size on ONE GPU (12960 x 10800 = 140 M cells, ECMWF + cool-skin/warm-layer, fp32 arrays:
     7.8 GB): every cell against the fp64 path on the same numbers (15.7 GB more), and j-block invariance at that size."""
