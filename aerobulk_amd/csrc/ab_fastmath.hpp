@@ -256,34 +256,39 @@ AB_FM void lds_tables_init()
     for (int i = (int)threadIdx.x; i < 2 * kLogN; i += (int)blockDim.x) s_logtab[i] = kLogTab[i];
     for (int i = (int)threadIdx.x; i < kExpN; i += (int)blockDim.x) s_exptab[i] = kExpTab[i];
 }
-AB_FM double log_invc(int k) { return s_logtab[2 * (k - kLogK0)]; }
-// -DAB_LOG_LATE_LOGC issues the load of logc after the polynomial (the asm ties the address to q) so that the pair does
-// not sit in four VGPRs across it.  Measured: it takes the COARE + skin kernels from 22 to 10 spilled VGPRs without making
-// them faster, and costs every other kernel 5 % (exposed LDS latency): off.
-AB_FM double log_logc(int k, double &q)
+// the pair (invc[k], logc[k]) with ONE ds_read_b128
+AB_FM void log_pair(int k, double &invc, double &logc)
 {
-#ifdef AB_LOG_LATE_LOGC
-    asm volatile("" : "+v"(k), "+v"(q));
-#endif
-    return s_logtab[2 * (k - kLogK0) + 1];
+    typedef double ab_d2 __attribute__((ext_vector_type(2)));
+    const ab_d2 t = *(const ab_d2 *)&s_logtab[2 * (k - kLogK0)];
+    invc = t[0];
+    logc = t[1];
 }
 AB_FM int p_lo32(double z) { return __double2loint(z); }
+AB_FM int p_hi32(double z) { return __double2hiint(z); }
+AB_FM double p_hilo(int hi, int lo) { return __hiloint2double(hi, lo); }
 #else
-AB_FM double log_invc(int k) { return kLogTab[2 * (k - kLogK0)]; }
-AB_FM double log_logc(int k, double &) { return kLogTab[2 * (k - kLogK0) + 1]; }
+AB_FM void log_pair(int k, double &invc, double &logc) { invc = kLogTab[2 * (k - kLogK0)]; logc = kLogTab[2 * (k - kLogK0) + 1]; }
 AB_FM int p_lo32(double z) { int64_t b; std::memcpy(&b, &z, 8); return (int)(uint32_t)b; }
+AB_FM int p_hi32(double z) { int64_t b; std::memcpy(&b, &z, 8); return (int)(b >> 32); }
+AB_FM double p_hilo(int hi, int lo) { const uint64_t b = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double z; std::memcpy(&z, &b, 8); return z; }
 #endif
 AB_FM double qlog(double x)
 {
-    const int t = 1 - p_exp(x * 1.4142135623730951);          // x sqrt2 in [2^(e-1), 2^e): n = e - 1 = -t
-    const double m = p_ldexp(x, t);                           // [1/sqrt2, sqrt2) (+- 1 ulp at the ends)
+    // x = 2^n m, m in [1/sqrt2, sqrt2), by integer arithmetic on the high word (x > 0 normal): the offset makes the exponent field
+    // roll over at a mantissa of sqrt2.  Five 32-bit operations (half an fp64 slot each) instead of mul + frexp + ldexp.
+    int hi = p_hi32(x) + (0x3ff00000 - 0x3fe6a09e);
+    const int n = (hi >> 20) - 0x3ff;
+    hi = (hi & 0x000fffff) + 0x3fe6a09e;
+    const double m = p_hilo(hi, p_lo32(x));
     const int k = p_lo32(p_fma(m, 64.0, 6755399441055744.0)); // rint(64 m) in the low word of 64 m + 1.5 2^52
-    const double r = p_fma(m, log_invc(k), -1.0);
-    double q = horner_coefs<6>(kLogQ, r);
-    const double logc = log_logc(k, q);
-    const double nf = (double)t;                              // = -n
-    const double lo = p_fma(-nf, 1.9082149292705877e-10, p_fma(r * r, q, r));   // n ln2_lo + log1p(r)
-    return p_fma(-nf, 0.6931471803691238, logc + lo);         // n ln2_hi: 21 trailing zero bits, exact
+    double invc, logc;
+    log_pair(k, invc, logc);
+    const double r = p_fma(m, invc, -1.0);
+    const double q = horner_coefs<6>(kLogQ, r);
+    const double nf = (double)n;
+    const double lo = p_fma(nf, 1.9082149292705877e-10, p_fma(r * r, q, r));   // n ln2_lo + log1p(r)
+    return p_fma(nf, 0.6931471803691238, logc + lo);          // n ln2_hi: 21 trailing zero bits, exact
 }
 AB_FM double qlog10(double x) { return qlog(x) * 0.4342944819032518; }
 
