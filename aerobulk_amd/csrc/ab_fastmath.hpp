@@ -9,7 +9,7 @@
 // below is: hardware seed (v_rcp_f64 / v_rsq_f64 / v_log_f32+v_exp_f32) or frexp range reduction,
 // one Newton/Halley step, a near-minimax polynomial (tools/gen_poly.py, 60-digit Chebyshev fits;
 // truncation errors quoted per table) evaluated with FMAs.  log and exp, the two most frequent, are
-// table-driven (tools/gen_logtab.py, tools/gen_exptab.py): 1 008 B of tables per block in LDS, one
+// table-driven (tools/gen_logtab.py, tools/gen_exptab.py): 1 280 B of tables per block in LDS, one
 // ds_read per call, no division in log (an fp64 v_rcp/v_rsq/v_sqrt issues at a quarter of the FMA
 // rate, profiles/r1_instr_rates.txt).  Measured accuracy on the MI355X: tests/test_gpu_math.py (max
 // error in ulp vs 80-bit references).
@@ -213,40 +213,52 @@ AB_FM double qsqrt(double x) { return x > 0.0 ? qsqrt_pos(x) : (x == 0.0 ? 0.0 :
 
 // ---------------------------------------------------------------- log
 // log(x), x > 0 normal (1e-300 < x < 1e300), WITHOUT a division (tools/gen_logtab.py):
-//    x = 2^n m, m in [1/sqrt2, sqrt2);  k = rint(64 m) in [45,91];  r = m invc[k] - 1 (one FMA, |r| <= 0.0112);
-//    log x = n ln2 + logc[k] + r + r^2 Q(r),  Q degree 5 (8.2e-17 relative to log1p(r)).
-// invc[k] = double(64/k) and logc[k] = -log(invc[k]) of that ROUNDED value, so the identity is exact; k = 64 holds (1, 0):
-// arguments next to 1 lose nothing.  On the device the 47 pairs live in LDS (752 B per block, filled by lds_tables_init();
-// one ds_read_b128 per log on the LDS pipe): 18 VALU slots instead of 28 for the atanh form, whose (m-1)/(m+1) costs a
-// quarter-rate v_rcp_f64 plus five FMAs.
-constexpr int kLogK0 = 45, kLogK1 = 91, kLogN = kLogK1 - kLogK0 + 1;
+//    x = 2^n m, m in [1/sqrt2, sqrt2), by integer arithmetic on the high word;  i = the top six bits of (high word of m - 0x3fe6a09e):
+//    64 bins of equal width in the HIGH WORD (2^-7 wide in m below 1, 2^-6 above);  r = m invc[i] - 1 (one FMA, |r| <= 0.00797);
+//    log x = n ln2 + logc[i] + r + r^2 Q(r),  Q degree 5 (7.9e-18 relative to log1p(r)).
+// invc[i] = a double within 2048 ulp of 1/centre of bin i and logc[i] = -log(invc[i]) of that very value, so the identity is exact;
+// the value is picked so that logc[i] is within 0.002 ulp of a double (Gal's accurate tables: no rounding error of its own where it
+// cancels against r); the bin that holds 1.0 (i = 37) has (1, 0): arguments next to 1 lose nothing.  On the device the 64 pairs live in LDS (1 KB per block, filled
+// by lds_tables_init(); one ds_read_b128 per log on the LDS pipe).  Issue slots (profiles/r2_instr_rates.txt: 32-bit add / and /
+// shift right 0.5, conversions and fp64 operations 1): 3.5 for the range reduction and the table address (the index is a shift and
+// a mask of the integer the reduction already holds: no rint(64 m) through the fp64 pipe, no multiplication by the entry size),
+// 13 for the rest; the atanh form, whose (m-1)/(m+1) costs a quarter-rate v_rcp_f64 plus five FMAs, took 28.
+constexpr int kLogN = 64;
+constexpr int kLogHi0 = 0x3fe6a09e;   // high word of the first bin's lower edge
 AB_TAB double kLogTab[2 * kLogN] = {
-    1.4222222222222223, -0.35222059358935215, 1.391304347826087, -0.3302416868705768,
-    1.3617021276595744, -0.30873548164961323, 1.3333333333333333, -0.28768207245178085,
-    1.3061224489795917, -0.26706278524904514, 1.28, -0.2468600779315258,
-    1.2549019607843137, -0.22705745063534608, 1.2307692307692308, -0.20763936477824455,
-    1.2075471698113207, -0.18859116980754997, 1.1851851851851851, -0.16989903679539742,
-    1.1636363636363636, -0.15154989812720088, 1.1428571428571428, -0.13353139262452257,
-    1.1228070175438596, -0.11583181552512165, 1.103448275862069, -0.09844007281325251,
-    1.0847457627118644, -0.0813456394539524, 1.0666666666666667, -0.06453852113757116,
-    1.0491803278688525, -0.04800921918636066, 1.032258064516129, -0.03174869831458027,
-    1.0158730158730158, -0.015748356968139112, 1.0, 0.0,
-    0.9846153846153847, 0.015504186535965199, 0.9696969696969697, 0.03077165866675366,
-    0.9552238805970149, 0.04580953603129422, 0.9411764705882353, 0.060624621816434854,
-    0.927536231884058, 0.07522342123758752, 0.9142857142857143, 0.08961215868968717,
-    0.9014084507042254, 0.10379679368164355, 0.8888888888888888, 0.11778303565638351,
-    0.8767123287671232, 0.13157635778871932, 0.8648648648648649, 0.14518200984449783,
-    0.8533333333333334, 0.15860503017663852, 0.8421052631578947, 0.17185025692665928,
-    0.8311688311688312, 0.18492233849401193, 0.8205128205128205, 0.19782574332991992,
-    0.810126582278481, 0.21056476910734964, 0.8, 0.2231435513142097,
-    0.7901234567901234, 0.23556607131276697, 0.7804878048780488, 0.2478361639045812,
-    0.7710843373493976, 0.259957524436926, 0.7619047619047619, 0.2719337154836418,
-    0.7529411764705882, 0.2837681731306446, 0.7441860465116279, 0.2954642128938359,
-    0.735632183908046, 0.3070250352949119, 0.7272727272727273, 0.3184537311185346,
-    0.7191011235955056, 0.32975328637246804, 0.7111111111111111, 0.3409265869705932,
-    0.7032967032967034, 0.3519764231571781};
-AB_TAB double kLogQ[ab_pad4(6)] = {-0.5000000000000073, 0.33333333333333987, -0.24999999892817357, 0.19999999904726232,
-                          -0.16668981738710087, 0.14287772132727572};
+    1.40644436128414, -0.3410647898888517, 1.3911585248550262, -0.3301368711171478,
+    1.3762013820078562, -0.31932708200595056, 1.361562443597324, -0.3086328959046604,
+    1.3472316620821487, -0.29805186636911646, 1.3331994085272663, -0.28758162380243396,
+    1.319456451025955, -0.2772198722680176, 1.3059939344496874, -0.26696438647108617,
+    1.292803361414938, -0.2568130088856901, 1.2798765744029772, -0.24676364703454223,
+    1.2672057389322124, -0.23681427089685103, 1.254783327728728, -0.22696291045039368,
+    1.2426021058121426, -0.21720765332825334, 1.2306551164431476, -0.20754664258973268,
+    1.2189356678781564, -0.19797807460130737, 1.2074373208692561, -0.1885001970145037,
+    1.1961538768665148, -0.17911130683989204, 1.1850793668733912, -0.1698097486087498,
+    1.1742080409227147, -0.16059391262545036, 1.1635343581165691, -0.15146223329117808,
+    1.15305297721258, -0.14241318751028523, 1.142758747710458, -0.1334452931647212,
+    1.132646701412085, -0.12455710765648759, 1.1227120444296328, -0.1157472265177142,
+    1.1129501496031886, -0.10701428207487695, 1.1033565493169324, -0.09835694217646686,
+    1.093926928682626, -0.08977390897437691, 1.084657119066004, -0.0812639177537976,
+    1.0755430919438906, -0.07282573581642736, 1.0665809530686323, -0.0644581614106576,
+    1.057766936914743, -0.05616002269948234, 1.0490974014082133, -0.04793017677979518,
+    1.0405688229078331, -0.03976750873701078, 1.0321777914271648, -0.03167093073582645,
+    1.0239210060943469, -0.023639381155692068, 1.0157952708155107, -0.015671823748565364,
+    1.007797490156108, -0.0077672468426328335, 1.0, 0.0,
+    0.9844693264034321, 0.01565253791100063, 0.969555303642437, 0.030917762458129654,
+    0.9550864115216001, 0.04595345932607962, 0.9410430147093403, 0.06076642874188761,
+    0.9274066159941303, 0.07536317313375712, 0.9141597750029562, 0.0897499142680678,
+    0.9012860337864758, 0.10393260917227824, 0.8887698486020315, 0.11791696494722517,
+    0.876596527307675, 0.13170845255253164, 0.8647521718262919, 0.1453123196603031,
+    0.8532236252176837, 0.15873360263975042, 0.8419984229233082, 0.17197713775426254,
+    0.8310647478138687, 0.18504757162179197, 0.8204113886912318, 0.19794937100406718,
+    0.8100277019437235, 0.210686831969934, 0.7999035760765578, 0.2232640884828251,
+    0.7900293988675742, 0.23568512045706153, 0.7803960269295959, 0.24795376131534103,
+    0.7709947574686512, 0.26007370509348016, 0.7618173020615893, 0.272048513116802,
+    0.7528557622857108, 0.2838816202798194, 0.7441026070444319, 0.29557634096399765,
+    0.7355506514604842, 0.30713587460826597, 0.7271930372063615, 0.31856331096343943,
+    0.7190232141607429, 0.32986163504969085, 0.7110349232870385, 0.34103373183800156};
+AB_TAB double kLogQ[ab_pad4(6)] = {-0.500000000000001, 0.3333333333333342, -0.2499999997172448, 0.19999999974866162, -0.16667855714108057, 0.14286771218144256};
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
 static __shared__ __attribute__((aligned(16))) double s_logtab[2 * kLogN];
 static __shared__ double s_exptab[kExpN];
@@ -256,11 +268,11 @@ AB_FM void lds_tables_init()
     for (int i = (int)threadIdx.x; i < 2 * kLogN; i += (int)blockDim.x) s_logtab[i] = kLogTab[i];
     for (int i = (int)threadIdx.x; i < kExpN; i += (int)blockDim.x) s_exptab[i] = kExpTab[i];
 }
-// the pair (invc[k], logc[k]) with ONE ds_read_b128
-AB_FM void log_pair(int k, double &invc, double &logc)
+// the pair (invc[i], logc[i]) at byte offset 16 i with ONE ds_read_b128
+AB_FM void log_pair(int off16, double &invc, double &logc)
 {
     typedef double ab_d2 __attribute__((ext_vector_type(2)));
-    const ab_d2 t = *(const ab_d2 *)&s_logtab[2 * (k - kLogK0)];
+    const ab_d2 t = *(const ab_d2 *)((const char *)s_logtab + off16);
     invc = t[0];
     logc = t[1];
 }
@@ -268,7 +280,7 @@ AB_FM int p_lo32(double z) { return __double2loint(z); }
 AB_FM int p_hi32(double z) { return __double2hiint(z); }
 AB_FM double p_hilo(int hi, int lo) { return __hiloint2double(hi, lo); }
 #else
-AB_FM void log_pair(int k, double &invc, double &logc) { invc = kLogTab[2 * (k - kLogK0)]; logc = kLogTab[2 * (k - kLogK0) + 1]; }
+AB_FM void log_pair(int off16, double &invc, double &logc) { invc = kLogTab[off16 >> 3]; logc = kLogTab[(off16 >> 3) + 1]; }
 AB_FM int p_lo32(double z) { int64_t b; std::memcpy(&b, &z, 8); return (int)(uint32_t)b; }
 AB_FM int p_hi32(double z) { int64_t b; std::memcpy(&b, &z, 8); return (int)(b >> 32); }
 AB_FM double p_hilo(int hi, int lo) { const uint64_t b = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double z; std::memcpy(&z, &b, 8); return z; }
@@ -276,14 +288,13 @@ AB_FM double p_hilo(int hi, int lo) { const uint64_t b = ((uint64_t)(uint32_t)hi
 AB_FM double qlog(double x)
 {
     // x = 2^n m, m in [1/sqrt2, sqrt2), by integer arithmetic on the high word (x > 0 normal): the offset makes the exponent field
-    // roll over at a mantissa of sqrt2.  Five 32-bit operations (half an fp64 slot each) instead of mul + frexp + ldexp.
-    int hi = p_hi32(x) + (0x3ff00000 - 0x3fe6a09e);
+    // roll over at a mantissa of sqrt2; what is left below the exponent is the distance of m's high word from the first bin's edge.
+    const int hi = p_hi32(x) + (0x3ff00000 - kLogHi0);
     const int n = (hi >> 20) - 0x3ff;
-    hi = (hi & 0x000fffff) + 0x3fe6a09e;
-    const double m = p_hilo(hi, p_lo32(x));
-    const int k = p_lo32(p_fma(m, 64.0, 6755399441055744.0)); // rint(64 m) in the low word of 64 m + 1.5 2^52
+    const int f = hi & 0x000fffff;
+    const double m = p_hilo(f + kLogHi0, p_lo32(x));
     double invc, logc;
-    log_pair(k, invc, logc);
+    log_pair((int)((unsigned)f >> 10) & 0x3f0, invc, logc);      // 16 (f >> 14)
     const double r = p_fma(m, invc, -1.0);
     const double q = horner_coefs<6>(kLogQ, r);
     const double nf = (double)n;

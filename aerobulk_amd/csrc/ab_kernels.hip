@@ -42,7 +42,7 @@ template <class S> struct DiagArgs {
 // 1280 in fp32), and works in four phases:
 //   1. owners (thread = cell, natural order, coalesced loads): pre-processing of aerobulk_compute, an fp32 forecast of the
 //      two predicates -> one of 16 buckets, pre-processed inputs parked in LDS (field-major, <= 39 KB);
-//   2. counting sort of the tile's cell indices by bucket (packed 16-bit histograms, wave scan, no atomics);
+//   2. counting sort of the tile's cell indices by bucket (ranks from LDS atomics while phase 1 runs, ab_tile.hpp);
 //   3. waves fetch groups of 64 like-behaved cells (dynamic queue, most work first come) and run TURB_* + BULK_FORMULA;
 //      results go back to the cell's LDS slot;
 //   4. owners store the results (coalesced).
@@ -145,8 +145,7 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
     using T = Tile<R, ALGO, SKIN>;
     __shared__ R s_f[T::kFields][T::kCells];
     __shared__ unsigned short s_inv[T::kCells];
-    __shared__ unsigned char s_bkt[T::kCells];
-    __shared__ unsigned long long s_wtot[kBlock / 64][4];
+    __shared__ unsigned s_cnt[kSortCounters], s_base[kSortCounters];
     __shared__ int s_next;
     const int tid = threadIdx.x;
     const int rounds = a.rounds;                          // <= T::kRounds; fewer on small grids so that every CU gets blocks
@@ -154,6 +153,8 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
 
     // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126
     if (tid == 0) s_next = 0;
+    tile_sort_reset(s_cnt, tid);
+    __syncthreads();                                             // counters zeroed before the first atomic of phase 1
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
         const int j = r * kBlock + tid;
@@ -182,12 +183,12 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
                 bkt = 0;
             }
         }
-        s_bkt[j] = (unsigned char)bkt;
+        if (a.regroup) tile_sort_note(s_cnt, s_inv, j, bkt, tid);
     }
     __syncthreads();
     // ---- phase 2: who computes which cell
     if (a.regroup) {
-        tile_sort<T::kCells>(s_bkt, s_inv, s_wtot, tid, rounds);
+        tile_sort_place<T::kRounds>(s_cnt, s_base, s_inv, tid, rounds);
     } else {
         for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
     }

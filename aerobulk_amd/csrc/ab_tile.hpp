@@ -1,5 +1,5 @@
-// ab_tile.hpp — tile machinery shared by flux_kernel (ab_kernels.hip) and turb_kernel (ab_turb_kernels.hip): LDS budget of
-// a block, forecast of a cell's divergent predicates, counting sort of a tile's cells by bucket, tile size on small grids.
+// ab_tile.hpp — tile machinery shared by flux_kernel (ab_kernels.hip), turb_kernel (ab_turb_kernels.hip) and the sea-ice kernels: LDS
+// budget of a block, forecast of a cell's divergent predicates, counting sort of a tile's cells by bucket, tile size on small grids.
 // The method is described at flux_kernel.  Internal; include after ab_physics.hpp and ab_launch.hpp.
 #pragma once
 
@@ -39,9 +39,10 @@ template <class R> __device__ __forceinline__ Heights<R> detached(const Heights<
 }     // 4 stability bins x 4 warm-layer bins
 template <class R, int ALGO, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // flux: sst theta q_zt u v slp [qsw rlw] ; turb: 8 / 6 too
-    // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) + bucket (1 B) per cell
+    // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) per cell (budgeted with 3 B: the
+    // byte the former sort kept per cell is headroom now)
     static constexpr int kWaves = AB_WAVES_PER_EU * 256 / kBlock;      // resident blocks per CU
-    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0);   // 1024: fm::s_logtab (752 B) + fm::s_exptab (256 B)
+    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0);   // fm::s_logtab (1024 B) + fm::s_exptab (256 B): 1024 here, the rest from the 2048 held back above
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;
@@ -87,76 +88,55 @@ __device__ __forceinline__ int forecast_bucket(float sst, float theta, float q, 
     return sbin * 4 + ((sbin & 1) ? 3 - wbin : wbin);
 }
 
-// Counting sort of the tile's cells by bucket: thread t owns the PER consecutive cells t*PER.., builds their histogram as
-// sixteen 16-bit counters packed in four 64-bit words, the block scans those (wave shuffle + 4 wave totals through LDS).
-template <int CELLS>
-__device__ __forceinline__ void tile_sort(const unsigned char *s_bkt, unsigned short *s_inv, unsigned long long (*s_wtot)[4], int tid,
-                                          int per)
+// Counting sort of the tile's cells by bucket with LDS atomics (the LDS pipe is all but idle in these kernels, the VALU is the
+// bottleneck: the previous sort by packed 16-bit histograms and wave scans cost about 150 VALU slots per cell, this one about 7):
+//   tile_sort_reset   before the block's first barrier: zero the counters;
+//   tile_sort_note    phase 1, per cell: rank = atomicAdd(counter[bucket]) (ds_add_rtn_u32); rank and bucket are parked in the
+//                     cell's own s_inv entry (11 + 4 bits: tiles have at most 1280 cells);
+//   tile_sort_place   after the barrier that ends phase 1: wave 0 turns the counts into first slots, every thread takes its
+//                     cells' keys into registers, barrier, s_inv[first slot of the bucket + rank] = cell.
+// The order of the cells INSIDE a bucket depends on the order the atomics were served in, so the composition of a wave may differ
+// from run to run; the arithmetic of a cell does not depend on its neighbours, so every output bit is the same
+// (tests/test_gpu_regroup.py).
+// Lanes of one wave-instruction that hit the same counter are served one after the other (without the skin schemes only four of the
+// sixteen buckets exist).  kSortSub counters per bucket, picked by the low bits of the lane, would spread them: measured, four
+// sub-counters are no faster than one (coare3p6 skin 2.831 / 2.852 ms, no skin n=8 1.926 / 1.943 ms; profiles/r2_notes.md).
+#ifndef AB_SORT_SUB
+#define AB_SORT_SUB 1
+#endif
+constexpr int kSortRankBits = 11, kSortSub = AB_SORT_SUB, kSortCounters = kBuckets * kSortSub;
+__device__ __forceinline__ void tile_sort_reset(unsigned *s_cnt, int tid)
 {
-    typedef unsigned long long u64;
-    constexpr int PER = CELLS / kBlock;   // most cells a thread can own; `per` (<= PER) are in use (small grids: smaller tiles)
-    const int lane = tid & 63, wave = tid >> 6;
-    u64 h[4] = {0, 0, 0, 0};
-    unsigned char b[PER];
+    if (tid < kSortCounters) s_cnt[tid] = 0u;
+}
+__device__ __forceinline__ void tile_sort_note(unsigned *s_cnt, unsigned short *s_inv, int j, int bkt, int tid)
+{
+    const unsigned rank = atomicAdd(&s_cnt[bkt * kSortSub + (tid & (kSortSub - 1))], 1u);
+    s_inv[j] = (unsigned short)(rank | ((unsigned)bkt << kSortRankBits));
+}
+template <int MAXROUNDS>
+__device__ __forceinline__ void tile_sort_place(const unsigned *s_cnt, unsigned *s_base, unsigned short *s_inv, int tid, int rounds)
+{
+    static_assert(kSortCounters <= 64, "one wave scans the counters");
+    if (tid < 64) {   // exclusive prefix over the counters, bucket-major (wave 0)
+        const unsigned c = tid < kSortCounters ? s_cnt[tid] : 0u;
+        unsigned incl = c;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        b[i] = 0;
-        if (i < per) {
-            b[i] = s_bkt[tid * per + i];
-            const u64 inc = 1ull << ((b[i] & 3) * 16);
-            const int w = b[i] >> 2;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) h[x] += (w == x) ? inc : 0ull;
+        for (int d = 1; d < kSortCounters; d <<= 1) {
+            const unsigned t = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += t;
         }
+        if (tid < kSortCounters) s_base[tid] = incl - c;
     }
-    u64 inc4[4] = {h[0], h[1], h[2], h[3]};          // inclusive scan over the 64 lanes
+    unsigned key[MAXROUNDS];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const u64 t = __shfl_up(inc4[x], d);
-            if (lane >= d) inc4[x] += t;
-        }
-    }
-    if (lane == 63) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) s_wtot[wave][x] = inc4[x];
-    }
+    for (int r = 0; r < MAXROUNDS; ++r) key[r] = (r < rounds) ? (unsigned)s_inv[r * kBlock + tid] : 0u;
     __syncthreads();
-    u64 pos[4], tot[4];
+    const unsigned sub = (unsigned)tid & (kSortSub - 1);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        pos[x] = inc4[x] - h[x];
-        tot[x] = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
-            const u64 t = s_wtot[w][x];
-            tot[x] += t;
-            if (w < wave) pos[x] += t;
-        }
-    }
-    // exclusive prefix over the 16 bucket totals -> first slot of each bucket, packed the same way
-    const u64 ones = 0x0001000100010001ull;
-    u64 carry = 0;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const u64 p = tot[x] + (tot[x] << 16) + (tot[x] << 32) + (tot[x] << 48);   // inclusive prefix inside the word
-        pos[x] += p - tot[x] + carry * ones;
-        carry += p >> 48;
-    }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        if (i < per) {
-            const int sh = (b[i] & 3) * 16, w = b[i] >> 2;
-            u64 cur = pos[0];
-#pragma unroll
-            for (int x = 1; x < 4; ++x) cur = (w == x) ? pos[x] : cur;
-            s_inv[(cur >> sh) & 0xffffu] = (unsigned short)(tid * per + i);
-            const u64 inc = 1ull << sh;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) pos[x] += (w == x) ? inc : 0ull;
-        }
-    }
+    for (int r = 0; r < MAXROUNDS; ++r)
+        if (r < rounds)
+            s_inv[s_base[(key[r] >> kSortRankBits) * kSortSub + sub] + (key[r] & ((1u << kSortRankBits) - 1u))] = (unsigned short)(r * kBlock + tid);
 }
 
 // blocks the chip holds at once: AB_WAVES_PER_EU per CU (one wave of each block per SIMD)

@@ -83,13 +83,14 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const Tur
     using T = Tile<R, ALGO, ANYSKIN>;
     __shared__ R s_f[T::kFields][T::kCells];       // in: T_s theta q_s q_zt U [slp] [qsw rlw] ; out: the 8 results (6 without skin)
     __shared__ unsigned short s_inv[T::kCells];
-    __shared__ unsigned char s_bkt[T::kCells];
-    __shared__ unsigned long long s_wtot[kBlock / 64][4];
+    __shared__ unsigned s_cnt[kSortCounters], s_base[kSortCounters];
     __shared__ int s_next;
     const int tid = threadIdx.x;
     const int rounds = a.rounds;
     const long tile0 = (long)blockIdx.x * ((long)rounds * kBlock);
     if (tid == 0) s_next = 0;
+    tile_sort_reset(s_cnt, tid);
+    __syncthreads();                                             // counters zeroed before the first atomic of phase 1
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
         const int j = r * kBlock + tid;
@@ -112,11 +113,11 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) turb_kernel(const Tur
                                                                 wll ? (float)a.wl0[k] : 0.f, (wll && ALGO != 4) ? (float)a.wl1[k] : 20.f);
             }
         }
-        s_bkt[j] = (unsigned char)bkt;
+        if (a.regroup) tile_sort_note(s_cnt, s_inv, j, bkt, tid);
     }
     __syncthreads();
     if (a.regroup) {
-        tile_sort<T::kCells>(s_bkt, s_inv, s_wtot, tid, rounds);
+        tile_sort_place<T::kRounds>(s_cnt, s_base, s_inv, tid, rounds);
     } else {
         for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
     }

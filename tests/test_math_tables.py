@@ -1,5 +1,6 @@
 """The LDS tables of the fp64 log / exp (aerobulk_amd/csrc/ab_fastmath.hpp) are what tools/gen_logtab.py / gen_exptab.py define:
-invc[k] = double(64/k), logc[k] = -log(invc[k]) of that rounded value (k = 45..91; k = 64 holds exactly (1, 0)), T[j] = 2^(j/32)."""
+invc[i] within 2048 ulp of 1/centre of bin i for the 64 equal steps of m's high word from 0x3fe6a09e, logc[i] = -log(invc[i]) of that
+very value and within 0.002 ulp of exact, the bin that holds 1.0 has exactly (1, 0); T[j] = 2^(j/32)."""
 import os
 import re
 
@@ -20,12 +21,24 @@ def _table(name):
 
 def test_log_table_is_exactly_what_the_identity_needs():
     mp.mp.dps = 50
+    import struct
     t = _table("kLogTab").reshape(-1, 2)
-    assert t.shape == (47, 2)
-    for k, (invc, logc) in zip(range(45, 92), t):
-        assert invc == float(mp.mpf(64) / k)
-        assert logc == float(-mp.log(mp.mpf(invc)))           # of the ROUNDED reciprocal: log m = log(m invc) - log(invc) exactly
-    assert tuple(t[64 - 45]) == (1.0, 0.0)
+    assert t.shape == (64, 2)
+    edge = lambda i: struct.unpack("<d", struct.pack("<Q", (0x3FE6A09E + i * (1 << 14)) << 32))[0]
+    assert edge(0) < 0.5 ** 0.5 and edge(64) == 2 * edge(0)      # the bins cover one binade starting just below 1/sqrt2
+    worst = 0.0
+    for i, (invc, logc) in enumerate(t):
+        a, b = edge(i), edge(i + 1)
+        if a <= 1.0 < b:
+            assert (invc, logc) == (1.0, 0.0)
+        else:
+            c0 = float(1 / ((mp.mpf(a) + mp.mpf(b)) / 2))
+            assert abs(invc - c0) <= 2048 * np.spacing(c0)
+        lg = -mp.log(mp.mpf(invc))
+        assert logc == float(lg)                               # of THAT reciprocal: log m = log(m invc) - log(invc) exactly
+        assert abs(lg - mp.mpf(logc)) <= mp.mpf(0.002) * mp.mpf(float(np.spacing(abs(logc)))) or logc == 0.0   # accurate table
+        worst = max(worst, abs(a * invc - 1), abs(b * invc - 1))
+    assert worst < 0.00797                                     # the range the polynomial Q was fitted on
 
 
 def test_exp_table_and_reduction_constants():
