@@ -81,6 +81,13 @@ template <int N> struct ab_coefs {
     double v[N];
 };
 constexpr int ab_pad4(int n) { return (n + 3) & ~3; }
+// fp64 constants that have to sit in VGPRs.  VOP3 reads ONE scalar operand (SGPR pair or inline constant), so the second constant of
+// an FMA — above all the first Horner step c[N-1] x + c[N-2] of every polynomial — costs two v_mov_b32 = one issue slot
+// (profiles/r2_instr_rates.txt).  The LDS pipe is all but idle in these kernels: such constants are kept in a small LDS table
+// and fetched by a broadcast ds_read_b64, which costs the VALU nothing.  The entries repeat coefficients of the tables they
+// belong to (tests/test_math_tables.py checks that they are the same numbers).
+enum ab_const { kC_LogQ4 = 0, kC_ExpQ3, kC_AtanP9, kC_PsikM21, kC_PsikH21, kC_PsicL24, kC_PsicG19, kC_Goff13, kC_Third, kC_Quarter,
+                kC_TwoNinths, kC_5_32, kC_N = 12, kC_None = -1 };
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST) && !defined(AB_NO_CONST_TABLES)
 #define AB_TAB __constant__ __attribute__((aligned(64)))
 typedef const double __attribute__((address_space(4))) *ab_tabp;
@@ -118,19 +125,23 @@ template <int N> AB_FM ab_coefs<N> ab_load(const double *g)
 // address of the next chunk is made to depend on the partial sum, so that a 21-coefficient table occupies 16 scalar
 // registers instead of 48 while it is evaluated (the kernels are at the SGPR limit: every table register beyond that is
 // a spilled loop invariant, reloaded with v_readlane_b32 in the iteration loop).
-template <int N> AB_FM double horner_coefs(const double *g, double x)
+AB_FM double ldsc(int i);   // entry i of the LDS constant table (below)
+// CL (optional): entry of the LDS constant table that holds c[N-2] — or c[N-1] where that coefficient is alone in its chunk
+// ((N-1) % 8 == 0) — so that the first step needs no VGPR copy of a scalar coefficient.
+template <int N, int CL = kC_None> AB_FM double horner_coefs(const double *g, double x)
 {
-#ifdef AB_WHOLE_TABLES
-    const ab_coefs<N> c = ab_load<N>(g);
-    double p = c.v[N - 1];
-#pragma unroll
-    for (int i = N - 2; i >= 0; --i) p = p_fmac(p, x, c.v[i]);
-    return p;
-#else
     constexpr int NP = ab_pad4(N), TOP = (NP - 1) & ~7;
+#ifdef AB_NO_LDS_CONSTS
+    constexpr int C = kC_None;
+#else
+    constexpr int C = CL;
+#endif
+    constexpr bool top_alone = (N - 1) % 8 == 0;
     double p = 0.0;
+    if (C != kC_None && top_alone) p = ldsc(C);
 #pragma unroll
     for (int i = TOP; i >= 0; i -= 8) {
+        if (C != kC_None && top_alone && i == TOP) continue;   // the top chunk held c[N-1] only
         ab_tabp q = (ab_tabp)g + i;
         if (i == TOP)
             asm volatile("" : "+s"(q));
@@ -139,17 +150,24 @@ template <int N> AB_FM double horner_coefs(const double *g, double x)
         if (NP - i >= 8) {
             const ab_d8 t = *(const ab_d8 __attribute__((address_space(4))) *)q;
 #pragma unroll
-            for (int k = 7; k >= 0; --k)
-                if (i + k < N) p = (i + k == N - 1) ? t[k] : p_fmac(p, x, t[k]);
+            for (int k = 7; k >= 0; --k) {
+                if (i + k >= N) continue;
+                if (i + k == N - 1) { if (C == kC_None) p = t[k]; }
+                else if (i + k == N - 2 && C != kC_None && !top_alone) p = p_fma(t[k + 1], x, ldsc(C));
+                else p = p_fmac(p, x, t[k]);
+            }
         } else {
             const ab_d4 t = *(const ab_d4 __attribute__((address_space(4))) *)q;
 #pragma unroll
-            for (int k = 3; k >= 0; --k)
-                if (i + k < N) p = (i + k == N - 1) ? t[k] : p_fmac(p, x, t[k]);
+            for (int k = 3; k >= 0; --k) {
+                if (i + k >= N) continue;
+                if (i + k == N - 1) { if (C == kC_None) p = t[k]; }
+                else if (i + k == N - 2 && C != kC_None && !top_alone) p = p_fma(t[k + 1], x, ldsc(C));
+                else p = p_fmac(p, x, t[k]);
+            }
         }
     }
     return p;
-#endif
 }
 #else
 #define AB_TAB static const
@@ -159,13 +177,16 @@ template <int N> AB_FM ab_coefs<N> ab_load(const double *g)
     for (int i = 0; i < N; ++i) r.v[i] = g[i];
     return r;
 }
-template <int N> AB_FM double horner_coefs(const double *g, double x)
+template <int N, int CL = kC_None> AB_FM double horner_coefs(const double *g, double x)
 {
     double p = g[N - 1];
     for (int i = N - 2; i >= 0; --i) p = p_fmac(p, x, g[i]);
     return p;
 }
 #endif
+AB_TAB double kConstTab[kC_N] = {-0.16667855714108057, 0.008333362425171237, 0.03923165829558719, 6.446912234869585e-09,
+                                  4.251847861014437e-10, -7.386244013567452e-10, 7.426603654517993e-10, 5.6079820609247194e-12,
+                                  0.3333333333333333, 0.25, 0.2222222222222222, 0.15625};
 // T[j] = 2^(j/32) of qexp (tools/gen_exptab.py)
 constexpr int kExpN = 32;
 AB_TAB double kExpTab[kExpN] = {
@@ -262,12 +283,27 @@ AB_TAB double kLogQ[ab_pad4(6)] = {-0.500000000000001, 0.3333333333333342, -0.24
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
 static __shared__ __attribute__((aligned(16))) double s_logtab[2 * kLogN];
 static __shared__ double s_exptab[kExpN];
-// every kernel that may evaluate a log calls this first (all threads), then __syncthreads()
+static __shared__ double s_ctab[kC_N];
+// every kernel that may evaluate a log calls this first (all threads of a block of at least 2 kLogN = 128), then __syncthreads().
+// The three loads of a thread are issued together and waited for once (three copy loops meant three round trips to the constant
+// cache at the start of every block: visible in the kernels with short-lived blocks, NCAR above all).
 AB_FM void lds_tables_init()
 {
-    for (int i = (int)threadIdx.x; i < 2 * kLogN; i += (int)blockDim.x) s_logtab[i] = kLogTab[i];
-    for (int i = (int)threadIdx.x; i < kExpN; i += (int)blockDim.x) s_exptab[i] = kExpTab[i];
+    const int t = (int)threadIdx.x;
+    const double a = t < 2 * kLogN ? kLogTab[t] : 0.0;
+    const double b = t < kExpN ? kExpTab[t] : 0.0;
+    const double c = t < kC_N ? kConstTab[t] : 0.0;
+    if (t < 2 * kLogN) s_logtab[t] = a;
+    if (t < kExpN) s_exptab[t] = b;
+    if (t < kC_N) s_ctab[t] = c;
 }
+// Plain read: the compiler may share one fetch between the polynomials of a basic block.  (A volatile read, one per use, measured
+// the same within 0.3 %.)
+#ifdef AB_LDSC_VOLATILE
+AB_FM double ldsc(int i) { return *(const volatile double __attribute__((address_space(3))) *)&s_ctab[i]; }
+#else
+AB_FM double ldsc(int i) { return s_ctab[i]; }
+#endif
 // the pair (invc[i], logc[i]) at byte offset 16 i with ONE ds_read_b128
 AB_FM void log_pair(int off16, double &invc, double &logc)
 {
@@ -281,10 +317,22 @@ AB_FM int p_hi32(double z) { return __double2hiint(z); }
 AB_FM double p_hilo(int hi, int lo) { return __hiloint2double(hi, lo); }
 #else
 AB_FM void log_pair(int off16, double &invc, double &logc) { invc = kLogTab[off16 >> 3]; logc = kLogTab[(off16 >> 3) + 1]; }
+AB_FM double ldsc(int i) { return kConstTab[i]; }
 AB_FM int p_lo32(double z) { int64_t b; std::memcpy(&b, &z, 8); return (int)(uint32_t)b; }
 AB_FM int p_hi32(double z) { int64_t b; std::memcpy(&b, &z, 8); return (int)(b >> 32); }
 AB_FM double p_hilo(int hi, int lo) { const uint64_t b = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double z; std::memcpy(&z, &b, 8); return z; }
 #endif
+// a literal that would otherwise be copied into VGPRs (second constant of an FMA): entry i of the LDS constant table holds it
+AB_FM double vconst(int i, double literal)
+{
+#ifdef AB_NO_LDS_CONSTS
+    (void)i;
+    return literal;
+#else
+    (void)literal;
+    return ldsc(i);
+#endif
+}
 AB_FM double qlog(double x)
 {
     // x = 2^n m, m in [1/sqrt2, sqrt2), by integer arithmetic on the high word (x > 0 normal): the offset makes the exponent field
@@ -296,7 +344,7 @@ AB_FM double qlog(double x)
     double invc, logc;
     log_pair((int)((unsigned)f >> 10) & 0x3f0, invc, logc);      // 16 (f >> 14)
     const double r = p_fma(m, invc, -1.0);
-    const double q = horner_coefs<6>(kLogQ, r);
+    const double q = horner_coefs<6, kC_LogQ4>(kLogQ, r);
     const double nf = (double)n;
     const double lo = p_fma(nf, 1.9082149292705877e-10, p_fma(r * r, q, r));   // n ln2_lo + log1p(r)
     return p_fma(nf, 0.6931471803691238, logc + lo);          // n ln2_hi: 21 trailing zero bits, exact
@@ -318,7 +366,7 @@ AB_FM double exp_t(int j) { return kExpTab[j]; }
 AB_FM double exp_finish(double r, int k)
 {
     const double t = exp_t(k & (kExpN - 1));
-    const double q = p_fma(r * r, horner_coefs<5>(kExpQ, r), r);
+    const double q = p_fma(r * r, horner_coefs<5, kC_ExpQ3>(kExpQ, r), r);
     return p_ldexp(p_fma(t, q, t), k >> 5);
 }
 AB_FM double qexp(double x)
@@ -350,7 +398,7 @@ AB_FM double qatan(double x)
     const double blo = big ? 6.123233995736766e-17 : (mid ? 3.061616997868383e-17 : 0.0);
     const double t = qdiv(num, den);
     const double u = t * t;
-    const double p = horner_coefs<11>(kAtanP, u);
+    const double p = horner_coefs<11, kC_AtanP9>(kAtanP, u);
     const double r = bhi + (p_fma(t * u, p, blo) + t);
     return p_copysign(r, x);
 }
@@ -361,7 +409,7 @@ AB_FM double qatan_ge1(double x)
     const bool big = x > 2.414213562373095;
     const double t = qdiv(big ? -1.0 : x - 1.0, big ? x : x + 1.0);
     const double u = t * t;
-    const double p = horner_coefs<11>(kAtanP, u);
+    const double p = horner_coefs<11, kC_AtanP9>(kAtanP, u);
     return (big ? 1.5707963267948966 : 0.7853981633974483) + (p_fma(t * u, p, big ? 6.123233995736766e-17 : 3.061616997868383e-17) + t);
 }
 // 1/sqrt(x), x > 0 normal: rsq seed, one Newton step, one residual correction (<= 1 ulp)
@@ -378,7 +426,7 @@ AB_FM double qrcbrt_mid(double x)
 {
     const double r = (double)p_exp2f(p_log2f((float)x) * -0.33333334f);
     const double h = p_fma(-(x * (r * r)), r, 1.0);      // 1 - x r^3
-    return p_fma(r * h, p_fma(h, 0.2222222222222222, 0.3333333333333333), r);
+    return p_fma(r * h, p_fma(h, 0.2222222222222222, vconst(kC_Third, 0.3333333333333333)), r);
 }
 // x^(-1/4) for x in [2^-100, 2^100] (float range): fp32 log2/exp2 seed u (relative error d <= ~1e-6), one cubic step on
 // h = 1 - x u^4 (= 4 d): u (1 + h/4 + 5 h^2/32), truncation 15/128 h^3 < 1e-17.  13.5 issue slots; x^0.75 = x * that, where two
@@ -388,7 +436,7 @@ AB_FM double qrqrt_mid(double x)
     const double u = (double)p_exp2f(p_log2f((float)x) * -0.25f);
     const double u2 = u * u;
     const double h = p_fma(-x, u2 * u2, 1.0);
-    return p_fma(u * h, p_fma(h, 0.15625, 0.25), u);
+    return p_fma(u * h, p_fma(h, 0.15625, vconst(kC_Quarter, 0.25)), u);
 }
 // cbrt(x), x >= 0.  Arguments below 2^-100 return 0 (callers add the square of it to O(1) terms).
 AB_FM double qcbrt(double x)

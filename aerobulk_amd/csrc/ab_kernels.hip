@@ -106,7 +106,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     tx = R(0.);
     ty = R(0.);
     if (in.wnd > R(1.E-3)) {
-        const R s = zTaum / in.wnd;
+        const R s = M::div(zTaum, in.wnd);
         // tiled path: u and v are still in the cell's LDS slots; re-reading them here keeps 4 VGPRs free across the iteration
         if constexpr (TILED) {
             tx = s * *pu;
@@ -122,18 +122,21 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
 template <class R, int ALGO, bool SKIN, bool DIAG, class S = R>
 __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R, S> a, const DiagArgs<S> dg)
 {
-    math_tables_init<R>();
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
-        if (k >= a.n) return;
-        const R slp = (R)a.slp[k], t_zt = (R)a.t_zt[k], hum = (R)a.hum[k];
+        const bool live = k < a.n;
+        // the cell's loads are in flight while the block fills its math tables
+        R slp = R(101000.), t_zt = R(290.), hum = R(0.01), sst = R(290.), uu = R(1.), vv = R(1.);
+        if (live) { slp = (R)a.slp[k]; t_zt = (R)a.t_zt[k]; hum = (R)a.hum[k]; sst = (R)a.sst[k]; uu = (R)a.u[k]; vv = (R)a.v[k]; }
+        math_tables_init<R>();
+        if (!live) return;
         R q_zt;
         if (a.hum_type == 0) q_zt = hum;
         else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));
         else q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));
         R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG, false, S>(a, dg, a.h, a.nb_iter, k, (R)a.sst[k], theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt), q_zt,
-                                                    (R)a.u[k], (R)a.v[k], slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
+        compute_cell<R, ALGO, SKIN, DIAG, false, S>(a, dg, a.h, a.nb_iter, k, sst, theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt), q_zt,
+                                                    uu, vv, slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
         a.ql[k] = (S)QL;
         a.qh[k] = (S)QH;
         a.tau_x[k] = (S)tx;
@@ -151,17 +154,33 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
     const int rounds = a.rounds;                          // <= T::kRounds; fewer on small grids so that every CU gets blocks
     const long tile0 = (long)blockIdx.x * ((long)rounds * kBlock);
 
-    // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126
+    // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126.  The loads of a round are
+    // issued one round ahead: those of round 0 are in flight while the block fills its math tables, those of round r+1 while
+    // round r is pre-processed (a block starts with nothing else to hide that latency behind).
+    struct Raw { R sst, t_zt, hum, uu, vv, slp, rsw, rlw; };
+    auto fetch = [&](int r) -> Raw {
+        Raw w{R(290.), R(290.), R(0.01), R(1.), R(1.), R(101000.), R(0.), R(0.)};
+        const long k = tile0 + r * kBlock + tid;
+        if (r < rounds && k < a.n) {
+            w.sst = (R)a.sst[k]; w.t_zt = (R)a.t_zt[k]; w.hum = (R)a.hum[k]; w.uu = (R)a.u[k]; w.vv = (R)a.v[k]; w.slp = (R)a.slp[k];
+            if (SKIN) { w.rsw = (R)a.rad_sw[k]; w.rlw = (R)a.rad_lw[k]; }
+        }
+        return w;
+    };
+    Raw nxt = fetch(0);
     if (tid == 0) s_next = 0;
     tile_sort_reset(s_cnt, tid);
-    __syncthreads();                                             // counters zeroed before the first atomic of phase 1
+    math_tables_init<R>();
+    if (sizeof(R) != 8) __syncthreads();                  // (fp64: the barrier of math_tables_init) counters zeroed before phase 1
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
         const int j = r * kBlock + tid;
         const long k = tile0 + j;
+        const Raw w = nxt;
+        nxt = fetch(r + 1);
         int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
         if (k < a.n) {
-            const R sst = (R)a.sst[k], t_zt = (R)a.t_zt[k], hum = (R)a.hum[k], uu = (R)a.u[k], vv = (R)a.v[k], slp = (R)a.slp[k];
+            const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
             R q_zt;
             if (a.hum_type == 0) q_zt = hum;                                        // 'sh'
             else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));   // 'dp' :103
@@ -170,8 +189,8 @@ __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const Flu
             s_f[0][j] = sst; s_f[1][j] = theta; s_f[2][j] = q_zt; s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
             R qsw = R(0.), rlw = R(0.);
             if (SKIN) {
-                qsw = (R(1.) - K<R>::roce_alb0) * (R)a.rad_sw[k];                   // :135,146,161
-                rlw = (R)a.rad_lw[k];
+                qsw = (R(1.) - K<R>::roce_alb0) * w.rsw;                            // :135,146,161
+                rlw = w.rlw;
                 s_f[SKIN ? 6 : 0][j] = qsw; s_f[SKIN ? 7 : 0][j] = rlw;
             }
             if (a.regroup) {

@@ -76,7 +76,7 @@ AB_TAB double kGoffA[fm::ab_pad4(15)] = {1.2415921763001385, 0.6554537644583072,
                                   5.6079820609247194e-12, -6.519141017660851e-13};
 __device__ __forceinline__ double goff_poly(double x)
 {
-    return fm::horner_coefs<15>(kGoffA, x);
+    return fm::horner_coefs<15, fm::kC_Goff13>(kGoffA, x);
 }
 __device__ __forceinline__ float goff_poly(float x)
 {
@@ -86,11 +86,11 @@ __device__ __forceinline__ float goff_poly(float x)
     return p;
 }
 // Horner evaluation of a constant-memory coefficient table (coefficients fetched with scalar loads)
-template <int N> __device__ __forceinline__ double horner_tab(const double *tab, double x)
+template <int N, int CL = fm::kC_None> __device__ __forceinline__ double horner_tab(const double *tab, double x)
 {
-    return fm::horner_coefs<N>(tab, x);
+    return fm::horner_coefs<N, CL>(tab, x);
 }
-template <int N> __device__ __forceinline__ float horner_tab(const double *tab, float x)
+template <int N, int CL = fm::kC_None> __device__ __forceinline__ float horner_tab(const double *tab, float x)
 {
     float p = (float)tab[N - 1];
 #pragma unroll
@@ -457,9 +457,9 @@ template <class R> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
     using M = Mth<R>;
     const R L = M::log(y);
     // (fp64 only: in fp32 the hardware exponential costs two slots and a degree-24 polynomial is a loss)
-    if (sizeof(R) == 8 && L <= R(7.4433710715553465)) return horner_tab<25>(kPsicL, L * R(2. / 7.4433710715553465) - R(1.));
+    if (sizeof(R) == 8 && L <= R(7.4433710715553465)) return horner_tab<25, fm::kC_PsicL24>(kPsicL, L * R(2. / 7.4433710715553465) - R(1.));
     const R w = M::exp(R(-.3333) * L);
-    return R(.9999) * L + horner_tab<21>(kPsicG, R(2.) * w - R(1.));
+    return R(.9999) * L + horner_tab<21, fm::kC_PsicG19>(kPsicG, R(2.) * w - R(1.));
 }
 // The Kansas / Paulson unstable profile functions (mod_common_coare.f90:235-238,326-328 with y = |1 - 15 zeta|;
 // mod_blk_ecmwf.f90:462-467,519-523, mod_blk_ncar.f90:350-362, mod_blk_andreas.f90:351-358,402-408 with y = |1 - 16 zeta|):
@@ -486,8 +486,8 @@ template <class R> __device__ __forceinline__ void psik(R y, R *pm, R *ph)
         const R sl = M::log(y);
         if (sl <= R(6.68586094706836)) {
             const R t = sl * R(2. / 6.68586094706836) - R(1.);
-            *pm = horner_tab<23>(kPsikM, t);
-            if (ph) *ph = horner_tab<23>(kPsikH, t);
+            *pm = horner_tab<23, fm::kC_PsikM21>(kPsikM, t);
+            if (ph) *ph = horner_tab<23, fm::kC_PsikH21>(kPsikH, t);
             return;
         }
     }

@@ -13,6 +13,7 @@ namespace ab {
 #endif
 
 constexpr int kBuckets = 16;
+static_assert(kBlock >= 2 * fm::kLogN, "fm::lds_tables_init() copies one table entry per thread");
 
 // detach a wave-uniform value from the scalar-load tuple it arrived in (see flux_kernel, phase 3)
 template <class T> __device__ __forceinline__ void uniform_scalar(T &x)
@@ -67,8 +68,9 @@ __device__ __forceinline__ int forecast_bucket(float sst, float theta, float q, 
         const F Cx = dthv > 0.f ? 0.96e-3f : 1.38e-3f;
         const F t2 = Ts * Ts;
         const F qns = 1.2f * Ub * Cx * (1005.f * (theta - Ts) + 2.45e6f * (q - qs)) + 0.98f * (rlw - 5.67e-8f * t2 * t2);
-        const F Hz = wl_load ? vmax(vmin(Hzprev, 20.f), 0.1f) : 20.f;
-        const F qabs = wl_absorb<F>(Hz) * qsw + qns;
+        // first record of a series: the layer depth is its initial 20 m, the absorbed fraction a constant (three exponentials less)
+        const F fabs = wl_load ? wl_absorb<F>(vmax(vmin(Hzprev, 20.f), 0.1f)) : 0.76714447f;
+        const F qabs = fabs * qsw + qns;
         wbin = qabs < -40.f ? 0 : (qabs < 0.f ? 1 : (qabs < 40.f ? 2 : 3));
         if (wl_load && M::abs(dTprev) >= 1.e-6f && wbin < 2) wbin = 2;
         if (qabs > 0.f) {      // the warming of this record shifts the stability: estimate of mod_skin_coare.f90:199-224

@@ -53,3 +53,34 @@ def test_exp_table_and_reduction_constants():
         m, _ = np.frexp(head)
         assert (m * 2.0 ** 30) == int(m * 2.0 ** 30)
         assert abs(mp.mpf(head) + mp.mpf(tail) - val) < mp.mpf(10) ** -28
+
+
+def test_lds_constant_table_repeats_the_coefficients_it_stands_for():
+    """fm::kConstTab (constants fetched from LDS instead of being copied into VGPRs) holds c[N-2] of the polynomial tables (c[N-1]
+    where the top coefficient is alone in its chunk of eight) and four literals of the cube / fourth root refinements."""
+    phys = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_physics.hpp")).read()
+
+    def tab(src, name):
+        m = re.search(rf"AB_TAB double {name}\[[^\]]*\] = \{{(.*?)\}};", src, re.S)
+        assert m, name
+        return [float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()]
+
+    names = re.search(r"enum ab_const \{(.*?)\};", HDR, re.S).group(1)
+    names = [n.split("=")[0].strip() for n in names.replace("\n", " ").split(",")]
+    names = [n for n in names if n and n not in ("kC_N", "kC_None")]
+    c = tab(HDR, "kConstTab")
+    assert len(c) == len(names) == 12
+    want = {"kC_LogQ4": tab(HDR, "kLogQ")[4], "kC_ExpQ3": tab(HDR, "kExpQ")[3], "kC_AtanP9": tab(HDR, "kAtanP")[9],
+            "kC_PsikM21": tab(phys, "kPsikM")[21], "kC_PsikH21": tab(phys, "kPsikH")[21], "kC_PsicL24": tab(phys, "kPsicL")[24],
+            "kC_PsicG19": tab(phys, "kPsicG")[19], "kC_Goff13": tab(phys, "kGoffA")[13], "kC_Third": 0.3333333333333333,
+            "kC_Quarter": 0.25, "kC_TwoNinths": 0.2222222222222222, "kC_5_32": 0.15625}
+    for n, v in zip(names, c):
+        assert v == want[n], n
+    # (N, entry) as used: the entry is c[N-2], or c[N-1] when (N-1) % 8 == 0
+    for n, (N, t) in {"kC_LogQ4": (6, "kLogQ"), "kC_ExpQ3": (5, "kExpQ"), "kC_AtanP9": (11, "kAtanP")}.items():
+        assert f"horner_coefs<{N}, {n}>({t}," in HDR
+    for n, (N, t) in {"kC_PsikM21": (23, "kPsikM"), "kC_PsikH21": (23, "kPsikH"), "kC_PsicL24": (25, "kPsicL"), "kC_PsicG19": (21, "kPsicG")}.items():
+        assert f"horner_tab<{N}, fm::{n}>({t}," in phys
+        idx = int(re.search(r"(\d+)$", n).group(1))
+        assert idx == (N - 1 if (N - 1) % 8 == 0 else N - 2)
+    assert "horner_coefs<15, fm::kC_Goff13>(kGoffA," in phys
