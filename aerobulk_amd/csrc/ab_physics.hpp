@@ -418,6 +418,10 @@ __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, const WlEcmwfCell<R> 
             zdTwl_n = R(0.5) * (zdTwl_n + zdTwl_b);
             zdTwl_n = vmax(zdTwl_b + zA + zB * zdTwl_n, R(0.));
         }
+    } else if (zdTwl_b == R(0.)) {
+        // cooling with no warm layer to erode (every cell of a first record, every night after the layer is gone): the ten passes
+        // give MAX(0 + zA + zB*0, 0) with zA <= 0, i.e. exactly 0 each time.  Ten square roots and ten divisions not executed.
+        zdTwl_n = R(0.);
     } else {
 #pragma unroll 1
         for (int jc = 0; jc < 10; ++jc) {

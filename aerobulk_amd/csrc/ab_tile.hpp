@@ -62,25 +62,33 @@ __device__ __forceinline__ int forecast_bucket(float sst, float theta, float q, 
     const F qs = 0.98f * q_sat<F>(Ts, slp);
     F dthv = theta * (1.f + 0.608f * q) - Ts * (1.f + 0.608f * qs);   // sign of the bulk Richardson number
     int wbin = 0;
-    if (SKIN && ALGO != 4) {   // WL_COARE runs its depth solve only where the layer gains heat (mod_skin_coare.f90:171-185)
+    // WL_ECMWF runs its ten-pass erosion (a square root and a division per pass) only where a warm layer EXISTS and loses heat
+    // (mod_skin_ecmwf.f90:210-225; exact shortcuts in wl_ecmwf): worth a bin from the second record of a series on
+    const bool ecmwf_layer = SKIN && ALGO == 4 && wl_load && dTprev > 0.f;
+    if ((SKIN && ALGO != 4) || ecmwf_layer) {
         const F w2 = uu * uu + vv * vv;
         const F wnd = M::sqrt(w2), Ub = vmax(M::sqrt(w2 + 0.25f), 0.5f);
         const F Cx = dthv > 0.f ? 0.96e-3f : 1.38e-3f;
         const F t2 = Ts * Ts;
         const F qns = 1.2f * Ub * Cx * (1005.f * (theta - Ts) + 2.45e6f * (q - qs)) + 0.98f * (rlw - 5.67e-8f * t2 * t2);
-        // first record of a series: the layer depth is its initial 20 m, the absorbed fraction a constant (three exponentials less)
-        const F fabs = wl_load ? wl_absorb<F>(vmax(vmin(Hzprev, 20.f), 0.1f)) : 0.76714447f;
-        const F qabs = fabs * qsw + qns;
-        wbin = qabs < -40.f ? 0 : (qabs < 0.f ? 1 : (qabs < 40.f ? 2 : 3));
-        if (wl_load && M::abs(dTprev) >= 1.e-6f && wbin < 2) wbin = 2;
-        if (qabs > 0.f) {      // the warming of this record shifts the stability: estimate of mod_skin_coare.f90:199-224
-            const F alpha = alpha_sw<F>(sst);
-            const F tac = vmax(1.44e-3f * Ub * wnd, 0.002f) * 3600.f;
-            const F qac = qabs * 3600.f;
-            const F hz = vmax(vmin(20.f, M::sqrt(5.422e-1f * M::rcp(alpha)) * tac * M::rsqrt_pos(qac)), 0.1f);
-            F dT = M::sqrt(2.942e-2f * alpha) * 3.687e-6f * qac * M::sqrt(qac) * M::rcp(tac);
-            if (hz < 1.f) dT *= M::rcp(hz);
-            dthv -= dT * (1.f + 11.5f * qs);
+        if (ALGO == 4) {
+            const F qabs = 0.635176f * qsw + qns;   // absorbed fraction of the fixed 3 m layer (mod_skin_ecmwf.f90:152)
+            wbin = qabs < -40.f ? 3 : (qabs < 0.f ? 2 : (qabs < 40.f ? 1 : 0));
+        } else {   // WL_COARE runs its depth solve only where the layer gains heat (mod_skin_coare.f90:171-185)
+            // first record of a series: the layer depth is its initial 20 m, the absorbed fraction a constant (three exponentials less)
+            const F fabs = wl_load ? wl_absorb<F>(vmax(vmin(Hzprev, 20.f), 0.1f)) : 0.76714447f;
+            const F qabs = fabs * qsw + qns;
+            wbin = qabs < -40.f ? 0 : (qabs < 0.f ? 1 : (qabs < 40.f ? 2 : 3));
+            if (wl_load && M::abs(dTprev) >= 1.e-6f && wbin < 2) wbin = 2;
+            if (qabs > 0.f) {      // the warming of this record shifts the stability: estimate of mod_skin_coare.f90:199-224
+                const F alpha = alpha_sw<F>(sst);
+                const F tac = vmax(1.44e-3f * Ub * wnd, 0.002f) * 3600.f;
+                const F qac = qabs * 3600.f;
+                const F hz = vmax(vmin(20.f, M::sqrt(5.422e-1f * M::rcp(alpha)) * tac * M::rsqrt_pos(qac)), 0.1f);
+                F dT = M::sqrt(2.942e-2f * alpha) * 3.687e-6f * qac * M::sqrt(qac) * M::rcp(tac);
+                if (hz < 1.f) dT *= M::rcp(hz);
+                dthv -= dT * (1.f + 11.5f * qs);
+            }
         }
     }
     const int sbin = dthv < -0.3f ? 0 : (dthv < 0.f ? 1 : (dthv < 0.3f ? 2 : 3));
