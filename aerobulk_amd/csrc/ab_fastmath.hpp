@@ -279,7 +279,7 @@ AB_TAB double kLogTab[2 * kLogN] = {
     0.7528557622857108, 0.2838816202798194, 0.7441026070444319, 0.29557634096399765,
     0.7355506514604842, 0.30713587460826597, 0.7271930372063615, 0.31856331096343943,
     0.7190232141607429, 0.32986163504969085, 0.7110349232870385, 0.34103373183800156};
-AB_TAB double kLogQ[ab_pad4(6)] = {-0.500000000000001, 0.3333333333333342, -0.2499999997172448, 0.19999999974866162, -0.16667855714108057, 0.14286771218144256};
+#define AB_LOGQ -0.500000000000001, 0.3333333333333342, -0.2499999997172448, 0.19999999974866162, -0.16667855714108057, 0.14286771218144256   /* Q, degree 5 */
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
 static __shared__ __attribute__((aligned(16))) double s_logtab[2 * kLogN];
 static __shared__ double s_exptab[kExpN];
@@ -333,6 +333,22 @@ AB_FM double vconst(int i, double literal)
     return ldsc(i);
 #endif
 }
+// The two short polynomials every log and every exponential evaluates (about 90 times per cell of the headline kernel) take their
+// coefficients as instruction literals (two s_mov_b32 each on the scalar unit, which has the room): no s_load and no wait for it,
+// no SGPR tuple to keep alive (SGPR spills of the headline kernel 45 -> 23).  The first step's second constant comes from the LDS
+// constant table.  Same-box: coare3p6 skin -0.6 %, no skin -1 %, ANDREAS -2.7 % (profiles/r2_notes.md).
+template <int CL> AB_FM double horner_lit6(double x, double c0, double c1, double c2, double c3, double c4, double c5)
+{
+    double p = p_fma(c5, x, vconst(CL, c4));
+    p = p_fma(p, x, c3); p = p_fma(p, x, c2); p = p_fma(p, x, c1);
+    return p_fma(p, x, c0);
+}
+template <int CL> AB_FM double horner_lit5(double x, double c0, double c1, double c2, double c3, double c4)
+{
+    double p = p_fma(c4, x, vconst(CL, c3));
+    p = p_fma(p, x, c2); p = p_fma(p, x, c1);
+    return p_fma(p, x, c0);
+}
 AB_FM double qlog(double x)
 {
     // x = 2^n m, m in [1/sqrt2, sqrt2), by integer arithmetic on the high word (x > 0 normal): the offset makes the exponent field
@@ -344,7 +360,7 @@ AB_FM double qlog(double x)
     double invc, logc;
     log_pair((int)((unsigned)f >> 10) & 0x3f0, invc, logc);      // 16 (f >> 14)
     const double r = p_fma(m, invc, -1.0);
-    const double q = horner_coefs<6, kC_LogQ4>(kLogQ, r);
+    const double q = horner_lit6<kC_LogQ4>(r, AB_LOGQ);
     const double nf = (double)n;
     const double lo = p_fma(nf, 1.9082149292705877e-10, p_fma(r * r, q, r));   // n ln2_lo + log1p(r)
     return p_fma(nf, 0.6931471803691238, logc + lo);          // n ln2_hi: 21 trailing zero bits, exact
@@ -356,7 +372,7 @@ AB_FM double qlog10(double x) { return qlog(x) * 0.4342944819032518; }
 //    exp x = 2^e T[j] (1 + r + r^2 P(r)),  T[j] = 2^(j/32),  P degree 4 (2.2e-19 relative) instead of degree 9 on |r| <= ln2/2.
 // T lives in LDS next to the log table (256 B per block, lds_tables_init()); 16 VALU slots instead of 19.
 // Any finite x: the exponent goes through a saturating conversion and ldexp (0 / inf beyond +-745).
-AB_TAB double kExpQ[ab_pad4(5)] = {0.5, 0.16666666666581356, 0.04166666666656003, 0.008333362425171237, 0.0013888925253674421};
+#define AB_EXPQ 0.5, 0.16666666666581356, 0.04166666666656003, 0.008333362425171237, 0.0013888925253674421   /* P, degree 4 */
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
 AB_FM double exp_t(int j) { return s_exptab[j]; }
 #else
@@ -366,7 +382,7 @@ AB_FM double exp_t(int j) { return kExpTab[j]; }
 AB_FM double exp_finish(double r, int k)
 {
     const double t = exp_t(k & (kExpN - 1));
-    const double q = p_fma(r * r, horner_coefs<5, kC_ExpQ3>(kExpQ, r), r);
+    const double q = p_fma(r * r, horner_lit5<kC_ExpQ3>(r, AB_EXPQ), r);
     return p_ldexp(p_fma(t, q, t), k >> 5);
 }
 AB_FM double qexp(double x)

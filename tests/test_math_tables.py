@@ -70,14 +70,21 @@ def test_lds_constant_table_repeats_the_coefficients_it_stands_for():
     names = [n for n in names if n and n not in ("kC_N", "kC_None")]
     c = tab(HDR, "kConstTab")
     assert len(c) == len(names) == 12
-    want = {"kC_LogQ4": tab(HDR, "kLogQ")[4], "kC_ExpQ3": tab(HDR, "kExpQ")[3], "kC_AtanP9": tab(HDR, "kAtanP")[9],
+    def macro(name):     # coefficient lists kept as macros (instruction literals)
+        m = re.search(rf"#define {name} ([^/\n]*)", HDR)
+        assert m, name
+        return [float(x) for x in m.group(1).split(",")]
+
+    assert len(macro("AB_LOGQ")) == 6 and len(macro("AB_EXPQ")) == 5
+    assert "horner_lit6<kC_LogQ4>(r, AB_LOGQ)" in HDR and "horner_lit5<kC_ExpQ3>(r, AB_EXPQ)" in HDR
+    want = {"kC_LogQ4": macro("AB_LOGQ")[4], "kC_ExpQ3": macro("AB_EXPQ")[3], "kC_AtanP9": tab(HDR, "kAtanP")[9],
             "kC_PsikM21": tab(phys, "kPsikM")[21], "kC_PsikH21": tab(phys, "kPsikH")[21], "kC_PsicL24": tab(phys, "kPsicL")[24],
             "kC_PsicG19": tab(phys, "kPsicG")[19], "kC_Goff13": tab(phys, "kGoffA")[13], "kC_Third": 0.3333333333333333,
             "kC_Quarter": 0.25, "kC_TwoNinths": 0.2222222222222222, "kC_5_32": 0.15625}
     for n, v in zip(names, c):
         assert v == want[n], n
     # (N, entry) as used: the entry is c[N-2], or c[N-1] when (N-1) % 8 == 0
-    for n, (N, t) in {"kC_LogQ4": (6, "kLogQ"), "kC_ExpQ3": (5, "kExpQ"), "kC_AtanP9": (11, "kAtanP")}.items():
+    for n, (N, t) in {"kC_AtanP9": (11, "kAtanP")}.items():
         assert f"horner_coefs<{N}, {n}>({t}," in HDR
     for n, (N, t) in {"kC_PsikM21": (23, "kPsikM"), "kC_PsikH21": (23, "kPsikH"), "kC_PsicL24": (25, "kPsicL"), "kC_PsicG19": (21, "kPsicG")}.items():
         assert f"horner_tab<{N}, fm::{n}>({t}," in phys
