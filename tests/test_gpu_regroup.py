@@ -46,6 +46,39 @@ def test_regrouped_multi_record_warm_layer_state(oracle):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+def test_regrouped_ecmwf_series_day_then_night(oracle):
+    """WL_ECMWF over a series: two sunny records build the layer, two dark ones erode it (the ten-pass branch of cells that lose heat
+    WITH a layer, which the forecast bins separately from the second record on; cells without a layer take the exact shortcut).
+    Regrouped == natural order bit for bit, and both follow the oracle."""
+    import aerobulk_amd as ab
+    ni, nj = 640, 29
+    f = oracle.synth_fields(ni, nj)
+    f["u_zu"] = f["u_zu"] * 0.15
+    f["v_zu"] = f["v_zu"] * 0.15
+    n = ni * nj
+    sw = [f["rad_sw"] * 1.0 + 200.0, f["rad_sw"] * 1.0 + 200.0, f["rad_sw"] * 0.0, f["rad_sw"] * 0.0]
+
+    def run(on):
+        outs = []
+        with ab.Session("ecmwf", n, 1, 4, True) as s:
+            s.set_regroup(on)
+            for jt in range(1, 5):
+                outs.append(s.compute(jt, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, rad_sw=sw[jt - 1], rad_lw=f["rad_lw"]))
+        return outs
+
+    ref, got = run(False), run(True)
+    assert (ref[1]["T_s"] - f["sst"]).max() > 0.3                       # a layer was built ...
+    assert ((ref[1]["T_s"] - ref[3]["T_s"]) > 0.05).mean() > 0.2       # ... and eroded at night
+    for a, b in zip(got, ref):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    o = oracle.OracleSession("ecmwf", n, 4, True)
+    for jt in range(1, 5):
+        want = o.compute(jt, 2.0, 10.0, 5, *[f[k] for k in IN6], rad_sw=sw[jt - 1], rad_lw=f["rad_lw"])
+        for k, ko in (("QL", "ql"), ("QH", "qh"), ("T_s", "t_s")):
+            np.testing.assert_allclose(got[jt - 1][k], want[ko], rtol=1e-9, atol=1e-9, err_msg=f"jt={jt} {k}")
+
+
 def test_regrouped_tiny_and_large_grids(oracle):
     for ni, nj in ((7, 1), (300, 1), (4320, 400)):      # fewer cells than one wave / one tile / 1.7 M cells
         f = oracle.synth_fields(ni, nj)
