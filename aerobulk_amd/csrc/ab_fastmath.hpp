@@ -9,7 +9,7 @@
 // below is: hardware seed (v_rcp_f64 / v_rsq_f64 / v_log_f32+v_exp_f32) or frexp range reduction,
 // one Newton/Halley step, a near-minimax polynomial (tools/gen_poly.py, 60-digit Chebyshev fits;
 // truncation errors quoted per table) evaluated with FMAs.  log and exp, the two most frequent, are
-// table-driven (tools/gen_logtab.py, tools/gen_exptab.py): 1 280 B of tables per block in LDS, one
+// table-driven (tools/gen_logtab.py, tools/gen_exptab.py): 1 640 B of tables per block in LDS, one
 // ds_read per call, no division in log (an fp64 v_rcp/v_rsq/v_sqrt issues at a quarter of the FMA
 // rate, profiles/r1_instr_rates.txt).  Measured accuracy on the MI355X: tests/test_gpu_math.py (max
 // error in ulp vs 80-bit references).
@@ -86,7 +86,7 @@ constexpr int ab_pad4(int n) { return (n + 3) & ~3; }
 // (profiles/r2_instr_rates.txt).  The LDS pipe is all but idle in these kernels: such constants are kept in a small LDS table
 // and fetched by a broadcast ds_read_b64, which costs the VALU nothing.  The entries repeat coefficients of the tables they
 // belong to (tests/test_math_tables.py checks that they are the same numbers).
-enum ab_const { kC_LogQ4 = 0, kC_ExpQ3, kC_AtanP9, kC_PsikM21, kC_PsikH21, kC_PsicL24, kC_PsicG19, kC_Goff13, kC_Third, kC_Quarter,
+enum ab_const { kC_LogQ4 = 0, kC_ExpQ2, kC_AtanP9, kC_PsikM21, kC_PsikH21, kC_PsicL24, kC_PsicG19, kC_Goff13, kC_Third, kC_Quarter,
                 kC_TwoNinths, kC_5_32, kC_N = 12, kC_None = -1 };
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST) && !defined(AB_NO_CONST_TABLES)
 #define AB_TAB __constant__ __attribute__((aligned(64)))
@@ -184,20 +184,28 @@ template <int N, int CL = kC_None> AB_FM double horner_coefs(const double *g, do
     return p;
 }
 #endif
-AB_TAB double kConstTab[kC_N] = {-0.16667855714108057, 0.008333362425171237, 0.03923165829558719, 6.446912234869585e-09,
+AB_TAB double kConstTab[kC_N] = {-0.16667855714108057, 0.04166670739519204, 0.03923165829558719, 6.446912234869585e-09,
                                   4.251847861014437e-10, -7.386244013567452e-10, 7.426603654517993e-10, 5.6079820609247194e-12,
                                   0.3333333333333333, 0.25, 0.2222222222222222, 0.15625};
-// T[j] = 2^(j/32) of qexp (tools/gen_exptab.py)
-constexpr int kExpN = 32;
+// T[j] = 2^(j/64) of qexp (tools/gen_exptab.py 64)
+constexpr int kExpN = 64;
 AB_TAB double kExpTab[kExpN] = {
-    1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
-    1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775,
-    1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
-    1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
-    1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228,
-    1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
-    1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072,
-    1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002};
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
 AB_TAB double kAtanP[ab_pad4(11)] = {-0.3333333333333333, 0.1999999999999552, -0.14285714284666542, 0.11111111015256361,
                             -0.09090904578123903, 0.07692183190826087, -0.06664511447381948, 0.0585814891280221,
                             -0.0508544973794026, 0.03923165829558719, -0.01917688711906226};
@@ -343,10 +351,10 @@ template <int CL> AB_FM double horner_lit6(double x, double c0, double c1, doubl
     p = p_fma(p, x, c3); p = p_fma(p, x, c2); p = p_fma(p, x, c1);
     return p_fma(p, x, c0);
 }
-template <int CL> AB_FM double horner_lit5(double x, double c0, double c1, double c2, double c3, double c4)
+template <int CL> AB_FM double horner_lit4(double x, double c0, double c1, double c2, double c3)
 {
-    double p = p_fma(c4, x, vconst(CL, c3));
-    p = p_fma(p, x, c2); p = p_fma(p, x, c1);
+    double p = p_fma(c3, x, vconst(CL, c2));
+    p = p_fma(p, x, c1);
     return p_fma(p, x, c0);
 }
 AB_FM double qlog(double x)
@@ -368,36 +376,37 @@ AB_FM double qlog(double x)
 AB_FM double qlog10(double x) { return qlog(x) * 0.4342944819032518; }
 
 // ---------------------------------------------------------------- exp
-// exp(x) with a 32-entry table (tools/gen_exptab.py):  x = (32 e + j) ln2/32 + r, |r| <= ln2/64:
-//    exp x = 2^e T[j] (1 + r + r^2 P(r)),  T[j] = 2^(j/32),  P degree 4 (2.2e-19 relative) instead of degree 9 on |r| <= ln2/2.
-// T lives in LDS next to the log table (256 B per block, lds_tables_init()); 16 VALU slots instead of 19.
+// exp(x) with a 64-entry table (tools/gen_exptab.py 64):  x = (64 e + j) ln2/64 + r, |r| <= ln2/128:
+//    exp x = 2^e T[j] (1 + r + r^2 P(r)),  T[j] = 2^(j/64),  P degree 3 (4.4e-18 relative) instead of degree 9 on |r| <= ln2/2
+//    (degree 4 with the 32 entries of round 1: the byte per cell the tile sort no longer needs pays for the larger table).
+// T lives in LDS next to the log table (512 B per block, lds_tables_init()); 15 VALU slots instead of 19.
 // Any finite x: the exponent goes through a saturating conversion and ldexp (0 / inf beyond +-745).
-#define AB_EXPQ 0.5, 0.16666666666581356, 0.04166666666656003, 0.008333362425171237, 0.0013888925253674421   /* P, degree 4 */
+#define AB_EXPQ 0.49999999999985073, 0.16666666666664534, 0.04166670739519204, 0.008333339151693509   /* P, degree 3 */
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
 AB_FM double exp_t(int j) { return s_exptab[j]; }
 #else
 AB_FM double exp_t(int j) { return kExpTab[j]; }
 #endif
-// 2^e T[j] (1 + r + r^2 P(r)) for k = 32 e + j
+// 2^e T[j] (1 + r + r^2 P(r)) for k = 64 e + j
 AB_FM double exp_finish(double r, int k)
 {
     const double t = exp_t(k & (kExpN - 1));
-    const double q = p_fma(r * r, horner_lit5<kC_ExpQ3>(r, AB_EXPQ), r);
-    return p_ldexp(p_fma(t, q, t), k >> 5);
+    const double q = p_fma(r * r, horner_lit4<kC_ExpQ2>(r, AB_EXPQ), r);
+    return p_ldexp(p_fma(t, q, t), k >> 6);
 }
 AB_FM double qexp(double x)
 {
-    const double k = p_rint(x * 46.16624130844683);     // 32/ln2
-    double r = p_fma(-k, 0.021660849393811077, x);      // ln2/32, 30-bit head: k*head exact
-    r = p_fma(-k, -1.312785960212839e-12, r);           // tail
+    const double k = p_rint(x * 92.33248261689366);     // 64/ln2
+    double r = p_fma(-k, 0.010830424696905538, x);      // ln2/64, 30-bit head: k*head exact
+    r = p_fma(-k, -6.563929801064195e-13, r);           // tail
     return exp_finish(r, (int)k);
 }
 // 10^x
 AB_FM double qexp10(double x)
 {
-    const double k = p_rint(x * 106.30169903639559);    // 32/log10(2)
-    double r = p_fma(-k, 0.009407187360920943, x);      // log10(2)/32, 30-bit head
-    r = p_fma(-k, 3.5784690306318245e-12, r);           // tail
+    const double k = p_rint(x * 212.60339807279118);    // 64/log10(2)
+    double r = p_fma(-k, 0.004703593680460472, x);      // log10(2)/64, 30-bit head
+    r = p_fma(-k, 1.7892345153159123e-12, r);           // tail
     return exp_finish(r * 2.302585092994046, (int)k);
 }
 

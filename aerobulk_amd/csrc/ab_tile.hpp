@@ -43,7 +43,7 @@ template <class R, int ALGO, bool SKIN> struct Tile {
     // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) per cell (budgeted with 3 B: the
     // byte the former sort kept per cell is headroom now)
     static constexpr int kWaves = AB_WAVES_PER_EU * 256 / kBlock;      // resident blocks per CU
-    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0);   // fm::s_logtab (1024 B) + fm::s_exptab (256 B): 1024 here, the rest from the 2048 held back above
+    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0);   // fm::s_logtab (1024 B) + fm::s_exptab (512 B) + fm::s_ctab (104 B): 1024 here, the rest from the 2048 held back above
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;

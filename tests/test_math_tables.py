@@ -1,6 +1,6 @@
 """The LDS tables of the fp64 log / exp (aerobulk_amd/csrc/ab_fastmath.hpp) are what tools/gen_logtab.py / gen_exptab.py define:
 invc[i] within 2048 ulp of 1/centre of bin i for the 64 equal steps of m's high word from 0x3fe6a09e, logc[i] = -log(invc[i]) of that
-very value and within 0.002 ulp of exact, the bin that holds 1.0 has exactly (1, 0); T[j] = 2^(j/32)."""
+very value and within 0.002 ulp of exact, the bin that holds 1.0 has exactly (1, 0); T[j] = 2^(j/64)."""
 import os
 import re
 
@@ -44,11 +44,11 @@ def test_log_table_is_exactly_what_the_identity_needs():
 def test_exp_table_and_reduction_constants():
     mp.mp.dps = 50
     t = _table("kExpTab")
-    assert t.size == 32
-    assert all(t[j] == float(mp.mpf(2) ** (mp.mpf(j) / 32)) for j in range(32))
-    # the 30-bit heads of ln2/32 and log10(2)/32 times any |k| < 2^22 are exact in double; head + tail reproduce the constant
-    for head, tail, val in ((0.021660849393811077, -1.312785960212839e-12, mp.log(2) / 32),
-                            (0.009407187360920943, 3.5784690306318245e-12, mp.log10(2) / 32)):
+    assert t.size == 64
+    assert all(t[j] == float(mp.mpf(2) ** (mp.mpf(j) / 64)) for j in range(64))
+    # the 30-bit heads of ln2/64 and log10(2)/64 times any |k| < 2^22 are exact in double; head + tail reproduce the constant
+    for head, tail, val in ((0.010830424696905538, -6.563929801064195e-13, mp.log(2) / 64),
+                            (0.004703593680460472, 1.7892345153159123e-12, mp.log10(2) / 64)):
         assert f"{head!r}" in HDR and f"{tail!r}" in HDR
         m, _ = np.frexp(head)
         assert (m * 2.0 ** 30) == int(m * 2.0 ** 30)
@@ -75,9 +75,9 @@ def test_lds_constant_table_repeats_the_coefficients_it_stands_for():
         assert m, name
         return [float(x) for x in m.group(1).split(",")]
 
-    assert len(macro("AB_LOGQ")) == 6 and len(macro("AB_EXPQ")) == 5
-    assert "horner_lit6<kC_LogQ4>(r, AB_LOGQ)" in HDR and "horner_lit5<kC_ExpQ3>(r, AB_EXPQ)" in HDR
-    want = {"kC_LogQ4": macro("AB_LOGQ")[4], "kC_ExpQ3": macro("AB_EXPQ")[3], "kC_AtanP9": tab(HDR, "kAtanP")[9],
+    assert len(macro("AB_LOGQ")) == 6 and len(macro("AB_EXPQ")) == 4
+    assert "horner_lit6<kC_LogQ4>(r, AB_LOGQ)" in HDR and "horner_lit4<kC_ExpQ2>(r, AB_EXPQ)" in HDR
+    want = {"kC_LogQ4": macro("AB_LOGQ")[4], "kC_ExpQ2": macro("AB_EXPQ")[2], "kC_AtanP9": tab(HDR, "kAtanP")[9],
             "kC_PsikM21": tab(phys, "kPsikM")[21], "kC_PsikH21": tab(phys, "kPsikH")[21], "kC_PsicL24": tab(phys, "kPsicL")[24],
             "kC_PsicG19": tab(phys, "kPsicG")[19], "kC_Goff13": tab(phys, "kGoffA")[13], "kC_Third": 0.3333333333333333,
             "kC_Quarter": 0.25, "kC_TwoNinths": 0.2222222222222222, "kC_5_32": 0.15625}
