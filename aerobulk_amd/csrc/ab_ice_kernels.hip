@@ -4,6 +4,10 @@
 // (ab_physics_ice.hpp).  Algorithmic bytes per cell, fp64: 5 in + 6 out = 88 B (+ 8 B ice concentration for
 // LU12, + 8 B per OPTIONAL output).  NEMO / LU12 are HBM-bound (no iteration), AN05 / LG15 VALU-bound like the open-ocean
 // algorithms.
+// these kernels keep four waves per SIMD on every instantiation (some would spill at five; next-tier rows, not tuned per kernel)
+#define AB_NOSKIN_OCC 4
+#define AB_F32_OCC 4
+#define AB_F32_NOSKIN_OCC 4
 #include "ab_kernels.hpp"
 #include "ab_physics_ice.hpp"
 #include "ab_launch.hpp"
@@ -40,7 +44,7 @@ __device__ __forceinline__ void ice_cell(const IceArgs<R> &a, const Heights<R> &
 // NEMO / LU12 (no iteration, HBM-bound): one lane per cell.  AN05 / LG15 / EASY (nb_iter iterations with stable / unstable branches):
 // the LDS-staged, regrouped tiles of flux_kernel (ab_tile.hpp); the bucket is the sign of the air-ice virtual temperature
 // difference in four bins.
-template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) ice_kernel(const IceArgs<R> a)
+template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, (Tile<R, ALGO, false>::kOcc)) ice_kernel(const IceArgs<R> a)
 {
     math_tables_init<R>();
     if (ALGO == 1 || ALGO == 3) {
@@ -138,7 +142,7 @@ template <class R, int ALGO> static hipError_t launch_t(const IceCall &c, hipStr
     a.nb_iter = c.nb_iter;
     for (int i = 0; i < 3; ++i) a.cxn[i] = (R)c.cxn[i];
     a.regroup = 1;
-    a.rounds = tile_rounds(c.n, Tile<R, ALGO, false>::kRounds);
+    a.rounds = tile_rounds(c.n, Tile<R, ALGO, false>::kRounds, Tile<R, ALGO, false>::kOcc);
     const long tile = (ALGO == 1 || ALGO == 3) ? kBlock : (long)a.rounds * kBlock;
     const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;

@@ -120,7 +120,8 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
 }
 
 template <class R, int ALGO, bool SKIN, bool DIAG, class S = R>
-__global__ void __launch_bounds__(kBlock, AB_WAVES_PER_EU) flux_kernel(const FluxArgs<R, S> a, const DiagArgs<S> dg)
+// (the DIAG instantiations carry sixteen more live values: four waves per SIMD, on the tiles sized for Tile::kOcc)
+__global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO, SKIN>::kOcc)) flux_kernel(const FluxArgs<R, S> a, const DiagArgs<S> dg)
 {
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -273,7 +274,7 @@ template <class R, int ALGO, bool SKIN, class S = R> static hipError_t launch_t(
     a.isecday = c.isecday;
     a.dawn_uniform = dawn_at_lon0(c.isecday);
     a.regroup = c.regroup ? 1 : 0;
-    const long rounds = tile_rounds(c.n, Tile<R, ALGO, SKIN>::kRounds);
+    const long rounds = tile_rounds(c.n, Tile<R, ALGO, SKIN>::kRounds, Tile<R, ALGO, SKIN>::kOcc);
     a.rounds = (int)rounds;
     const long tile = (ALGO == 3) ? kBlock : rounds * kBlock;
     const long nblk = (c.n + tile - 1) / tile;

@@ -5,9 +5,9 @@
 
 namespace ab {
 
-// Resident blocks per CU = waves per SIMD.  Every flux kernel fits 128 VGPRs without scratch, so four blocks of 256 lanes
-// share a CU (and its 160 KB of LDS): measured 1.5-4 % faster than three blocks with larger tiles and the height constants
-// parked in VGPRs (profiles/r1_notes.md).
+// Resident blocks per CU = waves per SIMD, at least.  Every flux kernel fits 128 VGPRs without scratch, so four blocks of 256
+// lanes share a CU (and its 160 KB of LDS): measured 1.5-4 % faster than three blocks with larger tiles and the height constants
+// parked in VGPRs (profiles/r1_notes.md).  Kernels that need fewer registers take more (Tile::kOcc).
 #ifndef AB_WAVES_PER_EU
 #define AB_WAVES_PER_EU 4
 #endif
@@ -42,7 +42,21 @@ template <class R, int ALGO, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // flux: sst theta q_zt u v slp [qsw rlw] ; turb: 8 / 6 too
     // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) per cell (budgeted with 3 B: the
     // byte the former sort kept per cell is headroom now)
-    static constexpr int kWaves = AB_WAVES_PER_EU * 256 / kBlock;      // resident blocks per CU
+    // Waves per SIMD (= resident blocks per CU) a kernel is built for.  The fp64 kernels with the skin schemes need 107-127 VGPRs:
+    // four.  Without them 72-95 VGPRs: five, on two-round tiles (-3...-4 % COARE, -1 % ECMWF; config 2 -3 %).  The fp32 kernels:
+    // five with the skin schemes (-3 %), six without (-3...-8 %).  Same-box A/Bs in profiles/r2_notes.md.
+#ifndef AB_NOSKIN_OCC
+#define AB_NOSKIN_OCC 5
+#endif
+#ifndef AB_F32_OCC
+#define AB_F32_OCC 5
+#endif
+#ifndef AB_F32_NOSKIN_OCC
+#define AB_F32_NOSKIN_OCC 6
+#endif
+    // waves per SIMD the kernel is built for
+    static constexpr int kOcc = sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : AB_NOSKIN_OCC) : (SKIN ? AB_F32_OCC : AB_F32_NOSKIN_OCC);
+    static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
     static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0);   // fm::s_logtab (1024 B) + fm::s_exptab (512 B) + fm::s_ctab (104 B): 1024 here, the rest from the 2048 held back above
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
@@ -150,8 +164,9 @@ __device__ __forceinline__ void tile_sort_place(const unsigned *s_cnt, unsigned 
 }
 
 // blocks the chip holds at once: AB_WAVES_PER_EU per CU (one wave of each block per SIMD)
-static inline long resident_block_slots()
+static inline long resident_block_slots(int occ = AB_WAVES_PER_EU)
 {
+    if (occ != AB_WAVES_PER_EU) return resident_block_slots() / AB_WAVES_PER_EU * occ;
     static long slots = 0;
     if (!slots) {
         int dev = 0, cus = 0;
@@ -164,9 +179,9 @@ static inline long resident_block_slots()
 
 // full tiles when the grid fills the chip several times over; smaller ones on small grids so that every CU gets work
 // (a 360x180 grid is 127 two-round tiles for 256 CUs, but 254 one-round tiles)
-static inline int tile_rounds(long n, int max_rounds)
+static inline int tile_rounds(long n, int max_rounds, int occ = AB_WAVES_PER_EU)
 {
-    long rounds = n / ((long)kBlock * resident_block_slots());
+    long rounds = n / ((long)kBlock * resident_block_slots(occ));
 #ifdef AB_FORCE_ROUNDS
     rounds = AB_FORCE_ROUNDS;
 #endif

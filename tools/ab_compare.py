@@ -20,15 +20,17 @@ import aerobulk_amd as ab
 ni, nj = (int(x) for x in sys.argv[2].split("x"))
 cfgs = [c.split(":") for c in sys.argv[3].split(",")]
 IN6 = ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp")
-f = ab.synth_fields_device(ni, nj)
+prec = sys.argv[4]
+f = ab.synth_fields_device(ni, nj, precision=prec)
+f64 = f if prec == "f64" else ab.synth_fields_device(ni, nj)
 with ab.Session("coare3p6", ni, nj, 1, False) as s:      # clock ramp
     for _ in range(80):
-        s.compute(1, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, check=False)
+        s.compute(1, 2.0, 10.0, *[f64[k] for k in IN6], Niter=5, check=False)
     s.last_kernel_ms()
 out = {}
 for algo, skin, niter in cfgs:
     skin, niter = skin == "1", int(niter)
-    with ab.Session(algo, ni, nj, 1, skin) as s:
+    with ab.Session(algo, ni, nj, 1, skin, precision=prec) as s:
         ms = []
         for _ in range(12):
             s.compute(1, 2.0, 10.0, *[f[k] for k in IN6], Niter=niter, rad_sw=f["rad_sw"] if skin else None,
@@ -45,6 +47,7 @@ def main():
     ap.add_argument("tags", nargs="+")
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--grid", default="4320x3600")
+    ap.add_argument("--precision", default="f64")
     ap.add_argument("--configs", default="coare3p6:1:5,coare3p6:0:8,ecmwf:1:5,coare3p0:1:5,andreas:0:5,ncar:0:5")
     a = ap.parse_args()
     res = {t: {} for t in a.tags}
@@ -55,7 +58,7 @@ def main():
                 env["AEROBULK_AMD_LIB"] = os.path.join(ROOT, "build", "var", f"libab_{t}.so")
             else:
                 env.pop("AEROBULK_AMD_LIB", None)
-            o = subprocess.run([sys.executable, "-c", CHILD, ROOT, a.grid, a.configs], env=env, capture_output=True, text=True)
+            o = subprocess.run([sys.executable, "-c", CHILD, ROOT, a.grid, a.configs, a.precision], env=env, capture_output=True, text=True)
             line = [l for l in o.stdout.splitlines() if l.startswith("RESULT ")]
             if not line:
                 print(t, "FAILED", o.stderr[-500:])
