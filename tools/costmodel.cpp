@@ -107,15 +107,16 @@ inline CD operator/(Prod a, CD b) { return CD(a.v / b.v); }
 inline CD operator/(CD a, Prod b) { return CD(a.v / b.v); }
 inline CD operator/(Prod a, Prod b) { return CD(a.v / b.v); }
 
-// issue cost, in fp64 slots, of the elementary functions of ab_fastmath.hpp (counted from their source; a quarter-rate
+// issue cost, in fp64 slots, of the elementary functions of ab_fastmath.hpp (counted from their source at the rates of
+// profiles/r2_instr_rates.txt: conversions, shifts left and v_ldexp_f64 a full slot, 32-bit add / and / shift right half; a quarter-rate
 // v_rcp/rsq_f64 = 4, ds_read = 0, 32-bit integer/convert = 0.5 .. 1)
 template <> struct Mth<CD> {
     using R = CD;
     static R f1(const char *n, double cost, double (*f)(double), R x) { g_acct.fn(n, cost); return R(f(x.v)); }
-    static R log(R x) { return f1("log", 18., fm::qlog, x); }
-    static R log10(R x) { return f1("log10", 19., fm::qlog10, x); }
-    static R exp(R x) { return f1("exp", 16., fm::qexp, x); }
-    static R exp10(R x) { return f1("exp10", 17., fm::qexp10, x); }
+    static R log(R x) { return f1("log", 16.5, fm::qlog, x); }
+    static R log10(R x) { return f1("log10", 17.5, fm::qlog10, x); }
+    static R exp(R x) { return f1("exp", 14.5, fm::qexp, x); }
+    static R exp10(R x) { return f1("exp10", 15.5, fm::qexp10, x); }
     static R atan(R x) { return f1("atan", 34., fm::qatan, x); }
     static R atan_ge1(R x) { return f1("atan_ge1", 30., fm::qatan_ge1, x); }
     static R rsqrt_pos(R x) { return f1("rsqrt", 12., fm::qrsqrt_pos, x); }
@@ -147,8 +148,8 @@ inline bool nonneg(Prod x) { return nonneg<CD>(CD(x)); }
 inline CD pow_pos(Prod x, CD y) { return pow_pos<CD>(CD(x), y); }
 // polynomial tables: N-1 FMAs
 CD goff_poly(CD x);
-template <int N> CD horner_tab(const double *tab, CD x);
-template <int N> CD horner_tab(const double *tab, Prod x) { return horner_tab<N>(tab, CD(x)); }
+template <int N, int CL = -1> CD horner_tab(const double *tab, CD x);
+template <int N, int CL = -1> CD horner_tab(const double *tab, Prod x) { return horner_tab<N, CL>(tab, CD(x)); }
 inline CD goff_poly(Prod x) { return goff_poly(CD(x)); }
 
 }  // namespace ab
@@ -157,8 +158,9 @@ inline CD goff_poly(Prod x) { return goff_poly(CD(x)); }
 #include "../aerobulk_amd/csrc/ab_launch.hpp"
 
 namespace ab {
-CD goff_poly(CD x) { g_acct.fn("poly_goff", 14.); return CD(fm::horner_coefs<15>(kGoffA, x.v)); }
-template <int N> CD horner_tab(const double *tab, CD x) { g_acct.fn("poly_psic", N - 1.); return CD(fm::horner_coefs<N>(tab, x.v)); }
+CD goff_poly(CD x) { g_acct.fn("poly_goff", 14.5); return CD(fm::horner_coefs<15>(kGoffA, x.v)); }
+// with an entry of the LDS constant table for the second constant of the first step: N - 1 FMAs and half a slot for the read's address
+template <int N, int CL> CD horner_tab(const double *tab, CD x) { g_acct.fn("poly_psi", N - 1. + (CL >= 0 ? 0.5 : 1.)); return CD(fm::horner_coefs<N>(tab, x.v)); }
 }  // namespace ab
 
 using namespace ab;
@@ -217,7 +219,7 @@ int main(int argc, char **argv)
             sum_ql += ql.v;
         }
     Acct &a = g_acct;
-    printf("%s skin=%d nb_iter=%d, %ld cells: %.0f slots per cell (sum QL %.6e)\n", algo, (int)skin, nb_iter, n, a.total / n, sum_ql);
+    printf("%s skin=%d nb_iter=%d, %ld cells: %.0f slots per cell (sum QL %.12e)\n", algo, (int)skin, nb_iter, n, a.total / n, sum_ql);
     printf("\n%-34s %10s %7s %10s %7s %9s\n", "region", "excl/cell", "%", "incl/cell", "%", "calls/cell");
     std::vector<int> ord(a.names.size());
     for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
