@@ -80,9 +80,14 @@ __device__ __forceinline__ double goff_poly(double x)
 }
 __device__ __forceinline__ float goff_poly(float x)
 {
-    float p = (float)kGoffA[8];   // fp32: the first 9 terms leave < 2e-8 in A
+    // fp32: the first 9 terms leave < 2e-8 in A; the coefficients as float LITERALS (read from the fp64 table each of them cost a
+    // v_cvt_f32_f64, a full issue slot, i.e. more than the polynomial's own FMAs)
+    constexpr float c[9] = {1.2415921763001385f, 0.6554537644583072f, -0.06042150514551698f, 0.0052061867921480934f,
+                            -0.0004389902243182716f, 4.0181440214509234e-05f, -4.299303765658193e-06f, 5.668664093041563e-07f,
+                            -8.717077199072555e-08f};
+    float p = c[8];
 #pragma unroll
-    for (int i = 7; i >= 0; --i) p = __builtin_fmaf(p, x, (float)kGoffA[i]);
+    for (int i = 7; i >= 0; --i) p = __builtin_fmaf(p, x, c[i]);
     return p;
 }
 // Horner evaluation of a constant-memory coefficient table (coefficients fetched with scalar loads)
@@ -460,6 +465,16 @@ template <class R> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
 {
     using M = Mth<R>;
     const R L = M::log(y);
+    if constexpr (sizeof(R) == 4) {
+        // fp32: G(1/c) by its degree-9 fit (3.4e-8 absolute; tools/gen_poly.py section 5), float literals
+        constexpr float g[10] = {-1.1378019f, 1.28571429f, -0.153059546f, -0.00291561207f, 0.0121689119f, -0.00531786575f,
+                                 0.00141114178f, -0.000133763491f, -0.000127543533f, 6.20082379e-05f};
+        const float x = 2.f * M::exp(-.3333f * L) - 1.f;
+        float p = g[9];
+#pragma unroll
+        for (int i = 8; i >= 0; --i) p = __builtin_fmaf(p, x, g[i]);
+        return .9999f * L + p;
+    }
     // (fp64 only: in fp32 the hardware exponential costs two slots and a degree-24 polynomial is a loss)
     if (sizeof(R) == 8 && L <= R(7.4433710715553465)) return horner_tab<25, fm::kC_PsicL24>(kPsicL, L * R(2. / 7.4433710715553465) - R(1.));
     const R w = M::exp(R(-.3333) * L);

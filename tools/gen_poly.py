@@ -113,11 +113,11 @@ for deg in (13, 14, 15):
 #    = 3 ln c + G(w), w = 1/c in (0,1]:  G(w) = 1.5 ln((w^2+w+1)/3) - S (pi/2 - atan(S w/(w+2))) + 1.813799447
 S3 = mp.mpf("1.7320508")
 G = lambda w: mp.mpf("1.5") * mp.log((w * w + w + 1) / 3) - S3 * (mp.pi / 2 - mp.atan(S3 * w / (w + 2))) + mp.mpf("1.813799447")
-for deg in (18, 20, 22, 24):
+for deg in (9, 18, 20, 22, 24):     # 9: the fp32 path (3.4e-8 absolute)
     c = cheb_fit(lambda x: G((x + 1) / 2), mp.mpf(-1), mp.mpf(1), deg)
     err = max_err(lambda x: G((x + 1) / 2), c, mp.mpf(-1), mp.mpf(1), rel=False)
     print("psic G deg", deg, "abs err", err)
-    if deg in (20, 22):
+    if deg in (9, 20, 22):
         show(f"PSIC_G{deg}: G(w), x = 2w-1", c)
 
 # 6) Round 2 — the Kansas/Paulson unstable profile functions as polynomials in s = ln(y), y = |1 - a zeta| >= 1
