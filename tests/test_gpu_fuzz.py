@@ -3,6 +3,8 @@ stable and very unstable cells, winds of 40 m/s, zt = zu and odd heights; HIP (r
 three consecutive records with the warm-layer state carried for the skin configurations.  Metric: oracle/parity.py — every value
 within 1e-10 (floor 1e-6 of the field maximum) or within 4 ulp of backward error (near-calm, strongly stable cells where the
 iteration runs on its clamps: the reference moves as much when one input moves by one ulp, profiles/r2_illcond_study.txt)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,6 +30,9 @@ def _fields(seed, n):
 
 
 SEEDS = list(range(100, 112))
+if os.environ.get("AB_FUZZ_SEEDS"):          # wider campaigns: AB_FUZZ_SEEDS=200:260 python -m pytest tests/test_gpu_fuzz.py -m gpu
+    _a, _b = (int(x) for x in os.environ["AB_FUZZ_SEEDS"].split(":"))
+    SEEDS = list(range(_a, _b))
 
 
 @pytest.mark.parametrize("seed", SEEDS)
