@@ -10,6 +10,7 @@
 // the cells can be dealt to the waves by kind (lane regrouping, below): same arithmetic per cell, less
 // SIMT divergence.
 #include "ab_kernels.hpp"
+#define AB_PSI_LDS_TABLES 1   // the tiled fp64 kernels of this file keep two psi functions as piecewise tables in LDS (ab_physics.hpp)
 #include "ab_physics.hpp"
 #include "ab_launch.hpp"
 #include "ab_tile.hpp"
@@ -171,6 +172,7 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     Raw nxt = fetch(0);
     if (tid == 0) s_next = 0;
     tile_sort_reset(s_cnt, tid);
+    if constexpr (sizeof(R) == 8) psi_tables_fill();      // (before the barrier of math_tables_init)
     math_tables_init<R>();
     if (sizeof(R) != 8) __syncthreads();                  // (fp64: the barrier of math_tables_init) counters zeroed before phase 1
 #pragma unroll 1

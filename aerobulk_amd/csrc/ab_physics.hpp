@@ -438,6 +438,179 @@ __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, const WlEcmwfCell<R> 
     dT_wl = zdTwl_n * ztcorr;
 }
 
+// ---- piecewise tables in LDS (kernels that define AB_PSI_LDS_TABLES before including this header and call psi_tables_fill())
+// psi_m of Kansas / Paulson in s = LOG(y) and COARE's convective psi in L = LOG(y) (the functions of the two sections below) on 32 equal intervals
+// of [0, 6.6875) / [0, 7.4453125), degree 7 on each (tools/gen_psitab.py; 2.1e-16 / 3.4e-16 absolute, the rounding of the
+// coefficients): 4 KB of LDS per block, coefficient-major, so that lanes on different intervals hit different banks.  An
+// evaluation is five operations for the interval and the local variable, a shift for the address and seven FMAs, the eight
+// coefficients arriving over the LDS pipe — where the global polynomials take 22 and 24 FMAs on the VALU, the unit that binds
+// these kernels.  A timing experiment with polynomials of that length bounded the gain at 5 % (COARE + skin) and 9 % (no skin)
+// before this was built (profiles/r2_notes.md).
+// psi_m (Kansas / Paulson) in s = LOG(y): max |table - function| = 2.14e-16
+AB_TAB double kPsiTabM[256] = {
+    0.02663778402106073, 0.08305199855091043, 0.14375312959675965, 0.20884670895689178,
+    0.27841790088177193, 0.35253077640424074, 0.431228032066807, 0.5145311410802141,
+    0.6024409072594966, 0.6949383774831795, 0.7919860576462795, 0.8935293704457201,
+    0.9994982907683915, 1.109809095540299, 1.2243661690015426, 1.3430638107310473,
+    1.465788001562772, 1.5924180910674675, 1.7228283788822931, 1.8568895703522126,
+    1.9944700943446678, 2.135437277492742, 2.2796583744108383, 2.42700145760461,
+    2.5773361739262186, 2.730534376614903, 2.886470643343973, 3.0450226914098955,
+    3.206071701385212, 3.369502560341748, 3.5352040352457172, 3.7030688864261356,
+    0.027155403479856115, 0.02926921894694357, 0.031440716135344215, 0.033659966301942734,
+    0.03591656720496811, 0.03819986506712594, 0.040499175360076765, 0.04280399296774216,
+    0.04510418357758432, 0.047390149911940294, 0.04965296843856426, 0.05188449428197962,
+    0.05407743401090371, 0.05622538766059889, 0.05832286267299822, 0.060365263364081205,
+    0.0623488600643626, 0.064270742265504, 0.06612876000633006, 0.06792145741686326,
+    0.06964800188119191, 0.07130811174384329, 0.0729019849235192, 0.07443023025346614,
+    0.0758938028677154, 0.07729394451405959, 0.07863212930588703, 0.07991001512687984,
+    0.08112940067127294, 0.08229218793103471, 0.08340034982158602, 0.08445590256068021,
+    0.0005204566372811247, 0.0005360651904701405, 0.0005492688123581237, 0.0005599219132716804,
+    0.000567933705231689, 0.0005732691565861454, 0.0005759474754264933, 0.0005760383701520509,
+    0.000573656477229656, 0.0005689544388085545, 0.0005621151522565781, 0.0005533437030253092,
+    0.0005428594403436595, 0.0005308885743069536, 0.0005176575762480438, 0.0005033875641622144,
+    0.000488289761369601, 0.00047256203645322135, 0.000456386469608833, 0.00043992784595700676,
+    0.00042333294908384033, 0.0004067305157153154, 0.0003902317119159542, 0.0003739309993025444,
+    0.0003579072734681921, 0.0003422251735592319, 0.0003269364797227339, 0.00031208153248237847,
+    0.00029769062403955227, 0.000283785325481023, 0.00027037972566832557, 0.0002574815671780474,
+    2.791567460114328e-06, 2.405797727893118e-06, 1.9913556502002186e-06, 1.5571534764374587e-06,
+    1.1124750559446903e-06, 6.665528323960359e-07, 2.2817213237744266e-07, -1.946701048491997e-07,
+    -5.950324081616795e-07, -9.672106568055118e-07, -1.3068325458877559e-06, -1.6108701547126142e-06,
+    -1.8775820547883733e-06, -2.10640012365236e-06, -2.297777779272976e-06, -2.4530160132774994e-06,
+    -2.574081848546395e-06, -2.6634312064009626e-06, -2.7238451375233366e-06, -2.758285354639302e-06,
+    -2.7697722915695336e-06, -2.761286671455216e-06, -2.7356938636469326e-06, -2.6956891339604703e-06,
+    -2.6437611868467225e-06, -2.582171074472776e-06, -2.5129435131269087e-06, -2.437867813105812e-06,
+    -2.3585059180090527e-06, -2.2762054023195756e-06, -2.1921156471653907e-06, -2.1072057722814713e-06,
+    -4.6080039484659066e-08, -5.019237245056883e-08, -5.3231588582316686e-08, -5.5124645429783004e-08,
+    -5.585177988279081e-08, -5.544502745793885e-08, -5.39829818348639e-08, -5.158258184765321e-08,
+    -4.8388961971928354e-08, -4.4564487699828224e-08, -4.027802880919681e-08, -3.569533584195664e-08,
+    -3.097112619503157e-08, -2.6243206091574613e-08, -2.1628695726008542e-08, -1.7222216175535134e-08,
+    -1.3095752515183008e-08, -9.299829095681163e-09, -5.865611760602451e-09, -2.807574191745459e-09,
+    -1.264163195342812e-10, 2.1880122504681355e-09, 4.15396284023042e-09, 5.7953282806888014e-09,
+    7.139535892506438e-09, 8.215813310210981e-09, 9.053817213307871e-09, 9.682595060346705e-09,
+    1.0129838555811923e-08, 1.042138281811812e-08, 1.0580905165990018e-08, 1.0629780469324681e-08,
+    -4.6116197990466797e-10, -3.5923248412525874e-10, -2.473889005617978e-10, -1.3089564350364883e-10,
+    -1.5074077855214937e-11, 9.510076069983048e-11, 1.953422365248781e-10, 2.8230036872811545e-10,
+    3.5369947275050597e-10, 4.083647409799105e-10, 4.4615129434105503e-10, 4.677988895123732e-10,
+    4.747400299460149e-10, 4.688890437594478e-10, 4.5243587269463354e-10, 4.2766233342350946e-10,
+    3.9679190852153295e-10, 3.6187785228537775e-10, 3.2472929748966867e-10, 2.8687145342204346e-10,
+    2.4953389239595064e-10, 2.1366011353870602e-10, 1.7993172564441746e-10, 1.4880136480313735e-10,
+    1.2052955712968757e-10, 9.522192048037894e-11, 7.286421445411441e-11, 5.335370493443619e-11,
+    3.6526069937890396e-11, 2.217763586183757e-11, 1.0083117559478611e-11, 9.272864524726536e-15,
+    7.939735957711018e-12, 8.97435251117241e-12, 9.584705124228157e-12, 9.748446336430188e-12,
+    9.478168847270938e-12, 8.81804316844119e-12, 7.837167066827024e-12, 6.620827883806037e-12,
+    5.261060224734529e-12, 3.8477958207381246e-12, 2.4616082883626903e-12, 1.1686472770314147e-12,
+    1.7933820519246104e-14, -9.591680275354929e-13, -1.7477316912975448e-12, -2.346846882813599e-12,
+    -2.7665499811447065e-12, -3.0245866929331907e-12, -3.143371169951502e-12, -3.1473768755344e-12,
+    -3.0610762729860846e-12, -2.9074520917168647e-12, -2.7070372305385923e-12, -2.4774019060540834e-12,
+    -2.2329905730889297e-12, -1.9852112331052295e-12, -1.74268998065767e-12, -1.511619006186786e-12,
+    -1.2961430919317752e-12, -1.0987455169049997e-12, -9.20607914016808e-13, -7.619294798376398e-13,
+    8.790740052648657e-14, 5.92312546172485e-14, 2.770148109055384e-14, -4.1594003634147245e-15,
+    -3.393022420999197e-14, -5.955979725891522e-14, -7.956274721434736e-14, -9.311972595915114e-14,
+    -1.0007893802249785e-13, -1.0087355117038882e-13, -9.638131056507251e-14, -8.775716493626773e-14,
+    -7.626752776676346e-14, -6.314796162348758e-14, -4.949714710390291e-14, -3.621128748615457e-14,
+    -2.3956184148730288e-14, -1.3169808613776823e-14, -4.086270451868386e-15, 3.227861564120148e-15,
+    8.832578736627006e-15, 1.2874520583213646e-14, 1.5551807782338705e-14, 1.7085496320376062e-14,
+    1.7698147568903484e-14, 1.759907783755744e-14, 1.6975320415084094e-14, 1.598711436776133e-14,
+    1.47667306758105e-14, 1.3419571582938847e-14, 1.2026666236119405e-14, 1.0647888149236058e-14};
+// COARE convective psi in L = LOG(y): max |table - function| = 3.44e-16
+AB_TAB double kPsiTabC[256] = {
+    0.039528726102123664, 0.12316644210081357, 0.21300563223062205, 0.3091250329737914,
+    0.4115635408596482, 0.5203204939370544, 0.6353569384722432, 0.7565977758746876,
+    0.8839346468990753, 1.0172293857270698, 1.156317866107955, 1.3010140642918857,
+    1.4511141768160811, 1.6064006524122763, 1.7666460232994539, 1.9316164490127157,
+    2.101074913274074, 2.27478403942807, 2.4525085114831033, 2.6340171052428123,
+    2.819084347282074, 3.0074918288673844, 3.199029207810646, 3.39349493425986,
+    3.590696737179579, 3.7904519073374194, 3.9925874105041834, 4.1969398617244575,
+    4.403355388265203, 4.6116894054624735, 4.821806326348987, 5.033579222784928,
+    0.04028653377145358, 0.04336101537216257, 0.04648474246108026, 0.04963789724601906,
+    0.05280054479413356, 0.05595314407481726, 0.059077018007357415, 0.06215476045965342,
+    0.06517056448455533, 0.06811046310374651, 0.07096248081462032, 0.0737167000112357,
+    0.07636525120990165, 0.07890223913562938, 0.08132361836522173, 0.08362703251497582,
+    0.08581163018926197, 0.08787786939459556, 0.08982732018555885, 0.09166247321256404,
+    0.09338655979343337, 0.09500338727203214, 0.09651719183909369, 0.09793250970588427,
+    0.09925406653794545, 0.10048668434809756, 0.1016352045766319, 0.1027044258086566,
+    0.10369905445090902, 0.10462366667391182, 0.10548267998665907, 0.10628033292278938,
+    0.0007608468681014699, 0.0007755928122068397, 0.0007854427848554367, 0.0007903018398525144,
+    0.0007902057527789811, 0.0007853139706165006, 0.0007758963673429966, 0.0007623152317432929,
+    0.0007450041946294949, 0.0007244458643860479, 0.0007011498055287725, 0.0006756322138873693,
+    0.0006483982755753088, 0.0006199278059811806, 0.0005906644000512547, 0.0005610080207780269,
+    0.0005313107268387183, 0.0005018750958137472, 0.00047295482868281, 0.0004447570103322506,
+    0.0004174455331766447, 0.00039114525076358836, 0.0003659465017623523, 0.00034190972153318687,
+    0.0003190699312598247, 0.0002974409589963768, 0.0002770193008140762, 0.00025778757307638115,
+    0.00023971753935208296, 0.00022277271884216628, 0.00020691059896326268, 0.00019208448444667388,
+    2.8548946820050563e-06, 2.054132719865524e-06, 1.2265539957385203e-06, 3.9414473691364535e-07,
+    -4.2170730852350597e-07, -1.2013395200598967e-06, -1.9277387431026174e-06, -2.587198374501398e-06,
+    -3.169679828253545e-06, -3.6688854986798984e-06, -4.082079443179022e-06, -4.409711510456431e-06,
+    -4.654909617917847e-06, -4.822904368262601e-06, -4.92044250520512e-06, -4.9552336729334606e-06,
+    -4.9354612644757866e-06, -4.86937497095364e-06, -4.764971397527784e-06, -4.629760499570267e-06,
+    -4.470609743411454e-06, -4.293654546122628e-06, -4.10426222116937e-06, -3.90703680538087e-06,
+    -3.705853250605255e-06, -3.5039110974890742e-06, -3.303799580265032e-06, -3.1075679138585882e-06,
+    -2.9167961493584784e-06, -2.732663380343554e-06, -2.5560112184798408e-06, -2.38740134120368e-06,
+    -9.75151108792765e-08, -1.0222794944948286e-07, -1.0420606710748598e-07, -1.034482799380546e-07,
+    -1.0010313738772114e-07, -9.444908980634954e-08, -8.68644069275184e-08, -7.779122217036304e-08,
+    -6.769833398771182e-08, -5.704689204872179e-08, -4.626204910465644e-08, -3.571235514556962e-08,
+    -2.569738474516057e-08, -1.644302817575688e-08, -8.10315355482771e-09, -7.659810888116756e-10,
+    5.536546353050911e-09, 1.0817944322636633e-08, 1.5126168671021555e-08, 1.8533299864101644e-08,
+    2.112649626967275e-08, 2.3000497597328128e-08, 2.4251740796102214e-08, 2.49739998330186e-08,
+    2.5255370012323686e-08, 2.5176374500546417e-08, 2.480896221441525e-08, 2.4216180154378188e-08,
+    2.3452329846015065e-08, 2.256344954239122e-08, 2.158799633815713e-08, 2.055763236526032e-08,
+    -6.040613045178274e-10, -3.35871533217387e-10, -5.974310241475503e-11, 2.0879092836771924e-10,
+    4.555456564572579e-10, 6.688984542781468e-10, 8.406063836318656e-10, 9.661594697486078e-10,
+    1.0446847880978866e-09, 1.0784833555627998e-09, 1.0723223129139952e-09, 1.0326160627089401e-09,
+    9.66616349859586e-10, 8.817015097146355e-10, 7.848190297643675e-10, 6.821013678685458e-10,
+    5.786479114142694e-10, 4.784482294367e-10, 3.844130859099757e-10, 2.984782675001519e-10,
+    2.2174976781286443e-10, 1.5466498467249587e-10, 9.715151397856938e-11, 4.8771640679024235e-11,
+    8.846061941308145e-12, -2.3445516383473284e-11, -4.8986455248312317e-11, -6.866576282543766e-11,
+    -8.333815128613264e-11, -9.379828135688046e-11, -1.0076603263387329e-10, -1.048799828732382e-10,
+    2.157176539563208e-11, 2.288732885071638e-11, 2.2893166124674294e-11, 2.164268157768004e-11,
+    1.930324536726664e-11, 1.612831899833023e-11, 1.2420468255485012e-11, 8.492286147244826e-12,
+    4.631652017303722e-12, 1.0758994191648143e-12, -2.0029714350715293e-12, -4.502236621479342e-12,
+    -6.383486748555225e-12, -7.66162712627659e-12, -8.39085855233819e-12, -8.650239388625704e-12,
+    -8.530705422285317e-12, -8.1246320729071e-12, -7.51833035585983e-12, -6.7873583175034714e-12,
+    -5.994220306671718e-12, -5.187890672895045e-12, -4.4045895253802224e-12, -3.669306910444218e-12,
+    -2.9976768710558607e-12, -2.3979148543863475e-12, -1.8726329904998177e-12, -1.4204294033696405e-12,
+    -1.0372079274271345e-12, -7.172251980744697e-13, -4.53886661440124e-13, -2.403256496645243e-13,
+    1.3977478543200897e-13, 4.7303542113844724e-14, -4.5833185801975875e-14, -1.3082817170851954e-13,
+    -2.0038618856094692e-13, -2.496108808258504e-13, -2.764072092961818e-13, -2.8138503219021783e-13,
+    -2.6735846105473816e-13, -2.38602992919902e-13, -2.0004833030717136e-13, -1.5655680586050874e-13,
+    -1.1238356427692268e-13, -7.085530260238856e-14, -3.425500261970698e-14, -3.868675415904508e-15,
+    1.9862530985053918e-14, 3.713940018932581e-14, 4.859440981129682e-14, 5.510331785005644e-14,
+    5.763397604132945e-14, 5.713692803299282e-14, 5.4475096980428775e-14, 5.038592456865748e-14,
+    4.546792642508214e-14, 4.018390301198579e-14, 3.4874225048470426e-14, 2.977513194223578e-14,
+    2.503847959106338e-14, 2.075065847864333e-14, 1.6949402297893268e-14, 1.3637923116401261e-14};
+
+constexpr double kPsiTabSMax = 6.6875, kPsiTabLMax = 7.4453125;
+#ifdef AB_PSI_LDS_TABLES
+constexpr bool kPsiTabDefault = true;
+#else
+constexpr bool kPsiTabDefault = false;
+#endif
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+static __shared__ double s_psitab[512];
+// all threads of a block of 256, BEFORE the barrier of math_tables_init()
+__device__ __forceinline__ void psi_tables_fill()
+{
+    for (int t = (int)threadIdx.x; t < 256; t += (int)blockDim.x) {
+        const double a = kPsiTabM[t], b = kPsiTabC[t];
+        s_psitab[t] = a;
+        s_psitab[256 + t] = b;
+    }
+}
+template <int WHICH> __device__ __forceinline__ double psi_tab_coef(int k, int i) { return s_psitab[WHICH * 256 + k * 32 + i]; }
+#else
+template <int WHICH> inline double psi_tab_coef(int k, int i) { return (WHICH ? kPsiTabC : kPsiTabM)[k * 32 + i]; }
+#endif
+// x32 = 32 x / range, 0 <= x32 < 32
+template <int WHICH> __device__ __forceinline__ double psi_tab_eval(double x32)
+{
+    const double fi = __builtin_floor(x32);
+    const int i = (int)fi;
+    const double u = __builtin_fma(x32 - fi, 2., -1.);
+    double p = psi_tab_coef<WHICH>(7, i);
+#pragma unroll
+    for (int k = 6; k >= 0; --k) p = __builtin_fma(p, u, psi_tab_coef<WHICH>(k, i));
+    return p;
+}
 // ---------------------------------------------------------------- COARE stability functions (mod_common_coare.f90)
 // Convective ("free convection") profile function of COARE, mod_common_coare.f90:240-243 (psi_m) and :330-333 (psi_h):
 //    c = y**.3333 ,  psi_c = 1.5 LOG((1+c+c*c)/3) - 1.7320508 ATAN((1+2c)/1.7320508) + 1.813799447     (y = |1 - a zeta| >= 1)
@@ -461,10 +634,13 @@ AB_TAB double kPsicL[fm::ab_pad4(25)] = {2.0150925272068325, 2.710495199372137, 
     1.5319367544130388e-05, -8.825168944553084e-06, 8.20341206092634e-07, 1.6890014539724033e-06, -1.0233606614380631e-06,
     4.458163497401242e-08, 2.2237828297719965e-07, -7.86594884389353e-08, -1.6678750033618162e-08, 1.1728431071594043e-08,
     -7.386244013567452e-10};
-template <class R> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
+template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
 {
     using M = Mth<R>;
     const R L = M::log(y);
+    if constexpr (sizeof(R) == 8 && TAB) {
+        if (L < R(kPsiTabLMax)) return R(psi_tab_eval<1>((double)(L * R(32. / kPsiTabLMax))));
+    }
     if constexpr (sizeof(R) == 4) {
         // fp32: G(1/c) by its degree-9 fit (3.4e-8 absolute; tools/gen_poly.py section 5), float literals
         constexpr float g[10] = {-1.1378019f, 1.28571429f, -0.153059546f, -0.00291561207f, 0.0121689119f, -0.00531786575f,
@@ -498,15 +674,15 @@ AB_TAB double kPsikH[fm::ab_pad4(23)] = {2.301130474750617, 2.813982186689832, 0
     -5.548391403673346e-08, 5.3152004586067324e-08, 4.251847861014437e-10, -5.020344151301874e-09};
 // psi_m and/or psi_h of the unstable Kansas / Paulson form at y = |1 - a zeta| >= 1.  psi_m (alone or with psi_h): through
 // s = LOG(y); psi_h alone: its closed form (a square root and a log) is cheaper than a log and a polynomial.
-template <class R> __device__ __forceinline__ void psik(R y, R *pm, R *ph)
+template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ void psik(R y, R *pm, R *ph)
 {
     using M = Mth<R>;
     if (pm && sizeof(R) == 8) {   // fp64 only: fp32 square roots, logs and atan are hardware instructions
         const R sl = M::log(y);
         if (sl <= R(6.68586094706836)) {
-            const R t = sl * R(2. / 6.68586094706836) - R(1.);
-            *pm = horner_tab<23, fm::kC_PsikM21>(kPsikM, t);
-            if (ph) *ph = horner_tab<23, fm::kC_PsikH21>(kPsikH, t);
+            if constexpr (sizeof(R) == 8 && TAB) *pm = R(psi_tab_eval<0>((double)(sl * R(32. / kPsiTabSMax))));   // psi_m: LDS table
+            else *pm = horner_tab<23, fm::kC_PsikM21>(kPsikM, sl * R(2. / 6.68586094706836) - R(1.));
+            if (ph) *ph = horner_tab<23, fm::kC_PsikH21>(kPsikH, sl * R(2. / 6.68586094706836) - R(1.));
             return;
         }
     }
@@ -951,7 +1127,7 @@ template <class R> __device__ __forceinline__ void psi_ncar(R z, R *pm, R *ph)
         if (pm) *pm = R(-5.) * z;
         if (ph) *ph = R(-5.) * z;
     } else {   // x2 = MAX(SQRT(ABS(1 - 16 zeta)), 1) (:350,395): the MAX never binds for zeta < 0
-        psik<R>(M::abs(R(1.) - R(16.) * z), pm, ph);
+        psik<R, false>(M::abs(R(1.) - R(16.) * z), pm, ph);   // (the direct NCAR kernel fills no psi table)
     }
 }
 // turb_ncar :57-240

@@ -57,7 +57,12 @@ template <class R, int ALGO, bool SKIN> struct Tile {
     // waves per SIMD the kernel is built for
     static constexpr int kOcc = sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : AB_NOSKIN_OCC) : (SKIN ? AB_F32_OCC : AB_F32_NOSKIN_OCC);
     static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
-    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0);   // fm::s_logtab (1024 B) + fm::s_exptab (512 B) + fm::s_ctab (104 B): 1024 here, the rest from the 2048 held back above
+#ifdef AB_PSI_LDS_TABLES
+    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? 4096 : 0;   // s_psitab (ab_physics.hpp)
+#else
+    static constexpr int kPsiTabBytes = 0;
+#endif
+    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0) - kPsiTabBytes;   // fm::s_logtab (1024 B) + fm::s_exptab (512 B) + fm::s_ctab (104 B): 1024 here, the rest from the 2048 held back above
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;

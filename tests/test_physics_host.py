@@ -18,10 +18,12 @@ ALGOS = {"coare3p0": 1, "coare3p6": 2, "ncar": 3, "ecmwf": 4, "andreas": 5}
 HUM = {"sh": 0, "dp": 1, "rh": 2}
 
 
-@pytest.fixture(scope="module")
-def exe(tmp_path_factory):
+# two builds: the polynomial psi functions (turb / ice kernels, NCAR) and the piecewise LDS tables of the tiled flux kernels
+@pytest.fixture(scope="module", params=["psi polynomials", "psi tables"])
+def exe(request, tmp_path_factory):
     out = str(tmp_path_factory.mktemp("physics_host") / "physics_host")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=fast", "-march=x86-64-v3", "-o", out,
+    flags = ["-DAB_PSI_LDS_TABLES=1"] if request.param == "psi tables" else []
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=fast", "-march=x86-64-v3", *flags, "-o", out,
                            os.path.join(ROOT, "tests", "physics_host.cpp")])
     return out
 
