@@ -48,7 +48,7 @@ def test_oracle_sensitivity_is_the_references_own(oracle, tag):
     for jt in range(1, m["nt"] + 1):
         o = s.compute(jt, m["zt"], m["zu"], m["niter"], *[f[k] for k in IN8[:6]], rad_sw=f["rad_sw"] if m["skin"] else None,
                       rad_lw=f["rad_lw"] if m["skin"] else None)
-        S = sens(jt, idx)
+        _, S = sens(jt, idx)          # the one-ulp (+ FMA) response, which the fixture holds for the reference
         for i, k in enumerate(OUT6[:nf]):
             # the oracle IS the reference on these cells (to the last bits: 1e-13 of the 1e-6-floored scale)
             err = np.abs(o[k] - ref[jt - 1, i])
