@@ -21,6 +21,9 @@
 #ifndef AB_REGION
 #define AB_REGION(name)
 #endif
+#ifndef AB_COUNT            // tools/costmodel.cpp: issue slots of a piece of plain double arithmetic its instrumented type cannot see
+#define AB_COUNT(name, slots)
+#endif
 
 namespace ab {
 
@@ -603,6 +606,7 @@ template <int WHICH> inline double psi_tab_coef(int k, int i) { return (WHICH ? 
 // x32 = 32 x / range, 0 <= x32 < 32
 template <int WHICH> __device__ __forceinline__ double psi_tab_eval(double x32)
 {
+    AB_COUNT(WHICH ? "tab_psic" : "tab_psik_m", 12.);   // floor, sub, fma, cvt, shift + 7 FMAs; the coefficients arrive over the LDS pipe
     const double fi = __builtin_floor(x32);
     const int i = (int)fi;
     const double u = __builtin_fma(x32 - fi, 2., -1.);
@@ -639,7 +643,7 @@ template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R psic_
     using M = Mth<R>;
     const R L = M::log(y);
     if constexpr (sizeof(R) == 8 && TAB) {
-        if (L < R(kPsiTabLMax)) return R(psi_tab_eval<1>((double)(L * R(32. / kPsiTabLMax))));
+        if (L < R(kPsiTabLMax)) return R(psi_tab_eval<1>((double)R(L * R(32. / kPsiTabLMax))));
     }
     if constexpr (sizeof(R) == 4) {
         // fp32: G(1/c) by its degree-9 fit (3.4e-8 absolute; tools/gen_poly.py section 5), float literals
@@ -680,7 +684,7 @@ template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ void ps
     if (pm && sizeof(R) == 8) {   // fp64 only: fp32 square roots, logs and atan are hardware instructions
         const R sl = M::log(y);
         if (sl <= R(6.68586094706836)) {
-            if constexpr (sizeof(R) == 8 && TAB) *pm = R(psi_tab_eval<0>((double)(sl * R(32. / kPsiTabSMax))));   // psi_m: LDS table
+            if constexpr (sizeof(R) == 8 && TAB) *pm = R(psi_tab_eval<0>((double)R(sl * R(32. / kPsiTabSMax))));   // psi_m: LDS table
             else *pm = horner_tab<23, fm::kC_PsikM21>(kPsikM, sl * R(2. / 6.68586094706836) - R(1.));
             if (ph) *ph = horner_tab<23, fm::kC_PsikH21>(kPsikH, sl * R(2. / 6.68586094706836) - R(1.));
             return;

@@ -58,6 +58,8 @@ struct RegionScope {
     ~RegionScope() { g_acct.stack.pop_back(); }
 };
 #define AB_REGION(name) ::ab::RegionScope ab_region_scope_(name)
+#define AB_COUNT(name, slots) ::ab::g_acct.fn(name, slots)
+#define AB_PSI_LDS_TABLES 1      // the psi functions as the tiled flux kernels evaluate them
 
 // ---- instrumented scalar ------------------------------------------------------------------------------------------------
 struct Prod;
