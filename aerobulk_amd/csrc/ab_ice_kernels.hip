@@ -7,6 +7,7 @@
 // these kernels keep four waves per SIMD on every instantiation (some would spill at five; next-tier rows, not tuned per kernel)
 #define AB_NOSKIN_OCC 4
 #define AB_F32_OCC 4
+#define AB_F32_ECMWF_OCC 4
 #define AB_F32_NOSKIN_OCC 4
 #include "ab_kernels.hpp"
 #include "ab_physics_ice.hpp"

@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     if (tid == 0) s_next = 0;
     tile_sort_reset(s_cnt, tid);
     if constexpr (sizeof(R) == 8) psi_tables_fill();      // (before the barrier of math_tables_init)
+    else psi_tables_fill32();                             // (before the barrier below)
     math_tables_init<R>();
     if (sizeof(R) != 8) __syncthreads();                  // (fp64: the barrier of math_tables_init) counters zeroed before phase 1
 #pragma unroll 1

@@ -615,6 +615,94 @@ template <int WHICH> __device__ __forceinline__ double psi_tab_eval(double x32)
     for (int k = 6; k >= 0; --k) p = __builtin_fma(p, u, psi_tab_coef<WHICH>(k, i));
     return p;
 }
+// fp32: psi_m, psi_h (Kansas / Paulson), convective psi; 32 intervals, degree 3, [function][coefficient][interval]; max |table - function| = 7.0e-09 / 9.7e-09 / 1.3e-08
+AB_TAB float kPsiTab32[384] = {
+    0.0266377889f, 0.0830520019f, 0.143753141f, 0.208846718f, 0.278417915f, 0.352530777f,
+    0.431228042f, 0.514531136f, 0.602440894f, 0.694938362f, 0.791986048f, 0.893529356f,
+    0.999498308f, 1.10980904f, 1.22436619f, 1.34306383f, 1.46578801f, 1.59241807f,
+    1.72282839f, 1.85688961f, 1.99447012f, 2.13543725f, 2.27965832f, 2.42700148f,
+    2.57733607f, 2.73053432f, 2.88647056f, 3.04502273f, 3.20607162f, 3.36950254f,
+    3.53520393f, 3.70306897f, 0.027155403f, 0.0292692184f, 0.0314407162f, 0.0336599648f,
+    0.0359165668f, 0.0381998643f, 0.0404991768f, 0.0428039916f, 0.0451041833f, 0.047390148f,
+    0.0496529676f, 0.0518844947f, 0.0540774353f, 0.0562253892f, 0.0583228618f, 0.0603652634f,
+    0.0623488612f, 0.0642707422f, 0.0661287606f, 0.0679214597f, 0.0696480051f, 0.0713081136f,
+    0.0729019865f, 0.0744302273f, 0.0758938044f, 0.0772939473f, 0.0786321312f, 0.0799100175f,
+    0.0811294019f, 0.0822921842f, 0.0834003463f, 0.0844558999f, 0.00052041054f, 0.000536015024f,
+    0.000549215591f, 0.000559866778f, 0.00056787784f, 0.000573213736f, 0.0005758935f, 0.000575986807f,
+    0.000573608093f, 0.000568909862f, 0.000562074885f, 0.000553307997f, 0.000542828464f, 0.000530862308f,
+    0.000517635955f, 0.000503370364f, 0.000488276652f, 0.000472552725f, 0.0004563806f, 0.000439925032f,
+    0.000423332822f, 0.000406732695f, 0.000390235859f, 0.000373936782f, 0.000357914425f, 0.000342233398f,
+    0.000326945534f, 0.000312091201f, 0.000297700753f, 0.000283795758f, 0.000270390301f, 0.000257492182f,
+    2.79110645e-06f, 2.40543864e-06f, 1.99110832e-06f, 1.55702253e-06f, 1.11245993e-06f, 6.66647907e-07f,
+    2.28367412e-07f, -1.9438788e-07f, -5.94678795e-07f, -9.66802418e-07f, -1.30638648e-06f, -1.61040248e-06f,
+    -1.87710737e-06f, -2.10593134e-06f, -2.29732541e-06f, -2.45258843e-06f, -2.57368515e-06f, -2.66306938e-06f,
+    -2.72352031e-06f, -2.75799857e-06f, -2.76952278e-06f, -2.76107289e-06f, -2.73551382e-06f, -2.69554039e-06f,
+    -2.64364076e-06f, -2.58207592e-06f, -2.51287065e-06f, -2.43781437e-06f, -2.35846937e-06f, -2.2761833e-06f,
+    -2.19210551e-06f, -2.10720577e-06f, 0.0529284403f, 0.16287373f, 0.278242528f, 0.398976237f,
+    0.524988532f, 0.65616715f, 0.79237622f, 0.933458984f, 1.07924044f, 1.22953069f,
+    1.38412833f, 1.54282284f, 1.70539832f, 1.87163615f, 2.04131699f, 2.21422386f,
+    2.39014363f, 2.56886864f, 2.7501986f, 2.93394041f, 3.11991096f, 3.30793571f,
+    3.49784994f, 3.68949938f, 3.88273907f, 4.07743406f, 4.27345848f, 4.47069693f,
+    4.66904116f, 4.86839247f, 5.06865931f, 5.2697587f, 0.0536106117f, 0.0563322119f,
+    0.059031684f, 0.0616948009f, 0.0643081069f, 0.0668591782f, 0.0693368316f, 0.0717312917f,
+    0.0740343034f, 0.0762391835f, 0.0783408359f, 0.0803356841f, 0.0822216198f, 0.0839978829f,
+    0.0856649131f, 0.0872242227f, 0.0886782259f, 0.0900300965f, 0.0912836194f, 0.0924430266f,
+    0.0935129076f, 0.0944980606f, 0.0954034105f, 0.0962339118f, 0.0969944894f, 0.0976899713f,
+    0.0983250439f, 0.0989042148f, 0.0994317904f, 0.0999118686f, 0.100348294f, 0.100744702f,
+    0.000681870733f, 0.000678163779f, 0.000670830079f, 0.00066002633f, 0.000645978784f, 0.000628973241f,
+    0.000609343173f, 0.000587456394f, 0.000563701382f, 0.000538474007f, 0.000512165076f, 0.000485149998f,
+    0.000457779883f, 0.000430374843f, 0.00040321963f, 0.000376560987f, 0.000350606831f, 0.000325526897f,
+    0.000301454653f, 0.000278489752f, 0.000256701489f, 0.000236132168f, 0.00021680085f, 0.000198706926f,
+    0.000181833602f, 0.000166151018f, 0.000151619155f, 0.000138190415f, 0.000125811741f, 0.00011442657f,
+    0.000103976359f, 9.44018975e-05f, -3.10091991e-07f, -9.2353946e-07f, -1.5170865e-06f, -2.07847256e-06f,
+    -2.59686453e-06f, -3.06327524e-06f, -3.47084733e-06f, -3.81499649e-06f, -4.09341146e-06f, -4.30592809e-06f,
+    -4.45430442e-06f, -4.54192104e-06f, -4.57343867e-06f, -4.5544466e-06f, -4.49111849e-06f, -4.38990128e-06f,
+    -4.25724784e-06f, -4.09939685e-06f, -3.92220591e-06f, -3.73103489e-06f, -3.53067253e-06f, -3.32530203e-06f,
+    -3.11849635e-06f, -2.91323863e-06f, -2.71195813e-06f, -2.51657821e-06f, -2.32856996e-06f, -2.14900979e-06f,
+    -1.97863346e-06f, -1.81789073e-06f, -1.66699499e-06f, -1.52596692e-06f, 0.0395287387f, 0.123166457f,
+    0.213005647f, 0.309125036f, 0.411563545f, 0.520320535f, 0.635356963f, 0.756597757f,
+    0.883934677f, 1.01722944f, 1.15631783f, 1.30101407f, 1.45111418f, 1.60640061f,
+    1.76664603f, 1.93161643f, 2.10107493f, 2.27478409f, 2.45250845f, 2.63401699f,
+    2.81908441f, 3.00749183f, 3.19902921f, 3.39349484f, 3.59069681f, 3.790452f,
+    3.99258733f, 4.19693995f, 4.4033556f, 4.61168957f, 4.82180643f, 5.03357935f,
+    0.0402865335f, 0.0433610156f, 0.0464847423f, 0.0496378988f, 0.0528005436f, 0.055953145f,
+    0.059077017f, 0.0621547587f, 0.0651705638f, 0.068110466f, 0.0709624812f, 0.0737167001f,
+    0.0763652474f, 0.0789022371f, 0.0813236162f, 0.0836270303f, 0.0858116299f, 0.0878778696f,
+    0.0898273215f, 0.091662474f, 0.0933865607f, 0.0950033888f, 0.0965171903f, 0.0979325101f,
+    0.0992540643f, 0.100486681f, 0.101635203f, 0.102704428f, 0.103699051f, 0.104623668f,
+    0.105482683f, 0.106280334f, 0.00076074939f, 0.000775490596f, 0.000785338576f, 0.000790198392f,
+    0.000790105667f, 0.000785219541f, 0.000775809516f, 0.000762237469f, 0.000744936522f, 0.00072438881f,
+    0.000701103534f, 0.000675596471f, 0.000648372574f, 0.000619911356f, 0.000590656302f, 0.00056100724f,
+    0.000531316269f, 0.000501885894f, 0.000472969958f, 0.000444775535f, 0.000417466654f, 0.000391168258f,
+    0.000365970744f, 0.000341934705f, 0.000319095183f, 0.000297466147f, 0.000277044106f, 0.0002578118f,
+    0.000239740984f, 0.000222795279f, 0.000206932193f, 0.000192105043f, 2.85429064e-06f, 2.05379683e-06f,
+    1.22649419e-06f, 3.94353407e-07f, -4.2125194e-07f, -1.20067079e-06f, -1.92689845e-06f, -2.58623254e-06f,
+    -3.16863543e-06f, -3.66780728e-06f, -4.08100732e-06f, -4.40867916e-06f, -4.65394305e-06f, -4.82202267e-06f,
+    -4.91965784e-06f, -4.95455151e-06f, -4.93488278e-06f, -4.86889667e-06f, -4.76458672e-06f, -4.62946218e-06f,
+    -4.47038792e-06f, -4.29349984e-06f, -4.10416487e-06f, -3.90698779e-06f, -3.70584439e-06f, -3.50393452e-06f,
+    -3.30384864e-06f, -3.10763653e-06f, -2.91687957e-06f, -2.73275714e-06f, -2.55611189e-06f, -2.38750613e-06f};
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+static __shared__ float s_psitab32[384];
+// fp32 kernels: all threads of a block of 256, before the block's first barrier
+__device__ __forceinline__ void psi_tables_fill32()
+{
+    for (int t = (int)threadIdx.x; t < 384; t += (int)blockDim.x) s_psitab32[t] = kPsiTab32[t];
+}
+template <int WHICH> __device__ __forceinline__ float psi_tab_coef32(int k, int i) { return s_psitab32[WHICH * 128 + k * 32 + i]; }
+#else
+template <int WHICH> inline float psi_tab_coef32(int k, int i) { return kPsiTab32[WHICH * 128 + k * 32 + i]; }
+#endif
+// WHICH: 0 psi_m, 1 psi_h (Kansas / Paulson, x32 = 32 s / 6.6875), 2 convective psi (x32 = 32 L / 7.4453125); 0 <= x32 < 32
+template <int WHICH> __device__ __forceinline__ float psi_tab_eval32(float x32)
+{
+    const float fi = __builtin_floorf(x32);
+    const int i = (int)fi;
+    const float u = __builtin_fmaf(x32 - fi, 2.f, -1.f);
+    float p = psi_tab_coef32<WHICH>(3, i);
+#pragma unroll
+    for (int k = 2; k >= 0; --k) p = __builtin_fmaf(p, u, psi_tab_coef32<WHICH>(k, i));
+    return p;
+}
 // ---------------------------------------------------------------- COARE stability functions (mod_common_coare.f90)
 // Convective ("free convection") profile function of COARE, mod_common_coare.f90:240-243 (psi_m) and :330-333 (psi_h):
 //    c = y**.3333 ,  psi_c = 1.5 LOG((1+c+c*c)/3) - 1.7320508 ATAN((1+2c)/1.7320508) + 1.813799447     (y = |1 - a zeta| >= 1)
@@ -644,6 +732,9 @@ template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R psic_
     const R L = M::log(y);
     if constexpr (sizeof(R) == 8 && TAB) {
         if (L < R(kPsiTabLMax)) return R(psi_tab_eval<1>((double)R(L * R(32. / kPsiTabLMax))));
+    }
+    if constexpr (sizeof(R) == 4 && TAB) {
+        if (L < R(kPsiTabLMax)) return R(psi_tab_eval32<2>((float)(L * R(32. / kPsiTabLMax))));
     }
     if constexpr (sizeof(R) == 4) {
         // fp32: G(1/c) by its degree-9 fit (3.4e-8 absolute; tools/gen_poly.py section 5), float literals
@@ -687,6 +778,15 @@ template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ void ps
             if constexpr (sizeof(R) == 8 && TAB) *pm = R(psi_tab_eval<0>((double)R(sl * R(32. / kPsiTabSMax))));   // psi_m: LDS table
             else *pm = horner_tab<23, fm::kC_PsikM21>(kPsikM, sl * R(2. / 6.68586094706836) - R(1.));
             if (ph) *ph = horner_tab<23, fm::kC_PsikH21>(kPsikH, sl * R(2. / 6.68586094706836) - R(1.));
+            return;
+        }
+    }
+    if constexpr (sizeof(R) == 4 && TAB) {   // fp32 kernels with the tables: one log, degree-3 pieces
+        const R sl = M::log(y);
+        if (sl < R(kPsiTabSMax)) {
+            const float x32 = (float)(sl * R(32. / kPsiTabSMax));
+            if (pm) *pm = R(psi_tab_eval32<0>(x32));
+            if (ph) *ph = R(psi_tab_eval32<1>(x32));
             return;
         }
     }

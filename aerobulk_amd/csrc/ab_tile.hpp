@@ -43,22 +43,27 @@ template <class R, int ALGO, bool SKIN> struct Tile {
     // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) per cell (budgeted with 3 B: the
     // byte the former sort kept per cell is headroom now)
     // Waves per SIMD (= resident blocks per CU) a kernel is built for.  The fp64 kernels with the skin schemes need 107-127 VGPRs:
-    // four.  Without them 72-95 VGPRs: five, on two-round tiles (-3...-4 % COARE, -1 % ECMWF; config 2 -3 %).  The fp32 kernels:
-    // five with the skin schemes (-3 %), six without (-3...-8 %).  Same-box A/Bs in profiles/r2_notes.md.
+    // four.  Without them 72-95 VGPRs: five, on two-round tiles (-3...-4 % COARE, -1 % ECMWF; config 2 -3 %).  The fp32 kernels,
+    // at 36-69 VGPRs once their psi functions come from the LDS tables: seven with the skin schemes (ECMWF: six), eight without,
+    // on two-round tiles (-3...-8 % at five / six, another -2...-4 % at six / seven).  Same-box A/Bs in profiles/r2_notes.md.
 #ifndef AB_NOSKIN_OCC
 #define AB_NOSKIN_OCC 5
 #endif
 #ifndef AB_F32_OCC
-#define AB_F32_OCC 5
+#define AB_F32_OCC 7
+#endif
+#ifndef AB_F32_ECMWF_OCC
+#define AB_F32_ECMWF_OCC 6
 #endif
 #ifndef AB_F32_NOSKIN_OCC
-#define AB_F32_NOSKIN_OCC 6
+#define AB_F32_NOSKIN_OCC 8
 #endif
     // waves per SIMD the kernel is built for
-    static constexpr int kOcc = sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : AB_NOSKIN_OCC) : (SKIN ? AB_F32_OCC : AB_F32_NOSKIN_OCC);
+    static constexpr int kOcc = sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : AB_NOSKIN_OCC)
+                                               : (SKIN ? (ALGO == 4 ? AB_F32_ECMWF_OCC : AB_F32_OCC) : AB_F32_NOSKIN_OCC);
     static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
 #ifdef AB_PSI_LDS_TABLES
-    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? 4096 : 0;   // s_psitab (ab_physics.hpp)
+    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? 4096 : 1536;   // s_psitab / s_psitab32 (ab_physics.hpp)
 #else
     static constexpr int kPsiTabBytes = 0;
 #endif

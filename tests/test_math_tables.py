@@ -119,3 +119,30 @@ def test_psi_lds_tables_are_what_the_generator_defines_and_accurate():
                 p = p * u + t[k, i]
             worst = max(worst, abs(p - float(f(g.mp.mpf(float(x))))))
         assert worst < 3e-15, (name, worst)      # values up to 6.6: a few ulp
+
+
+def test_fp32_psi_tables():
+    """kPsiTab32: psi_m, psi_h (Kansas / Paulson) and the convective psi, 32 intervals x degree 3, float entries (tools/gen_psitab.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_psitab", os.path.join(ROOT, "tools", "gen_psitab.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    phys = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_physics.hpp")).read()
+    m = re.search(r"AB_TAB float kPsiTab32\[384\] = \{(.*?)\};", phys, re.S)
+    assert m
+    t = np.array([np.float32(x.strip().rstrip("f")) for x in m.group(1).replace("\n", " ").split(",") if x.strip()]).reshape(3, 4, 32)
+    rng = np.random.default_rng(6)
+    for w, (f, xmax) in enumerate(((g.psik_m, 6.6875), (g.psik_h, 6.6875), (g.psic_L, 7.4453125))):
+        rows, err = g.table(f, g.mp.mpf(xmax), 3)
+        assert err < 2e-8
+        np.testing.assert_array_equal(t[w], np.array(rows, dtype=np.float32).T)
+        worst = 0.0
+        for x in rng.uniform(0, xmax, 200):
+            x32 = np.float32(x) * np.float32(32.0 / xmax)
+            i = int(np.floor(x32))
+            u = np.float32((x32 - np.floor(x32)) * np.float32(2.0) - np.float32(1.0))
+            p = t[w, 3, i]
+            for k in range(2, -1, -1):
+                p = np.float32(p * u + t[w, k, i])
+            worst = max(worst, abs(float(p) - float(f(g.mp.mpf(float(np.float32(x)))))))
+        assert worst < 3e-6, (w, worst)     # fp32: values up to 6.6 (ulp 4.8e-7), the argument itself rounded to float

@@ -11,6 +11,7 @@ on different intervals hit different LDS banks (32 intervals x 8 B = the 64 bank
 Prints the C initialisers and the measured error.
 """
 import mpmath as mp
+import numpy as np
 
 mp.mp.dps = 60
 NINT, DEG = 32, 7
@@ -26,14 +27,18 @@ def psik_m(s):
     return 2 * mp.log((1 + mp.exp(s / 4)) / 2) + mp.log((1 + mp.exp(s / 2)) / 2) - 2 * mp.atan(mp.exp(s / 4)) + RPI / 2
 
 
+def psik_h(s):
+    return 2 * mp.log((1 + mp.exp(s / 2)) / 2)
+
+
 def psic_L(L):
     c = mp.exp(mp.mpf("0.3333") * L)
     return mp.mpf("1.5") * mp.log((1 + c + c * c) / 3) - S3 * mp.atan((1 + 2 * c) / S3) + mp.mpf("1.813799447")
 
 
-def local_fit(f, a, b):
-    """monomial coefficients in u = (2 x - a - b)/(b - a) of the degree-DEG interpolant at the Chebyshev nodes of [a, b]"""
-    n = DEG + 1
+def local_fit(f, a, b, deg=None):
+    """monomial coefficients in u = (2 x - a - b)/(b - a) of the degree-deg interpolant at the Chebyshev nodes of [a, b]"""
+    n = (DEG if deg is None else deg) + 1
     us = [mp.cos(mp.pi * (k + mp.mpf(1) / 2) / n) for k in range(n)]
     A = mp.matrix(n, n)
     y = mp.matrix(n, 1)
@@ -45,11 +50,11 @@ def local_fit(f, a, b):
     return [float(c[j]) for j in range(n)]
 
 
-def table(f, xmax):
+def table(f, xmax, deg=None):
     rows, worst = [], mp.mpf(0)
     for i in range(NINT):
         a, b = xmax * i / NINT, xmax * (i + 1) / NINT
-        c = local_fit(f, a, b)
+        c = local_fit(f, a, b, deg)
         rows.append(c)
         for k in range(41):
             u = mp.mpf(-1) + mp.mpf(2) * k / 40
@@ -74,6 +79,17 @@ def main():
     emit("kPsiTabM", rows, err, "psi_m (Kansas / Paulson) in s = LOG(y)")
     rows, err = table(psic_L, LMAX)
     emit("kPsiTabC", rows, err, "COARE convective psi in L = LOG(y)")
+    # fp32 kernels: degree 3 on the same intervals (5e-9 of interpolation error), float entries: psi_m, psi_h, convective psi
+    flat, errs = [], []
+    for f, xmax in ((psik_m, SMAX), (psik_h, SMAX), (psic_L, LMAX)):
+        rows, err = table(f, xmax, 3)
+        errs.append(err)
+        flat += [rows[i][k] for k in range(4) for i in range(NINT)]
+    print("// fp32: psi_m, psi_h (Kansas / Paulson), convective psi; 32 intervals, degree 3, [function][coefficient][interval]; "
+          "max |table - function| = " + " / ".join(f"{e:.1e}" for e in errs))
+    print("AB_TAB float kPsiTab32[384] = {")
+    for j in range(0, len(flat), 6):
+        print("    " + ", ".join(f"{np.float32(v):.9g}f" for v in flat[j:j + 6]) + ("," if j + 6 < len(flat) else "};"))
 
 
 if __name__ == "__main__":
