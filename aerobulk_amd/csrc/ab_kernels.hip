@@ -64,7 +64,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     in.q_zt = q_zt;
     in.slp = slp;
     in.wnd = M::sqrt(uu * uu + vv * vv);                                       // :111
-    in.ssq = K<R>::rdct_qsat_salt * q_sat(sst, slp);                           // :114
+    in.ssq = K<R>::rdct_qsat_salt * q_sat<R, (TILED && SKIN && kPsiTabDefault)>(sst, slp);   // :114 (e_sat from its LDS table in the tiled kernels with the skin schemes only)
     in.qsw = qsw;
     in.rlw = rlw;
 
@@ -134,10 +134,10 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
         if (!live) return;
         R q_zt;
         if (a.hum_type == 0) q_zt = hum;
-        else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));
-        else q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));
+        else if (a.hum_type == 1) q_zt = q_air_dp<R, false>(hum, vmax(slp, R(50000.)));
+        else q_zt = q_air_rh<R, false>(hum, t_zt, vmax(slp, R(50000.)));
         R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG, false, S>(a, dg, a.h, a.nb_iter, k, sst, theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt), q_zt,
+        compute_cell<R, ALGO, SKIN, DIAG, false, S>(a, dg, a.h, a.nb_iter, k, sst, theta_from_z_p0_t_q<R, false>(a.h.zt, slp, t_zt, q_zt), q_zt,
                                                     uu, vv, slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
         a.ql[k] = (S)QL;
         a.qh[k] = (S)QH;
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     Raw nxt = fetch(0);
     if (tid == 0) s_next = 0;
     tile_sort_reset(s_cnt, tid);
-    if constexpr (sizeof(R) == 8) psi_tables_fill();      // (before the barrier of math_tables_init)
+    if constexpr (sizeof(R) == 8) psi_tables_fill<SKIN>();   // (before the barrier of math_tables_init)
     else psi_tables_fill32();                             // (before the barrier below)
     math_tables_init<R>();
     if (sizeof(R) != 8) __syncthreads();                  // (fp64: the barrier of math_tables_init) counters zeroed before phase 1
@@ -187,9 +187,9 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
             const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
             R q_zt;
             if (a.hum_type == 0) q_zt = hum;                                        // 'sh'
-            else if (a.hum_type == 1) q_zt = q_air_dp(hum, vmax(slp, R(50000.)));   // 'dp' :103
-            else q_zt = q_air_rh(hum, t_zt, vmax(slp, R(50000.)));                  // 'rh' :105
-            const R theta = theta_from_z_p0_t_q(a.h.zt, slp, t_zt, q_zt);           // :118
+            else if (a.hum_type == 1) q_zt = q_air_dp<R, SKIN && kPsiTabDefault>(hum, vmax(slp, R(50000.)));   // 'dp' :103
+            else q_zt = q_air_rh<R, SKIN && kPsiTabDefault>(hum, t_zt, vmax(slp, R(50000.)));                  // 'rh' :105
+            const R theta = theta_from_z_p0_t_q<R, SKIN && kPsiTabDefault>(a.h.zt, slp, t_zt, q_zt);           // :118
             s_f[0][j] = sst; s_f[1][j] = theta; s_f[2][j] = q_zt; s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
             R qsw = R(0.), rlw = R(0.);
             if (SKIN) {
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(kBlock) synth_kernel(R *sst, R *t_zt, R *q_zt,
     sst[k] = (R)s;
     t_zt[k] = (R)t;
     slp[k] = (R)p;
-    q_zt[k] = (R)(dadd(0.55, mul_rn(0.4, r[3])) * q_sat<double>(t, p));   // q_sat: device math, within an ulp or two of libm
+    q_zt[k] = (R)(dadd(0.55, mul_rn(0.4, r[3])) * q_sat<double, false>(t, p));   // q_sat: device math, within an ulp or two of libm
     u[k] = (R)dadd(-14., mul_rn(28., r[4]));
     v[k] = (R)dadd(-14., mul_rn(28., r[5]));
     if (rsw) rsw[k] = (R)mul_rn(900., r[6]);
@@ -452,6 +452,7 @@ hipError_t launch_synth(void *sst, void *t_zt, void *q_zt, void *u, void *v, voi
 // Unit-test hook for the fp64 device math of ab_fastmath.hpp (tests/test_gpu_math.py).
 __global__ void __launch_bounds__(kBlock) math_test_kernel(int op, const double *x, const double *y, double *o, long n)
 {
+    psi_tables_fill();
     math_tables_init<double>();
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
@@ -468,7 +469,8 @@ __global__ void __launch_bounds__(kBlock) math_test_kernel(int op, const double 
     case 7: r = fm::qatan(a); break;
     case 8: r = fm::qcbrt(a); break;
     case 9: r = fm::qrcbrt_mid(a); break;
-    case 10: r = e_sat<double>(a); break;
+    case 10: r = e_sat<double, false>(a); break;
+    case 13: r = e_sat<double, true>(a); break;     // through the piecewise LDS table of the tiled flux kernels
     case 11: r = pow_pos<double>(a, b); break;
     case 12: r = fm::qrqrt_mid(a); break;
     default: r = 0.; break;

@@ -105,11 +105,322 @@ template <int N, int CL = fm::kC_None> __device__ __forceinline__ float horner_t
     for (int i = N - 2; i >= 0; --i) p = __builtin_fmaf(p, x, (float)tab[i]);
     return p;
 }
-template <class R> __device__ __forceinline__ R e_sat(R pTa)
+// ---- piecewise tables in LDS (kernels that define AB_PSI_LDS_TABLES before including this header and call psi_tables_fill())
+// psi_m of Kansas / Paulson in s = LOG(y) and COARE's convective psi in L = LOG(y) (the functions of the two sections below) on 28
+// equal intervals of [0, 6.6875) / [0, 7.4453125), and e_sat(T) of Goff (mod_phymbl.f90:777-800, in Pa) on 24 intervals of
+// [265, 312) K; degree 7 on each interval (tools/gen_psitab.py; 1.7e-16 / 3.0e-16 absolute, 8.8e-17 relative: the rounding of
+// the coefficients): 5 KB of LDS per block, coefficient-major, so that lanes on different intervals hit different banks.  An
+// evaluation is five operations for the interval and the local variable, a shift for the address and seven FMAs, the eight
+// coefficients arriving over the LDS pipe — where the global polynomials take 22 and 24 FMAs, and e_sat 14 FMAs plus a
+// table-driven exponential, on the VALU, the unit that binds these kernels.  A timing experiment with polynomials of that
+// length bounded the gain at 5 % (COARE + skin) and 9 % (no skin) before the psi tables were built (profiles/r2_notes.md).
+// psi_m (Kansas / Paulson) in s = LOG(y): 28 intervals, max |table - function| = 1.74e-16
+AB_TAB double kPsiTabM[224] = {
+    0.03052775705881332, 0.09569459816076224, 0.16649173498048575, 0.24306809907978588,
+    0.3255373854005741, 0.41397700911275687, 0.5084280413731213, 0.6088960675764189,
+    0.7153528659332404, 0.8277387704664977, 0.9459655623341142, 1.0699197265915636,
+    1.199465916528804, 1.3344504820390828, 1.474704939159095, 1.6200492820379016,
+    1.7702950635759997, 1.9252481948058313, 2.0847114343599187, 2.248486557282549,
+    2.416376206674841, 2.5881854422897566, 2.7637230075374064, 2.942802340891784,
+    3.125242359935898, 3.3108680467660823, 3.499510862675603, 3.6910090183626405,
+    0.031204886571636177, 0.03397715791512851, 0.036832406802617554, 0.03975344056493264,
+    0.042722297486414575, 0.04572074154600107, 0.04873074201122734, 0.05173491249611595,
+    0.054716889405301915, 0.05766163622829874, 0.06055566701898868, 0.06338718879595336,
+    0.06614616793518777, 0.06882432955751876, 0.07141510134401277, 0.07391351424823855,
+    0.07631607245161438, 0.07862060392904273, 0.08082610146582168, 0.08293256216971825,
+    0.08494083167500442, 0.08685245749632754, 0.08866955445822267, 0.09039468384977874,
+    0.09203074694468139, 0.0935808927702025, 0.09504843947513002, 0.09643680829950728,
+    0.0006813353371241145, 0.0007041342259125406, 0.0007227718336838751, 0.0007369945639184909,
+    0.000746672048977916, 0.0007517968588122264, 0.0007524773561120927, 0.0007489247980486743,
+    0.0007414362040625, 0.0007303747028428929, 0.0007161490471518711, 0.0006991937831634975,
+    0.0006799512414631592, 0.0006588561442141945, 0.0006363232541051578, 0.0006127381674278633,
+    0.0005884511004364536, 0.000563773343375515, 0.000538975956286597, 0.0005142902431643387,
+    0.0004899095509211493, 0.0004659919813074102, 0.00044266366359377784, 0.000420022302478213,
+    0.0003981407814680827, 0.0003770706618950755, 0.0003568454690670414, 0.00033748369889548795,
+    4.127559437475423e-06, 3.4617589477758207e-06, 2.743712946799944e-06, 1.993576819526483e-06,
+    1.2320654398309443e-06, 4.792510265219546e-07, -2.465020544196497e-07, -9.293781529820021e-07,
+    -1.5566754334010277e-06, -2.119081844731723e-06, -2.6106823187424425e-06, -3.0287424598339737e-06,
+    -3.373328147038388e-06, -3.646824240565006e-06, -3.853410995109635e-06, -3.998546657960362e-06,
+    -4.088491952195642e-06, -4.129899121654917e-06, -4.129476625381295e-06, -4.093731341084459e-06,
+    -4.028783562011731e-06, -3.940245993789422e-06, -3.833155963597368e-06, -3.7119496282786124e-06,
+    -3.58046760324456e-06, -3.4419826939307842e-06, -3.299241957409948e-06, -3.1545169144142243e-06,
+    -7.916829140090213e-08, -8.689671698407174e-08, -9.219227462026078e-08, -9.490764404626353e-08,
+    -9.504977154847372e-08, -9.276946379724926e-08, -8.833812611829906e-08, -8.211570533455604e-08,
+    -7.451461269761672e-08, -6.596423097625129e-08, -5.687973715599592e-08, -4.763769665527144e-08,
+    -3.855952122461422e-08, -2.990268539460097e-08, -2.1858719605941388e-08, -1.4556491958246473e-08,
+    -8.069122884601244e-09, -2.4229675828273926e-09, 2.392646854249734e-09, 6.4159179119852594e-09,
+    9.703956869326108e-09, 1.232544002487095e-08, 1.4354662176143612e-08, 1.5866969250432907e-08,
+    1.6935443517756067e-08, 1.762866003805171e-08, 1.8009314181926494e-08, 1.8133525350457043e-08,
+    -8.857639094562493e-10, -6.54942137011601e-10, -4.017059425725472e-10, -1.4150162827072004e-10,
+    1.1052300799825258e-10, 3.409606519048898e-10, 5.392466674788325e-10, 6.983040569529862e-10,
+    8.147056706982533e-10, 8.884102294150357e-10, 9.22184981039305e-10, 9.208519024157707e-10,
+    8.904889726508847e-10, 8.37691879380982e-10, 7.689653510631449e-10, 6.902767531121146e-10,
+    6.067742316049553e-10, 5.226506654690567e-10, 4.411232476855104e-10, 3.644950667565402e-10,
+    2.942672080713355e-10, 2.312752310301979e-10, 1.758304310835484e-10, 1.2785270305552333e-10,
+    8.698730298180299e-11, 5.2702039570999284e-11, 2.436440193618319e-11, 1.3000101952937403e-12,
+    1.7882670004025236e-11, 2.0367792886558298e-11, 2.1598488652772115e-11, 2.153394244682336e-11,
+    2.0262456842161683e-11, 1.7980471034525226e-11, 1.4958163374716286e-11, 1.1499088978008626e-11,
+    7.901368500373368e-12, 4.426341804705842e-12, 1.2780527689590527e-12, -1.4057402782842982e-12,
+    -3.55248090780079e-12, -5.14639585834831e-12, -6.215880692926163e-12, -6.819541109148499e-12,
+    -7.033050434661618e-12, -6.9381642349897165e-12, -6.6144837900130434e-12, -6.133989462793558e-12,
+    -5.558002546094944e-12, -4.936058147735612e-12, -4.306135245760123e-12, -3.695741728049886e-12,
+    -3.123447840100227e-12, -2.600568955789507e-12, -2.1327981902626267e-12, -1.7216713047944073e-12,
+    2.1898532076333346e-13, 1.3401002027023471e-13, 4.1332215565528644e-14, -4.9500971570289244e-14,
+    -1.2981468832580349e-13, -1.9299410000071784e-13, -2.3518921321774244e-13, -2.5546184588991767e-13,
+    -2.5543660008072107e-13, -2.3861410677537513e-13, -2.0954232124773003e-13, -1.7302405789650912e-13,
+    -1.3348537584474725e-13, -9.456373372731918e-14, -5.891675223579186e-14, -2.8213038951662673e-14,
+    -3.2481969585605714e-15, 1.5871856937263337e-14, 2.9528178190219994e-14, 3.8399990827391315e-14,
+    4.3308552170185995e-14, 4.510064268397301e-14, 4.457054076602444e-14, 4.24147581433846e-14,
+    3.921197389904554e-14, 3.542059996000773e-14, 3.1387425990005986e-14, 2.7362220958820366e-14};
+// COARE convective psi in L = LOG(y): 28 intervals, max |table - function| = 2.95e-16
+AB_TAB double kPsiTabC[224] = {
+    0.04529948098209352, 0.14189234846792742, 0.2466101756786744, 0.3595535229864228,
+    0.48075504594608276, 0.610180876850435, 0.7477340893445559, 0.8932599224377806,
+    1.0465523549720697, 1.2073615824151536, 1.3754019521211005, 1.5503599530424756,
+    1.7319019204183703, 1.9196811936716718, 2.1133445462761236, 2.3125377816626242,
+    2.5169104540305747, 2.726119724530255, 2.9398334011343463, 3.15773223557881,
+    3.3795115648810437, 3.604882390379675, 3.833571986244687, 4.0653241240197735,
+    4.299898991684401, 4.53707287629091, 4.776637669416922, 5.0184002451421135,
+    0.046290391133633264, 0.050316467242499566, 0.05440974743396389, 0.05853630941680868,
+    0.062662361968251, 0.06675534771018629, 0.07078491270516744, 0.07472368911604557,
+    0.07854785976082436, 0.08223749630746098, 0.0857766829600353, 0.0891534527008305,
+    0.09235957258748725, 0.09539021844313389, 0.09824357845570657, 0.10092042103931514,
+    0.10342365618176914, 0.1057579126136941, 0.1079291464009916, 0.10994429057991162,
+    0.11181095053319257, 0.113537146035445, 0.11513109821496434, 0.11660105794022727,
+    0.1179551711590232, 0.11920137631095869, 0.12034732893257373, 0.12140034883900841,
+    0.0009953416310716696, 0.0010163212118455532, 0.0010289005559759729, 0.0010329678291042393,
+    0.0010286978168085044, 0.001016527027106686, 0.0009971127869080388, 0.0009712816343667031,
+    0.0009399728422009146, 0.000904182560910266, 0.0008649130587175914, 0.0008231301517304476,
+    0.0007797304571360984, 0.0007355187965635099, 0.000691195067971766, 0.0006473492443284129,
+    0.0006044628271567312, 0.0005629150207524989, 0.0005229920191157457, 0.0004848980349650175,
+    0.00044876698445599217, 0.0004146740260199319, 0.0003826464080686944, 0.00035267329357035137,
+    0.0003247143955267429, 0.0002987073787023812, 0.00027457406568436716, 0.00025222553700215224,
+    4.178173373109641e-06, 2.803765721441124e-06, 1.3862571800150163e-06, -2.557357932599896e-08,
+    -1.3855228409764022e-06, -2.653002248822162e-06, -3.7952926549550493e-06, -4.788843658112981e-06,
+    -5.619607318037562e-06, -6.282526775530033e-06, -6.78038799110039e-06, -7.122279164248292e-06,
+    -7.321893631907095e-06, -7.39587173771854e-06, -7.3623210596974165e-06, -7.2395962415528935e-06,
+    -7.045369040101726e-06, -6.795980995001982e-06, -6.506046415283077e-06, -6.188260674115349e-06,
+    -5.853365355733585e-06, -5.510224575967214e-06, -5.165973105697561e-06, -4.826204686894181e-06,
+    -4.495176730529954e-06, -4.176014591556879e-06, -3.8709044366193895e-06, -3.581268262732922e-06,
+    -1.6708124301857217e-07, -1.7551635196022662e-07, -1.7783707608487505e-07, -1.7415157032601542e-07,
+    -1.64985382160261e-07, -1.5120009627595043e-07, -1.3388121118123845e-07, -1.1421501031742401e-07,
+    -9.33730343056178e-08, -7.241817033805637e-08, -5.224008552240641e-08, -3.352150100239719e-08,
+    -1.6731913636596045e-08, -2.142418713780187e-09, 1.0145754555907475e-08, 2.0165942500437135e-08,
+    2.8049591289711673e-08, 3.399256836955515e-08, 3.822653040840923e-08, 4.09962935856305e-08,
+    4.254318667536689e-08, 4.3093768784997036e-08, 4.2852996280071244e-08, 4.2000843520490476e-08,
+    4.069143992203817e-08, 3.9053917211777894e-08, 3.719431955880926e-08, 3.5198086280489954e-08,
+    -1.1415332950006078e-09, -5.397285986110226e-10, 7.372219848236811e-11, 6.544804842613599e-10,
+    1.1642061086916462e-09, 1.574550155027219e-09, 1.8692600045982588e-09, 2.044296530644463e-09,
+    2.106276243542072e-09, 2.069813582790475e-09, 1.954415844498125e-09, 1.781502571681103e-09,
+    1.571945775048792e-09, 1.3443260909518626e-09, 1.1139257064133314e-09, 8.923591921524777e-10,
+    6.876828340453736e-10, 5.04811129474378e-10, 3.4608906496142196e-10, 2.1190424759955593e-10,
+    1.0126147366414524e-10, 1.2276280138662402e-11, -5.7429966439500326e-11, -1.1043332422072651e-10,
+    -1.4929849148148553e-10, -1.7644285780776803e-10, -1.9405723511507826e-10, -2.0406828176125495e-10,
+    4.8362578112254345e-11, 5.123785237365567e-11, 5.031463438371543e-11, 4.5883241032265476e-11,
+    3.863218884233347e-11, 2.950847273492058e-11, 1.954999038506005e-11, 9.728300742858384e-12,
+    8.307714760785022e-13, -6.6037316694358056e-12, -1.2296428604148812e-11, -1.6199094906629782e-11,
+    -1.8439955934519478e-11, -1.926118717254953e-11, -1.8960464403963518e-11, -1.784401034458074e-11,
+    -1.6193957232734446e-11, -1.4249460096520059e-11, -1.2199057418830646e-11, -1.0181065663113648e-11,
+    -8.288918549044043e-12, -6.578930268935798e-12, -5.0786743815120455e-12, -3.794840206532353e-12,
+    -2.7199662344806123e-12, -1.8378322659166164e-12, -1.1275334275684914e-12, -5.663906051781826e-13,
+    3.3962374534011237e-13, 6.898763685989287e-14, -1.974083861208119e-13, -4.274734570264325e-13,
+    -5.971795865833129e-13, -6.939544771419252e-13, -7.172524390048276e-13, -6.766195955596589e-13,
+    -5.881820728387849e-13, -4.706881351354242e-13, -3.420610913229443e-13, -2.1702933343091422e-13,
+    -1.0597886679959869e-13, -1.485557025840927e-14, 5.421856617375942e-14, 1.019741178382386e-13,
+    1.3095994457039944e-13, 1.446353058102738e-13, 1.466787304650988e-13, 1.4052952720324492e-13,
+    1.2913291761216073e-13, 1.1484012642507805e-13, 9.94124486272133e-14, 8.408555406772081e-14,
+    6.966118885884548e-14, 5.6604317094079784e-14, 4.513279603485118e-14, 3.529332826378247e-14};
+// e_sat(T) [Pa] on 265 K <= T < 312 K, RELATIVE error: 24 intervals, max |table - function| = 8.78e-17
+AB_TAB double kEsatTab[192] = {
+    357.2473193130473, 414.99422650940124, 480.89879968552964, 555.9404053510848,
+    641.193756944363, 737.8357614239685, 847.1526368401525, 970.5472954120968,
+    1109.546985510079, 1265.8111848316844, 1441.139735976542, 1637.4812145717008,
+    1856.9415190867264, 2101.7926705105347, 2374.4818091471448, 2677.6403749307447,
+    3014.093456867087, 3386.8692964830925, 3799.208929513944, 4254.575949480656,
+    4756.666376314284, 5309.418612768136, 5917.023471028621, 6583.934251690093,
+    26.986008246361397, 30.83506241256419, 35.15106987493428, 39.98003818371885,
+    45.37132966983021, 51.377798113790305, 58.055922961622855, 65.46594052089891,
+    73.67197157702778, 82.742144880563, 92.74871597066488, 103.76818081780259,
+    115.88138379013216, 129.17361947257095, 143.73472789519766, 159.65918275801153,
+    177.04617227203855, 195.99967227201748, 216.62851129315396, 239.04642734342102,
+    263.3721161433104, 289.72927064651367, 318.24661169743365, 349.0579097244075,
+    0.907525583565605, 1.0187838881623963, 1.1411362466431223, 1.2754041017436164,
+    1.4224433225964472, 1.5831436626506878, 1.758428075352492, 1.9492518888283727,
+    2.1566018417699566, 2.3814949836560606, 2.6249774433571615, 2.8881230710411536,
+    3.172031959130745, 3.4778288488456357, 3.806661429590969, 4.1596985391226085,
+    4.5381282730252055, 4.94315601257733, 5.376002380546362, 5.83790113485231,
+    6.330097010363011, 6.8538435193325125, 7.4104007211700855, 8.00103297232984,
+    0.017662733441308524, 0.019445219272153237, 0.021361719184827543, 0.023418008163795714,
+    0.02561978272878074, 0.0279726371784461, 0.03048203996056908, 0.03315331032937133,
+    0.035991595448065884, 0.039001848090695304, 0.04218880509204964, 0.04555696668795754,
+    0.04911057688063653, 0.052853604955179975, 0.056789728263760005, 0.060922316383859206,
+    0.06525441674592955, 0.06978874181443896, 0.07452765789442758, 0.07947317562357822,
+    0.08462694219752889, 0.08999023536383384, 0.0955639592077234, 0.10134864174072697,
+    0.00021467733159965372, 0.00023106562811270342, 0.00024817971197498424, 0.00026601126007818373,
+    0.0002845489786084486, 0.0003037786087524401, 0.0003236829525898746, 0.0003442419189358377,
+    0.00036543258871942635, 0.00038722929931755414, 0.0004096037471055955, 0.00043252510734128604,
+    0.00045596017036606467, 0.00047987349298974274, 0.0005042275638207016, 0.0005289829812152407,
+    0.0005540986424464857, 0.0005795319426355102, 0.0006052389819449223, 0.0006311747795078368,
+    0.0006572934925524941, 0.0006835486391842012, 0.0007098933233011101, 0.0007362804601477862,
+    1.602336891035799e-06, 1.6752330203033473e-06, 1.7474450578751448e-06, 1.8186763230346066e-06,
+    1.8886296930256124e-06, 1.957009627454928e-06, 2.023524178117305e-06, 2.0878869661764966e-06,
+    2.1498191094520063e-06, 2.2090510835434227e-06, 2.2653245016509664e-06, 2.318393799200849e-06,
+    2.3680278107354875e-06, 2.41401122795973e-06, 2.4561459293236684e-06, 2.4942521730494786e-06,
+    2.5281696470542003e-06, 2.557758370763515e-06, 2.5828994453359132e-06, 2.603495650305908e-06,
+    2.6194718860945453e-06, 2.6307754632123036e-06, 2.6373762402821345e-06, 2.6392666142291488e-06,
+    6.0947654464108995e-09, 6.050062482498647e-09, 5.9807122686975955e-09, 5.886593610941404e-09,
+    5.767754092812698e-09, 5.624409632847216e-09, 5.456942507409448e-09, 5.265897899720514e-09,
+    5.051979050248024e-09, 4.816041096603773e-09, 4.5590837022653705e-09, 4.282242582801332e-09,
+    3.98678004582405e-09, 3.6740746666373754e-09, 3.345610225525678e-09, 3.0029640349119706e-09,
+    2.647794785275628e-09, 2.281830037863602e-09, 1.9068534899643302e-09, 1.5246921349629106e-09,
+    1.1372034346896617e-09, 7.462626158472491e-10, 3.537501956924897e-10, -3.846016520331592e-11,
+    -2.3186442213180708e-12, -4.070853390546014e-12, -5.837729791075412e-12, -7.607239227392809e-12,
+    -9.367323170999561e-12, -1.1106010151343443e-11, -1.2811523380341068e-11, -1.4472383507402099e-11,
+    -1.6077505519413973e-11, -1.7616288924063598e-11, -1.9078700482838034e-11, -2.045534888986772e-11,
+    -2.173755092241504e-11, -2.2917388716405885e-11, -2.3987757944278737e-11, -2.4942406791111382e-11,
+    -2.5775965737211713e-11, -2.6483968260063418e-11, -2.706286266484236e-11, -2.7510015340004322e-11,
+    -2.7823705812219213e-11, -2.8003114042898774e-11, -2.804830046660785e-11, -2.7960179319789003e-11};
+constexpr double kPsiTabSMax = 6.6875, kPsiTabLMax = 7.4453125, kEsatTabT0 = 265., kEsatTabT1 = 312.;
+constexpr int kTabPsikM = 0, kTabPsic = 1, kTabEsat = 2;
+constexpr int kTabNint[3] = {28, 28, 24}, kTabOff[3] = {0, 224, 448}, kTabTotal = 640;
+#ifdef AB_PSI_LDS_TABLES
+constexpr bool kPsiTabDefault = true;
+#else
+constexpr bool kPsiTabDefault = false;
+#endif
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+// two arrays: a kernel that never evaluates e_sat through its table (ESAT = false below) does not allocate the second
+static __shared__ double s_psitab[kTabOff[2]];
+static __shared__ double s_esattab[kTabTotal - kTabOff[2]];
+// all threads of a block, BEFORE the barrier of math_tables_init().  ESAT: also the e_sat table (the kernels with the skin schemes,
+// where e_sat is evaluated a dozen times per cell; without them four times: not worth 1.5 KB of the LDS five blocks per CU share)
+template <bool ESAT = true> __device__ __forceinline__ void psi_tables_fill()
+{
+    for (int t = (int)threadIdx.x; t < kTabOff[2]; t += (int)blockDim.x) s_psitab[t] = t < kTabOff[1] ? kPsiTabM[t] : kPsiTabC[t - kTabOff[1]];
+    if constexpr (ESAT)
+        for (int t = (int)threadIdx.x; t < kTabTotal - kTabOff[2]; t += (int)blockDim.x) s_esattab[t] = kEsatTab[t];
+}
+template <int WHICH> __device__ __forceinline__ double psi_tab_coef(int k, int i)
+{
+    if constexpr (WHICH == kTabEsat) return s_esattab[k * kTabNint[WHICH] + i];
+    else return s_psitab[kTabOff[WHICH] + k * kTabNint[WHICH] + i];
+}
+#else
+template <int WHICH> inline double psi_tab_coef(int k, int i)
+{
+    const double *tab = WHICH == kTabPsikM ? &kPsiTabM[0] : (WHICH == kTabPsic ? &kPsiTabC[0] : &kEsatTab[0]);
+    return tab[k * kTabNint[WHICH] + i];
+}
+#endif
+// xn = position in units of intervals, 0 <= xn < kTabNint[WHICH]
+template <int WHICH> __device__ __forceinline__ double psi_tab_eval(double xn)
+{
+    AB_COUNT(WHICH == kTabPsikM ? "tab_psik_m" : (WHICH == kTabPsic ? "tab_psic" : "tab_e_sat"), 12.);   // floor, sub, fma, cvt, shift + 7 FMAs; the coefficients arrive over the LDS pipe
+    const double fi = __builtin_floor(xn);
+    const int i = (int)fi;
+    const double u = __builtin_fma(xn - fi, 2., -1.);
+    double p = psi_tab_coef<WHICH>(7, i);
+#pragma unroll
+    for (int k = 6; k >= 0; --k) p = __builtin_fma(p, u, psi_tab_coef<WHICH>(k, i));
+    return p;
+}
+// fp32: psi_m, psi_h (Kansas / Paulson), convective psi; 32 intervals, degree 3, [function][coefficient][interval]; max |table - function| = 7.0e-09 / 9.7e-09 / 1.3e-08
+AB_TAB float kPsiTab32[384] = {
+    0.0266377889f, 0.0830520019f, 0.143753141f, 0.208846718f, 0.278417915f, 0.352530777f,
+    0.431228042f, 0.514531136f, 0.602440894f, 0.694938362f, 0.791986048f, 0.893529356f,
+    0.999498308f, 1.10980904f, 1.22436619f, 1.34306383f, 1.46578801f, 1.59241807f,
+    1.72282839f, 1.85688961f, 1.99447012f, 2.13543725f, 2.27965832f, 2.42700148f,
+    2.57733607f, 2.73053432f, 2.88647056f, 3.04502273f, 3.20607162f, 3.36950254f,
+    3.53520393f, 3.70306897f, 0.027155403f, 0.0292692184f, 0.0314407162f, 0.0336599648f,
+    0.0359165668f, 0.0381998643f, 0.0404991768f, 0.0428039916f, 0.0451041833f, 0.047390148f,
+    0.0496529676f, 0.0518844947f, 0.0540774353f, 0.0562253892f, 0.0583228618f, 0.0603652634f,
+    0.0623488612f, 0.0642707422f, 0.0661287606f, 0.0679214597f, 0.0696480051f, 0.0713081136f,
+    0.0729019865f, 0.0744302273f, 0.0758938044f, 0.0772939473f, 0.0786321312f, 0.0799100175f,
+    0.0811294019f, 0.0822921842f, 0.0834003463f, 0.0844558999f, 0.00052041054f, 0.000536015024f,
+    0.000549215591f, 0.000559866778f, 0.00056787784f, 0.000573213736f, 0.0005758935f, 0.000575986807f,
+    0.000573608093f, 0.000568909862f, 0.000562074885f, 0.000553307997f, 0.000542828464f, 0.000530862308f,
+    0.000517635955f, 0.000503370364f, 0.000488276652f, 0.000472552725f, 0.0004563806f, 0.000439925032f,
+    0.000423332822f, 0.000406732695f, 0.000390235859f, 0.000373936782f, 0.000357914425f, 0.000342233398f,
+    0.000326945534f, 0.000312091201f, 0.000297700753f, 0.000283795758f, 0.000270390301f, 0.000257492182f,
+    2.79110645e-06f, 2.40543864e-06f, 1.99110832e-06f, 1.55702253e-06f, 1.11245993e-06f, 6.66647907e-07f,
+    2.28367412e-07f, -1.9438788e-07f, -5.94678795e-07f, -9.66802418e-07f, -1.30638648e-06f, -1.61040248e-06f,
+    -1.87710737e-06f, -2.10593134e-06f, -2.29732541e-06f, -2.45258843e-06f, -2.57368515e-06f, -2.66306938e-06f,
+    -2.72352031e-06f, -2.75799857e-06f, -2.76952278e-06f, -2.76107289e-06f, -2.73551382e-06f, -2.69554039e-06f,
+    -2.64364076e-06f, -2.58207592e-06f, -2.51287065e-06f, -2.43781437e-06f, -2.35846937e-06f, -2.2761833e-06f,
+    -2.19210551e-06f, -2.10720577e-06f, 0.0529284403f, 0.16287373f, 0.278242528f, 0.398976237f,
+    0.524988532f, 0.65616715f, 0.79237622f, 0.933458984f, 1.07924044f, 1.22953069f,
+    1.38412833f, 1.54282284f, 1.70539832f, 1.87163615f, 2.04131699f, 2.21422386f,
+    2.39014363f, 2.56886864f, 2.7501986f, 2.93394041f, 3.11991096f, 3.30793571f,
+    3.49784994f, 3.68949938f, 3.88273907f, 4.07743406f, 4.27345848f, 4.47069693f,
+    4.66904116f, 4.86839247f, 5.06865931f, 5.2697587f, 0.0536106117f, 0.0563322119f,
+    0.059031684f, 0.0616948009f, 0.0643081069f, 0.0668591782f, 0.0693368316f, 0.0717312917f,
+    0.0740343034f, 0.0762391835f, 0.0783408359f, 0.0803356841f, 0.0822216198f, 0.0839978829f,
+    0.0856649131f, 0.0872242227f, 0.0886782259f, 0.0900300965f, 0.0912836194f, 0.0924430266f,
+    0.0935129076f, 0.0944980606f, 0.0954034105f, 0.0962339118f, 0.0969944894f, 0.0976899713f,
+    0.0983250439f, 0.0989042148f, 0.0994317904f, 0.0999118686f, 0.100348294f, 0.100744702f,
+    0.000681870733f, 0.000678163779f, 0.000670830079f, 0.00066002633f, 0.000645978784f, 0.000628973241f,
+    0.000609343173f, 0.000587456394f, 0.000563701382f, 0.000538474007f, 0.000512165076f, 0.000485149998f,
+    0.000457779883f, 0.000430374843f, 0.00040321963f, 0.000376560987f, 0.000350606831f, 0.000325526897f,
+    0.000301454653f, 0.000278489752f, 0.000256701489f, 0.000236132168f, 0.00021680085f, 0.000198706926f,
+    0.000181833602f, 0.000166151018f, 0.000151619155f, 0.000138190415f, 0.000125811741f, 0.00011442657f,
+    0.000103976359f, 9.44018975e-05f, -3.10091991e-07f, -9.2353946e-07f, -1.5170865e-06f, -2.07847256e-06f,
+    -2.59686453e-06f, -3.06327524e-06f, -3.47084733e-06f, -3.81499649e-06f, -4.09341146e-06f, -4.30592809e-06f,
+    -4.45430442e-06f, -4.54192104e-06f, -4.57343867e-06f, -4.5544466e-06f, -4.49111849e-06f, -4.38990128e-06f,
+    -4.25724784e-06f, -4.09939685e-06f, -3.92220591e-06f, -3.73103489e-06f, -3.53067253e-06f, -3.32530203e-06f,
+    -3.11849635e-06f, -2.91323863e-06f, -2.71195813e-06f, -2.51657821e-06f, -2.32856996e-06f, -2.14900979e-06f,
+    -1.97863346e-06f, -1.81789073e-06f, -1.66699499e-06f, -1.52596692e-06f, 0.0395287387f, 0.123166457f,
+    0.213005647f, 0.309125036f, 0.411563545f, 0.520320535f, 0.635356963f, 0.756597757f,
+    0.883934677f, 1.01722944f, 1.15631783f, 1.30101407f, 1.45111418f, 1.60640061f,
+    1.76664603f, 1.93161643f, 2.10107493f, 2.27478409f, 2.45250845f, 2.63401699f,
+    2.81908441f, 3.00749183f, 3.19902921f, 3.39349484f, 3.59069681f, 3.790452f,
+    3.99258733f, 4.19693995f, 4.4033556f, 4.61168957f, 4.82180643f, 5.03357935f,
+    0.0402865335f, 0.0433610156f, 0.0464847423f, 0.0496378988f, 0.0528005436f, 0.055953145f,
+    0.059077017f, 0.0621547587f, 0.0651705638f, 0.068110466f, 0.0709624812f, 0.0737167001f,
+    0.0763652474f, 0.0789022371f, 0.0813236162f, 0.0836270303f, 0.0858116299f, 0.0878778696f,
+    0.0898273215f, 0.091662474f, 0.0933865607f, 0.0950033888f, 0.0965171903f, 0.0979325101f,
+    0.0992540643f, 0.100486681f, 0.101635203f, 0.102704428f, 0.103699051f, 0.104623668f,
+    0.105482683f, 0.106280334f, 0.00076074939f, 0.000775490596f, 0.000785338576f, 0.000790198392f,
+    0.000790105667f, 0.000785219541f, 0.000775809516f, 0.000762237469f, 0.000744936522f, 0.00072438881f,
+    0.000701103534f, 0.000675596471f, 0.000648372574f, 0.000619911356f, 0.000590656302f, 0.00056100724f,
+    0.000531316269f, 0.000501885894f, 0.000472969958f, 0.000444775535f, 0.000417466654f, 0.000391168258f,
+    0.000365970744f, 0.000341934705f, 0.000319095183f, 0.000297466147f, 0.000277044106f, 0.0002578118f,
+    0.000239740984f, 0.000222795279f, 0.000206932193f, 0.000192105043f, 2.85429064e-06f, 2.05379683e-06f,
+    1.22649419e-06f, 3.94353407e-07f, -4.2125194e-07f, -1.20067079e-06f, -1.92689845e-06f, -2.58623254e-06f,
+    -3.16863543e-06f, -3.66780728e-06f, -4.08100732e-06f, -4.40867916e-06f, -4.65394305e-06f, -4.82202267e-06f,
+    -4.91965784e-06f, -4.95455151e-06f, -4.93488278e-06f, -4.86889667e-06f, -4.76458672e-06f, -4.62946218e-06f,
+    -4.47038792e-06f, -4.29349984e-06f, -4.10416487e-06f, -3.90698779e-06f, -3.70584439e-06f, -3.50393452e-06f,
+    -3.30384864e-06f, -3.10763653e-06f, -2.91687957e-06f, -2.73275714e-06f, -2.55611189e-06f, -2.38750613e-06f};
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+static __shared__ float s_psitab32[384];
+// fp32 kernels: all threads of a block of 256, before the block's first barrier
+__device__ __forceinline__ void psi_tables_fill32()
+{
+    for (int t = (int)threadIdx.x; t < 384; t += (int)blockDim.x) s_psitab32[t] = kPsiTab32[t];
+}
+template <int WHICH> __device__ __forceinline__ float psi_tab_coef32(int k, int i) { return s_psitab32[WHICH * 128 + k * 32 + i]; }
+#else
+template <int WHICH> inline float psi_tab_coef32(int k, int i) { return kPsiTab32[WHICH * 128 + k * 32 + i]; }
+#endif
+// WHICH: 0 psi_m, 1 psi_h (Kansas / Paulson, x32 = 32 s / 6.6875), 2 convective psi (x32 = 32 L / 7.4453125); 0 <= x32 < 32
+template <int WHICH> __device__ __forceinline__ float psi_tab_eval32(float x32)
+{
+    const float fi = __builtin_floorf(x32);
+    const int i = (int)fi;
+    const float u = __builtin_fmaf(x32 - fi, 2.f, -1.f);
+    float p = psi_tab_coef32<WHICH>(3, i);
+#pragma unroll
+    for (int k = 2; k >= 0; --k) p = __builtin_fmaf(p, u, psi_tab_coef32<WHICH>(k, i));
+    return p;
+}
+template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R e_sat(R pTa)
 {
     AB_REGION("e_sat");
     using M = Mth<R>;
     const R zta = vmax(pTa, R(180.));
+    if constexpr (sizeof(R) == 8 && TAB) {   // the tiled fp64 flux kernels: e_sat itself from its piecewise LDS table
+        if ((zta >= R(kEsatTabT0)) && (zta < R(kEsatTabT1)))
+            return R(psi_tab_eval<kTabEsat>((double)R((zta - R(kEsatTabT0)) * R(24. / (kEsatTabT1 - kEsatTabT0)))));
+    }
     R e;
     if ((zta >= R(265.)) && (zta <= R(312.))) {
         e = goff_poly((zta - R(288.5)) * R(1. / 23.5));
@@ -123,22 +434,22 @@ template <class R> __device__ __forceinline__ R e_sat(R pTa)
     return R(100.) * M::exp10(e);
 }
 // q_sat_sclr :881-904
-template <class R> __device__ __forceinline__ R q_sat(R pTa, R pslp)
+template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R q_sat(R pTa, R pslp)
 {
     AB_REGION("q_sat");
-    const R ze_s = e_sat(pTa);
+    const R ze_s = e_sat<R, TAB>(pTa);
     return Mth<R>::div(K<R>::reps0 * ze_s, pslp - K<R>::one_m_reps0 * ze_s);
 }
 // q_air_rh :963-985
-template <class R> __device__ __forceinline__ R q_air_rh(R prha, R pTa, R pslp)
+template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R q_air_rh(R prha, R pTa, R pslp)
 {
-    const R ze = R(0.01) * prha * e_sat(pTa);
+    const R ze = R(0.01) * prha * e_sat<R, TAB>(pTa);
     return Mth<R>::div(ze * K<R>::reps0, vmax(pslp - K<R>::one_m_reps0 * ze, R(1.)));
 }
 // q_air_dp :990-1000
-template <class R> __device__ __forceinline__ R q_air_dp(R da, R pslp)
+template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R q_air_dp(R da, R pslp)
 {
-    const R q = vmax(e_sat(da), R(0.));
+    const R q = vmax(e_sat<R, TAB>(da), R(0.));
     return Mth<R>::div(q * K<R>::reps0, vmax(pslp - K<R>::one_m_reps0 * q, R(1.)));
 }
 // Theta_from_z_P0_T_q :343-375 = Pz_from_P0_tz_qz_sclr :283-318 (3 barometric iterations) + Poisson :189-200
@@ -153,11 +464,11 @@ template <class R> __device__ __forceinline__ R exp_tiny(R x)
     p = p * x + R(1.);
     return p * x + R(1.);
 }
-template <class R> __device__ __forceinline__ R theta_from_z_p0_t_q(R pz, R pslp, R pTa, R pqa)
+template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R theta_from_z_p0_t_q(R pz, R pslp, R pTa, R pqa)
 {
     using M = Mth<R>;
     // e_sat(pTa) does not depend on the pressure iterate: evaluate once (the reference recomputes it)
-    const R ze_s = e_sat(pTa);
+    const R ze_s = e_sat<R, TAB>(pTa);
     const R c = M::div(-K<R>::grav * pz, K<R>::R_gas * pTa);
     const R zi = M::rcp(K<R>::reps0 * ze_s);
     // |c M| <= 9.8 * 0.029 * pz / (8.3145 * pTa): below 2.5e-3 for pz <= 10 m and pTa >= 137 K (pz is wave-uniform)
@@ -441,268 +752,6 @@ __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, const WlEcmwfCell<R> 
     dT_wl = zdTwl_n * ztcorr;
 }
 
-// ---- piecewise tables in LDS (kernels that define AB_PSI_LDS_TABLES before including this header and call psi_tables_fill())
-// psi_m of Kansas / Paulson in s = LOG(y) and COARE's convective psi in L = LOG(y) (the functions of the two sections below) on 32 equal intervals
-// of [0, 6.6875) / [0, 7.4453125), degree 7 on each (tools/gen_psitab.py; 2.1e-16 / 3.4e-16 absolute, the rounding of the
-// coefficients): 4 KB of LDS per block, coefficient-major, so that lanes on different intervals hit different banks.  An
-// evaluation is five operations for the interval and the local variable, a shift for the address and seven FMAs, the eight
-// coefficients arriving over the LDS pipe — where the global polynomials take 22 and 24 FMAs on the VALU, the unit that binds
-// these kernels.  A timing experiment with polynomials of that length bounded the gain at 5 % (COARE + skin) and 9 % (no skin)
-// before this was built (profiles/r2_notes.md).
-// psi_m (Kansas / Paulson) in s = LOG(y): max |table - function| = 2.14e-16
-AB_TAB double kPsiTabM[256] = {
-    0.02663778402106073, 0.08305199855091043, 0.14375312959675965, 0.20884670895689178,
-    0.27841790088177193, 0.35253077640424074, 0.431228032066807, 0.5145311410802141,
-    0.6024409072594966, 0.6949383774831795, 0.7919860576462795, 0.8935293704457201,
-    0.9994982907683915, 1.109809095540299, 1.2243661690015426, 1.3430638107310473,
-    1.465788001562772, 1.5924180910674675, 1.7228283788822931, 1.8568895703522126,
-    1.9944700943446678, 2.135437277492742, 2.2796583744108383, 2.42700145760461,
-    2.5773361739262186, 2.730534376614903, 2.886470643343973, 3.0450226914098955,
-    3.206071701385212, 3.369502560341748, 3.5352040352457172, 3.7030688864261356,
-    0.027155403479856115, 0.02926921894694357, 0.031440716135344215, 0.033659966301942734,
-    0.03591656720496811, 0.03819986506712594, 0.040499175360076765, 0.04280399296774216,
-    0.04510418357758432, 0.047390149911940294, 0.04965296843856426, 0.05188449428197962,
-    0.05407743401090371, 0.05622538766059889, 0.05832286267299822, 0.060365263364081205,
-    0.0623488600643626, 0.064270742265504, 0.06612876000633006, 0.06792145741686326,
-    0.06964800188119191, 0.07130811174384329, 0.0729019849235192, 0.07443023025346614,
-    0.0758938028677154, 0.07729394451405959, 0.07863212930588703, 0.07991001512687984,
-    0.08112940067127294, 0.08229218793103471, 0.08340034982158602, 0.08445590256068021,
-    0.0005204566372811247, 0.0005360651904701405, 0.0005492688123581237, 0.0005599219132716804,
-    0.000567933705231689, 0.0005732691565861454, 0.0005759474754264933, 0.0005760383701520509,
-    0.000573656477229656, 0.0005689544388085545, 0.0005621151522565781, 0.0005533437030253092,
-    0.0005428594403436595, 0.0005308885743069536, 0.0005176575762480438, 0.0005033875641622144,
-    0.000488289761369601, 0.00047256203645322135, 0.000456386469608833, 0.00043992784595700676,
-    0.00042333294908384033, 0.0004067305157153154, 0.0003902317119159542, 0.0003739309993025444,
-    0.0003579072734681921, 0.0003422251735592319, 0.0003269364797227339, 0.00031208153248237847,
-    0.00029769062403955227, 0.000283785325481023, 0.00027037972566832557, 0.0002574815671780474,
-    2.791567460114328e-06, 2.405797727893118e-06, 1.9913556502002186e-06, 1.5571534764374587e-06,
-    1.1124750559446903e-06, 6.665528323960359e-07, 2.2817213237744266e-07, -1.946701048491997e-07,
-    -5.950324081616795e-07, -9.672106568055118e-07, -1.3068325458877559e-06, -1.6108701547126142e-06,
-    -1.8775820547883733e-06, -2.10640012365236e-06, -2.297777779272976e-06, -2.4530160132774994e-06,
-    -2.574081848546395e-06, -2.6634312064009626e-06, -2.7238451375233366e-06, -2.758285354639302e-06,
-    -2.7697722915695336e-06, -2.761286671455216e-06, -2.7356938636469326e-06, -2.6956891339604703e-06,
-    -2.6437611868467225e-06, -2.582171074472776e-06, -2.5129435131269087e-06, -2.437867813105812e-06,
-    -2.3585059180090527e-06, -2.2762054023195756e-06, -2.1921156471653907e-06, -2.1072057722814713e-06,
-    -4.6080039484659066e-08, -5.019237245056883e-08, -5.3231588582316686e-08, -5.5124645429783004e-08,
-    -5.585177988279081e-08, -5.544502745793885e-08, -5.39829818348639e-08, -5.158258184765321e-08,
-    -4.8388961971928354e-08, -4.4564487699828224e-08, -4.027802880919681e-08, -3.569533584195664e-08,
-    -3.097112619503157e-08, -2.6243206091574613e-08, -2.1628695726008542e-08, -1.7222216175535134e-08,
-    -1.3095752515183008e-08, -9.299829095681163e-09, -5.865611760602451e-09, -2.807574191745459e-09,
-    -1.264163195342812e-10, 2.1880122504681355e-09, 4.15396284023042e-09, 5.7953282806888014e-09,
-    7.139535892506438e-09, 8.215813310210981e-09, 9.053817213307871e-09, 9.682595060346705e-09,
-    1.0129838555811923e-08, 1.042138281811812e-08, 1.0580905165990018e-08, 1.0629780469324681e-08,
-    -4.6116197990466797e-10, -3.5923248412525874e-10, -2.473889005617978e-10, -1.3089564350364883e-10,
-    -1.5074077855214937e-11, 9.510076069983048e-11, 1.953422365248781e-10, 2.8230036872811545e-10,
-    3.5369947275050597e-10, 4.083647409799105e-10, 4.4615129434105503e-10, 4.677988895123732e-10,
-    4.747400299460149e-10, 4.688890437594478e-10, 4.5243587269463354e-10, 4.2766233342350946e-10,
-    3.9679190852153295e-10, 3.6187785228537775e-10, 3.2472929748966867e-10, 2.8687145342204346e-10,
-    2.4953389239595064e-10, 2.1366011353870602e-10, 1.7993172564441746e-10, 1.4880136480313735e-10,
-    1.2052955712968757e-10, 9.522192048037894e-11, 7.286421445411441e-11, 5.335370493443619e-11,
-    3.6526069937890396e-11, 2.217763586183757e-11, 1.0083117559478611e-11, 9.272864524726536e-15,
-    7.939735957711018e-12, 8.97435251117241e-12, 9.584705124228157e-12, 9.748446336430188e-12,
-    9.478168847270938e-12, 8.81804316844119e-12, 7.837167066827024e-12, 6.620827883806037e-12,
-    5.261060224734529e-12, 3.8477958207381246e-12, 2.4616082883626903e-12, 1.1686472770314147e-12,
-    1.7933820519246104e-14, -9.591680275354929e-13, -1.7477316912975448e-12, -2.346846882813599e-12,
-    -2.7665499811447065e-12, -3.0245866929331907e-12, -3.143371169951502e-12, -3.1473768755344e-12,
-    -3.0610762729860846e-12, -2.9074520917168647e-12, -2.7070372305385923e-12, -2.4774019060540834e-12,
-    -2.2329905730889297e-12, -1.9852112331052295e-12, -1.74268998065767e-12, -1.511619006186786e-12,
-    -1.2961430919317752e-12, -1.0987455169049997e-12, -9.20607914016808e-13, -7.619294798376398e-13,
-    8.790740052648657e-14, 5.92312546172485e-14, 2.770148109055384e-14, -4.1594003634147245e-15,
-    -3.393022420999197e-14, -5.955979725891522e-14, -7.956274721434736e-14, -9.311972595915114e-14,
-    -1.0007893802249785e-13, -1.0087355117038882e-13, -9.638131056507251e-14, -8.775716493626773e-14,
-    -7.626752776676346e-14, -6.314796162348758e-14, -4.949714710390291e-14, -3.621128748615457e-14,
-    -2.3956184148730288e-14, -1.3169808613776823e-14, -4.086270451868386e-15, 3.227861564120148e-15,
-    8.832578736627006e-15, 1.2874520583213646e-14, 1.5551807782338705e-14, 1.7085496320376062e-14,
-    1.7698147568903484e-14, 1.759907783755744e-14, 1.6975320415084094e-14, 1.598711436776133e-14,
-    1.47667306758105e-14, 1.3419571582938847e-14, 1.2026666236119405e-14, 1.0647888149236058e-14};
-// COARE convective psi in L = LOG(y): max |table - function| = 3.44e-16
-AB_TAB double kPsiTabC[256] = {
-    0.039528726102123664, 0.12316644210081357, 0.21300563223062205, 0.3091250329737914,
-    0.4115635408596482, 0.5203204939370544, 0.6353569384722432, 0.7565977758746876,
-    0.8839346468990753, 1.0172293857270698, 1.156317866107955, 1.3010140642918857,
-    1.4511141768160811, 1.6064006524122763, 1.7666460232994539, 1.9316164490127157,
-    2.101074913274074, 2.27478403942807, 2.4525085114831033, 2.6340171052428123,
-    2.819084347282074, 3.0074918288673844, 3.199029207810646, 3.39349493425986,
-    3.590696737179579, 3.7904519073374194, 3.9925874105041834, 4.1969398617244575,
-    4.403355388265203, 4.6116894054624735, 4.821806326348987, 5.033579222784928,
-    0.04028653377145358, 0.04336101537216257, 0.04648474246108026, 0.04963789724601906,
-    0.05280054479413356, 0.05595314407481726, 0.059077018007357415, 0.06215476045965342,
-    0.06517056448455533, 0.06811046310374651, 0.07096248081462032, 0.0737167000112357,
-    0.07636525120990165, 0.07890223913562938, 0.08132361836522173, 0.08362703251497582,
-    0.08581163018926197, 0.08787786939459556, 0.08982732018555885, 0.09166247321256404,
-    0.09338655979343337, 0.09500338727203214, 0.09651719183909369, 0.09793250970588427,
-    0.09925406653794545, 0.10048668434809756, 0.1016352045766319, 0.1027044258086566,
-    0.10369905445090902, 0.10462366667391182, 0.10548267998665907, 0.10628033292278938,
-    0.0007608468681014699, 0.0007755928122068397, 0.0007854427848554367, 0.0007903018398525144,
-    0.0007902057527789811, 0.0007853139706165006, 0.0007758963673429966, 0.0007623152317432929,
-    0.0007450041946294949, 0.0007244458643860479, 0.0007011498055287725, 0.0006756322138873693,
-    0.0006483982755753088, 0.0006199278059811806, 0.0005906644000512547, 0.0005610080207780269,
-    0.0005313107268387183, 0.0005018750958137472, 0.00047295482868281, 0.0004447570103322506,
-    0.0004174455331766447, 0.00039114525076358836, 0.0003659465017623523, 0.00034190972153318687,
-    0.0003190699312598247, 0.0002974409589963768, 0.0002770193008140762, 0.00025778757307638115,
-    0.00023971753935208296, 0.00022277271884216628, 0.00020691059896326268, 0.00019208448444667388,
-    2.8548946820050563e-06, 2.054132719865524e-06, 1.2265539957385203e-06, 3.9414473691364535e-07,
-    -4.2170730852350597e-07, -1.2013395200598967e-06, -1.9277387431026174e-06, -2.587198374501398e-06,
-    -3.169679828253545e-06, -3.6688854986798984e-06, -4.082079443179022e-06, -4.409711510456431e-06,
-    -4.654909617917847e-06, -4.822904368262601e-06, -4.92044250520512e-06, -4.9552336729334606e-06,
-    -4.9354612644757866e-06, -4.86937497095364e-06, -4.764971397527784e-06, -4.629760499570267e-06,
-    -4.470609743411454e-06, -4.293654546122628e-06, -4.10426222116937e-06, -3.90703680538087e-06,
-    -3.705853250605255e-06, -3.5039110974890742e-06, -3.303799580265032e-06, -3.1075679138585882e-06,
-    -2.9167961493584784e-06, -2.732663380343554e-06, -2.5560112184798408e-06, -2.38740134120368e-06,
-    -9.75151108792765e-08, -1.0222794944948286e-07, -1.0420606710748598e-07, -1.034482799380546e-07,
-    -1.0010313738772114e-07, -9.444908980634954e-08, -8.68644069275184e-08, -7.779122217036304e-08,
-    -6.769833398771182e-08, -5.704689204872179e-08, -4.626204910465644e-08, -3.571235514556962e-08,
-    -2.569738474516057e-08, -1.644302817575688e-08, -8.10315355482771e-09, -7.659810888116756e-10,
-    5.536546353050911e-09, 1.0817944322636633e-08, 1.5126168671021555e-08, 1.8533299864101644e-08,
-    2.112649626967275e-08, 2.3000497597328128e-08, 2.4251740796102214e-08, 2.49739998330186e-08,
-    2.5255370012323686e-08, 2.5176374500546417e-08, 2.480896221441525e-08, 2.4216180154378188e-08,
-    2.3452329846015065e-08, 2.256344954239122e-08, 2.158799633815713e-08, 2.055763236526032e-08,
-    -6.040613045178274e-10, -3.35871533217387e-10, -5.974310241475503e-11, 2.0879092836771924e-10,
-    4.555456564572579e-10, 6.688984542781468e-10, 8.406063836318656e-10, 9.661594697486078e-10,
-    1.0446847880978866e-09, 1.0784833555627998e-09, 1.0723223129139952e-09, 1.0326160627089401e-09,
-    9.66616349859586e-10, 8.817015097146355e-10, 7.848190297643675e-10, 6.821013678685458e-10,
-    5.786479114142694e-10, 4.784482294367e-10, 3.844130859099757e-10, 2.984782675001519e-10,
-    2.2174976781286443e-10, 1.5466498467249587e-10, 9.715151397856938e-11, 4.8771640679024235e-11,
-    8.846061941308145e-12, -2.3445516383473284e-11, -4.8986455248312317e-11, -6.866576282543766e-11,
-    -8.333815128613264e-11, -9.379828135688046e-11, -1.0076603263387329e-10, -1.048799828732382e-10,
-    2.157176539563208e-11, 2.288732885071638e-11, 2.2893166124674294e-11, 2.164268157768004e-11,
-    1.930324536726664e-11, 1.612831899833023e-11, 1.2420468255485012e-11, 8.492286147244826e-12,
-    4.631652017303722e-12, 1.0758994191648143e-12, -2.0029714350715293e-12, -4.502236621479342e-12,
-    -6.383486748555225e-12, -7.66162712627659e-12, -8.39085855233819e-12, -8.650239388625704e-12,
-    -8.530705422285317e-12, -8.1246320729071e-12, -7.51833035585983e-12, -6.7873583175034714e-12,
-    -5.994220306671718e-12, -5.187890672895045e-12, -4.4045895253802224e-12, -3.669306910444218e-12,
-    -2.9976768710558607e-12, -2.3979148543863475e-12, -1.8726329904998177e-12, -1.4204294033696405e-12,
-    -1.0372079274271345e-12, -7.172251980744697e-13, -4.53886661440124e-13, -2.403256496645243e-13,
-    1.3977478543200897e-13, 4.7303542113844724e-14, -4.5833185801975875e-14, -1.3082817170851954e-13,
-    -2.0038618856094692e-13, -2.496108808258504e-13, -2.764072092961818e-13, -2.8138503219021783e-13,
-    -2.6735846105473816e-13, -2.38602992919902e-13, -2.0004833030717136e-13, -1.5655680586050874e-13,
-    -1.1238356427692268e-13, -7.085530260238856e-14, -3.425500261970698e-14, -3.868675415904508e-15,
-    1.9862530985053918e-14, 3.713940018932581e-14, 4.859440981129682e-14, 5.510331785005644e-14,
-    5.763397604132945e-14, 5.713692803299282e-14, 5.4475096980428775e-14, 5.038592456865748e-14,
-    4.546792642508214e-14, 4.018390301198579e-14, 3.4874225048470426e-14, 2.977513194223578e-14,
-    2.503847959106338e-14, 2.075065847864333e-14, 1.6949402297893268e-14, 1.3637923116401261e-14};
-
-constexpr double kPsiTabSMax = 6.6875, kPsiTabLMax = 7.4453125;
-#ifdef AB_PSI_LDS_TABLES
-constexpr bool kPsiTabDefault = true;
-#else
-constexpr bool kPsiTabDefault = false;
-#endif
-#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
-static __shared__ double s_psitab[512];
-// all threads of a block of 256, BEFORE the barrier of math_tables_init()
-__device__ __forceinline__ void psi_tables_fill()
-{
-    for (int t = (int)threadIdx.x; t < 256; t += (int)blockDim.x) {
-        const double a = kPsiTabM[t], b = kPsiTabC[t];
-        s_psitab[t] = a;
-        s_psitab[256 + t] = b;
-    }
-}
-template <int WHICH> __device__ __forceinline__ double psi_tab_coef(int k, int i) { return s_psitab[WHICH * 256 + k * 32 + i]; }
-#else
-template <int WHICH> inline double psi_tab_coef(int k, int i) { return (WHICH ? kPsiTabC : kPsiTabM)[k * 32 + i]; }
-#endif
-// x32 = 32 x / range, 0 <= x32 < 32
-template <int WHICH> __device__ __forceinline__ double psi_tab_eval(double x32)
-{
-    AB_COUNT(WHICH ? "tab_psic" : "tab_psik_m", 12.);   // floor, sub, fma, cvt, shift + 7 FMAs; the coefficients arrive over the LDS pipe
-    const double fi = __builtin_floor(x32);
-    const int i = (int)fi;
-    const double u = __builtin_fma(x32 - fi, 2., -1.);
-    double p = psi_tab_coef<WHICH>(7, i);
-#pragma unroll
-    for (int k = 6; k >= 0; --k) p = __builtin_fma(p, u, psi_tab_coef<WHICH>(k, i));
-    return p;
-}
-// fp32: psi_m, psi_h (Kansas / Paulson), convective psi; 32 intervals, degree 3, [function][coefficient][interval]; max |table - function| = 7.0e-09 / 9.7e-09 / 1.3e-08
-AB_TAB float kPsiTab32[384] = {
-    0.0266377889f, 0.0830520019f, 0.143753141f, 0.208846718f, 0.278417915f, 0.352530777f,
-    0.431228042f, 0.514531136f, 0.602440894f, 0.694938362f, 0.791986048f, 0.893529356f,
-    0.999498308f, 1.10980904f, 1.22436619f, 1.34306383f, 1.46578801f, 1.59241807f,
-    1.72282839f, 1.85688961f, 1.99447012f, 2.13543725f, 2.27965832f, 2.42700148f,
-    2.57733607f, 2.73053432f, 2.88647056f, 3.04502273f, 3.20607162f, 3.36950254f,
-    3.53520393f, 3.70306897f, 0.027155403f, 0.0292692184f, 0.0314407162f, 0.0336599648f,
-    0.0359165668f, 0.0381998643f, 0.0404991768f, 0.0428039916f, 0.0451041833f, 0.047390148f,
-    0.0496529676f, 0.0518844947f, 0.0540774353f, 0.0562253892f, 0.0583228618f, 0.0603652634f,
-    0.0623488612f, 0.0642707422f, 0.0661287606f, 0.0679214597f, 0.0696480051f, 0.0713081136f,
-    0.0729019865f, 0.0744302273f, 0.0758938044f, 0.0772939473f, 0.0786321312f, 0.0799100175f,
-    0.0811294019f, 0.0822921842f, 0.0834003463f, 0.0844558999f, 0.00052041054f, 0.000536015024f,
-    0.000549215591f, 0.000559866778f, 0.00056787784f, 0.000573213736f, 0.0005758935f, 0.000575986807f,
-    0.000573608093f, 0.000568909862f, 0.000562074885f, 0.000553307997f, 0.000542828464f, 0.000530862308f,
-    0.000517635955f, 0.000503370364f, 0.000488276652f, 0.000472552725f, 0.0004563806f, 0.000439925032f,
-    0.000423332822f, 0.000406732695f, 0.000390235859f, 0.000373936782f, 0.000357914425f, 0.000342233398f,
-    0.000326945534f, 0.000312091201f, 0.000297700753f, 0.000283795758f, 0.000270390301f, 0.000257492182f,
-    2.79110645e-06f, 2.40543864e-06f, 1.99110832e-06f, 1.55702253e-06f, 1.11245993e-06f, 6.66647907e-07f,
-    2.28367412e-07f, -1.9438788e-07f, -5.94678795e-07f, -9.66802418e-07f, -1.30638648e-06f, -1.61040248e-06f,
-    -1.87710737e-06f, -2.10593134e-06f, -2.29732541e-06f, -2.45258843e-06f, -2.57368515e-06f, -2.66306938e-06f,
-    -2.72352031e-06f, -2.75799857e-06f, -2.76952278e-06f, -2.76107289e-06f, -2.73551382e-06f, -2.69554039e-06f,
-    -2.64364076e-06f, -2.58207592e-06f, -2.51287065e-06f, -2.43781437e-06f, -2.35846937e-06f, -2.2761833e-06f,
-    -2.19210551e-06f, -2.10720577e-06f, 0.0529284403f, 0.16287373f, 0.278242528f, 0.398976237f,
-    0.524988532f, 0.65616715f, 0.79237622f, 0.933458984f, 1.07924044f, 1.22953069f,
-    1.38412833f, 1.54282284f, 1.70539832f, 1.87163615f, 2.04131699f, 2.21422386f,
-    2.39014363f, 2.56886864f, 2.7501986f, 2.93394041f, 3.11991096f, 3.30793571f,
-    3.49784994f, 3.68949938f, 3.88273907f, 4.07743406f, 4.27345848f, 4.47069693f,
-    4.66904116f, 4.86839247f, 5.06865931f, 5.2697587f, 0.0536106117f, 0.0563322119f,
-    0.059031684f, 0.0616948009f, 0.0643081069f, 0.0668591782f, 0.0693368316f, 0.0717312917f,
-    0.0740343034f, 0.0762391835f, 0.0783408359f, 0.0803356841f, 0.0822216198f, 0.0839978829f,
-    0.0856649131f, 0.0872242227f, 0.0886782259f, 0.0900300965f, 0.0912836194f, 0.0924430266f,
-    0.0935129076f, 0.0944980606f, 0.0954034105f, 0.0962339118f, 0.0969944894f, 0.0976899713f,
-    0.0983250439f, 0.0989042148f, 0.0994317904f, 0.0999118686f, 0.100348294f, 0.100744702f,
-    0.000681870733f, 0.000678163779f, 0.000670830079f, 0.00066002633f, 0.000645978784f, 0.000628973241f,
-    0.000609343173f, 0.000587456394f, 0.000563701382f, 0.000538474007f, 0.000512165076f, 0.000485149998f,
-    0.000457779883f, 0.000430374843f, 0.00040321963f, 0.000376560987f, 0.000350606831f, 0.000325526897f,
-    0.000301454653f, 0.000278489752f, 0.000256701489f, 0.000236132168f, 0.00021680085f, 0.000198706926f,
-    0.000181833602f, 0.000166151018f, 0.000151619155f, 0.000138190415f, 0.000125811741f, 0.00011442657f,
-    0.000103976359f, 9.44018975e-05f, -3.10091991e-07f, -9.2353946e-07f, -1.5170865e-06f, -2.07847256e-06f,
-    -2.59686453e-06f, -3.06327524e-06f, -3.47084733e-06f, -3.81499649e-06f, -4.09341146e-06f, -4.30592809e-06f,
-    -4.45430442e-06f, -4.54192104e-06f, -4.57343867e-06f, -4.5544466e-06f, -4.49111849e-06f, -4.38990128e-06f,
-    -4.25724784e-06f, -4.09939685e-06f, -3.92220591e-06f, -3.73103489e-06f, -3.53067253e-06f, -3.32530203e-06f,
-    -3.11849635e-06f, -2.91323863e-06f, -2.71195813e-06f, -2.51657821e-06f, -2.32856996e-06f, -2.14900979e-06f,
-    -1.97863346e-06f, -1.81789073e-06f, -1.66699499e-06f, -1.52596692e-06f, 0.0395287387f, 0.123166457f,
-    0.213005647f, 0.309125036f, 0.411563545f, 0.520320535f, 0.635356963f, 0.756597757f,
-    0.883934677f, 1.01722944f, 1.15631783f, 1.30101407f, 1.45111418f, 1.60640061f,
-    1.76664603f, 1.93161643f, 2.10107493f, 2.27478409f, 2.45250845f, 2.63401699f,
-    2.81908441f, 3.00749183f, 3.19902921f, 3.39349484f, 3.59069681f, 3.790452f,
-    3.99258733f, 4.19693995f, 4.4033556f, 4.61168957f, 4.82180643f, 5.03357935f,
-    0.0402865335f, 0.0433610156f, 0.0464847423f, 0.0496378988f, 0.0528005436f, 0.055953145f,
-    0.059077017f, 0.0621547587f, 0.0651705638f, 0.068110466f, 0.0709624812f, 0.0737167001f,
-    0.0763652474f, 0.0789022371f, 0.0813236162f, 0.0836270303f, 0.0858116299f, 0.0878778696f,
-    0.0898273215f, 0.091662474f, 0.0933865607f, 0.0950033888f, 0.0965171903f, 0.0979325101f,
-    0.0992540643f, 0.100486681f, 0.101635203f, 0.102704428f, 0.103699051f, 0.104623668f,
-    0.105482683f, 0.106280334f, 0.00076074939f, 0.000775490596f, 0.000785338576f, 0.000790198392f,
-    0.000790105667f, 0.000785219541f, 0.000775809516f, 0.000762237469f, 0.000744936522f, 0.00072438881f,
-    0.000701103534f, 0.000675596471f, 0.000648372574f, 0.000619911356f, 0.000590656302f, 0.00056100724f,
-    0.000531316269f, 0.000501885894f, 0.000472969958f, 0.000444775535f, 0.000417466654f, 0.000391168258f,
-    0.000365970744f, 0.000341934705f, 0.000319095183f, 0.000297466147f, 0.000277044106f, 0.0002578118f,
-    0.000239740984f, 0.000222795279f, 0.000206932193f, 0.000192105043f, 2.85429064e-06f, 2.05379683e-06f,
-    1.22649419e-06f, 3.94353407e-07f, -4.2125194e-07f, -1.20067079e-06f, -1.92689845e-06f, -2.58623254e-06f,
-    -3.16863543e-06f, -3.66780728e-06f, -4.08100732e-06f, -4.40867916e-06f, -4.65394305e-06f, -4.82202267e-06f,
-    -4.91965784e-06f, -4.95455151e-06f, -4.93488278e-06f, -4.86889667e-06f, -4.76458672e-06f, -4.62946218e-06f,
-    -4.47038792e-06f, -4.29349984e-06f, -4.10416487e-06f, -3.90698779e-06f, -3.70584439e-06f, -3.50393452e-06f,
-    -3.30384864e-06f, -3.10763653e-06f, -2.91687957e-06f, -2.73275714e-06f, -2.55611189e-06f, -2.38750613e-06f};
-#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
-static __shared__ float s_psitab32[384];
-// fp32 kernels: all threads of a block of 256, before the block's first barrier
-__device__ __forceinline__ void psi_tables_fill32()
-{
-    for (int t = (int)threadIdx.x; t < 384; t += (int)blockDim.x) s_psitab32[t] = kPsiTab32[t];
-}
-template <int WHICH> __device__ __forceinline__ float psi_tab_coef32(int k, int i) { return s_psitab32[WHICH * 128 + k * 32 + i]; }
-#else
-template <int WHICH> inline float psi_tab_coef32(int k, int i) { return kPsiTab32[WHICH * 128 + k * 32 + i]; }
-#endif
-// WHICH: 0 psi_m, 1 psi_h (Kansas / Paulson, x32 = 32 s / 6.6875), 2 convective psi (x32 = 32 L / 7.4453125); 0 <= x32 < 32
-template <int WHICH> __device__ __forceinline__ float psi_tab_eval32(float x32)
-{
-    const float fi = __builtin_floorf(x32);
-    const int i = (int)fi;
-    const float u = __builtin_fmaf(x32 - fi, 2.f, -1.f);
-    float p = psi_tab_coef32<WHICH>(3, i);
-#pragma unroll
-    for (int k = 2; k >= 0; --k) p = __builtin_fmaf(p, u, psi_tab_coef32<WHICH>(k, i));
-    return p;
-}
 // ---------------------------------------------------------------- COARE stability functions (mod_common_coare.f90)
 // Convective ("free convection") profile function of COARE, mod_common_coare.f90:240-243 (psi_m) and :330-333 (psi_h):
 //    c = y**.3333 ,  psi_c = 1.5 LOG((1+c+c*c)/3) - 1.7320508 ATAN((1+2c)/1.7320508) + 1.813799447     (y = |1 - a zeta| >= 1)
@@ -731,7 +780,7 @@ template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R psic_
     using M = Mth<R>;
     const R L = M::log(y);
     if constexpr (sizeof(R) == 8 && TAB) {
-        if (L < R(kPsiTabLMax)) return R(psi_tab_eval<1>((double)R(L * R(32. / kPsiTabLMax))));
+        if (L < R(kPsiTabLMax)) return R(psi_tab_eval<kTabPsic>((double)R(L * R(28. / kPsiTabLMax))));
     }
     if constexpr (sizeof(R) == 4 && TAB) {
         if (L < R(kPsiTabLMax)) return R(psi_tab_eval32<2>((float)(L * R(32. / kPsiTabLMax))));
@@ -775,7 +824,7 @@ template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ void ps
     if (pm && sizeof(R) == 8) {   // fp64 only: fp32 square roots, logs and atan are hardware instructions
         const R sl = M::log(y);
         if (sl <= R(6.68586094706836)) {
-            if constexpr (sizeof(R) == 8 && TAB) *pm = R(psi_tab_eval<0>((double)R(sl * R(32. / kPsiTabSMax))));   // psi_m: LDS table
+            if constexpr (sizeof(R) == 8 && TAB) *pm = R(psi_tab_eval<kTabPsikM>((double)R(sl * R(28. / kPsiTabSMax))));   // psi_m: LDS table
             else *pm = horner_tab<23, fm::kC_PsikM21>(kPsikM, sl * R(2. / 6.68586094706836) - R(1.));
             if (ph) *ph = horner_tab<23, fm::kC_PsikH21>(kPsikH, sl * R(2. / 6.68586094706836) - R(1.));
             return;

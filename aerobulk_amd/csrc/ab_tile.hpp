@@ -40,8 +40,6 @@ template <class R> __device__ __forceinline__ Heights<R> detached(const Heights<
 }     // 4 stability bins x 4 warm-layer bins
 template <class R, int ALGO, bool SKIN> struct Tile {
     static constexpr int kFields = SKIN ? 8 : 6;                       // flux: sst theta q_zt u v slp [qsw rlw] ; turb: 8 / 6 too
-    // kWaves blocks per CU (one wave of each per SIMD) share 160 KB of LDS: fields + index (2 B) per cell (budgeted with 3 B: the
-    // byte the former sort kept per cell is headroom now)
     // Waves per SIMD (= resident blocks per CU) a kernel is built for.  The fp64 kernels with the skin schemes need 107-127 VGPRs:
     // four.  Without them 72-95 VGPRs: five, on two-round tiles (-3...-4 % COARE, -1 % ECMWF; config 2 -3 %).  The fp32 kernels,
     // at 36-69 VGPRs once their psi functions come from the LDS tables: seven with the skin schemes (ECMWF: six), eight without,
@@ -58,17 +56,21 @@ template <class R, int ALGO, bool SKIN> struct Tile {
 #ifndef AB_F32_NOSKIN_OCC
 #define AB_F32_NOSKIN_OCC 8
 #endif
-    // waves per SIMD the kernel is built for
     static constexpr int kOcc = sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : AB_NOSKIN_OCC)
                                                : (SKIN ? (ALGO == 4 ? AB_F32_ECMWF_OCC : AB_F32_OCC) : AB_F32_NOSKIN_OCC);
     static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
+    // The kWaves blocks of a CU share its 160 KB of LDS.  Per block, besides the tile (fields + a 2-byte index per cell): the sort's
+    // counters, the queue head and alignment (256 B), the tables of the fp64 log / exp and the constants (fm::s_logtab 1024 B,
+    // s_exptab 512 B, s_ctab 144 B: 1 792 B with alignment), and, in the translation units that define AB_PSI_LDS_TABLES, the
+    // piecewise psi / e_sat tables (ab_physics.hpp: 5 120 B in fp64 with the skin schemes, 3 584 B without, 1 536 B in fp32).  The fp64
+    // flux kernels with the skin schemes come out at exactly two rounds with 280 B to spare: nothing is left in LDS.
 #ifdef AB_PSI_LDS_TABLES
-    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? 4096 : 1536;   // s_psitab / s_psitab32 (ab_physics.hpp)
+    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? (SKIN ? 5120 : 3584) : 1536;   // (the e_sat table: kernels with the skin schemes only)
 #else
     static constexpr int kPsiTabBytes = 0;
 #endif
-    static constexpr int kBudget = (160 * 1024 - 2048) / kWaves - 256 - (sizeof(R) == 8 ? 1024 : 0) - kPsiTabBytes;   // fm::s_logtab (1024 B) + fm::s_exptab (512 B) + fm::s_ctab (104 B): 1024 here, the rest from the 2048 held back above
-    static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 3)); // f64: 2 (skin) / 3 ; f32: 4 / 5
+    static constexpr int kBudget = 160 * 1024 / kWaves - 256 - (sizeof(R) == 8 ? 1792 : 0) - kPsiTabBytes;
+    static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 2)); // f64: 2 (skin, 4 blocks) / 2 (5 blocks); f32: 2
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;
 };

@@ -246,7 +246,8 @@ int ab_synth_fields_device(void *sst, void *t_zt, void *q_zt, void *u_zu, void *
                            void *stream);
 
 /* Test hook: apply the engine's fp64 device math function `op` elementwise to host arrays (y may be NULL):
- * 0 div 1 rcp 2 sqrt 3 log 4 log10 5 exp 6 exp10 7 atan 8 cbrt 9 rcbrt 10 e_sat 11 pow 12 x^(-1/4).  tests/test_gpu_math.py */
+ * 0 div 1 rcp 2 sqrt 3 log 4 log10 5 exp 6 exp10 7 atan 8 cbrt 9 rcbrt 10 e_sat 11 pow 12 x^(-1/4) 13 e_sat through the
+ * piecewise LDS table of the tiled flux kernels.  tests/test_gpu_math.py */
 int ab_test_math(int op, const double *x, const double *y, double *out, long n);
 
 /* ---- the reference's own entry points --------------------------------------------------- */

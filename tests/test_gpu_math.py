@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-OPS = {"div": 0, "rcp": 1, "sqrt": 2, "log": 3, "log10": 4, "exp": 5, "exp10": 6, "atan": 7, "cbrt": 8, "rcbrt": 9, "e_sat": 10, "pow": 11, "rqrt": 12}
+OPS = {"div": 0, "rcp": 1, "sqrt": 2, "log": 3, "log10": 4, "exp": 5, "exp10": 6, "atan": 7, "cbrt": 8, "rcbrt": 9, "e_sat": 10, "pow": 11, "rqrt": 12, "e_sat_tab": 13}
 
 
 def run(op, x, y=None):
@@ -86,4 +86,12 @@ def test_e_sat_matches_oracle(oracle):
     rel = np.abs(got - want) / want
     print("e_sat max rel err vs oracle", rel.max(), "at T =", t[np.argmax(rel)])
     # both sides carry ~1e-15 of rounding in the exponent (A ~ 0.3..2, times ln 10)
+    assert rel.max() < 6e-15
+    # the same through the piecewise LDS table of the tiled flux kernels (265 K <= T < 312 K; the formula path elsewhere): the table
+    # itself is good to 1e-16, what is left is the oracle's own rounding
+    tt = np.concatenate([t, [265.0, np.nextafter(312.0, 0.0), 312.0, np.nextafter(265.0, 0.0)], RNG.uniform(265.0, 312.0, 200000)])
+    got = run("e_sat_tab", tt)
+    want = np.array([oracle.lib().abo_e_sat(v) for v in tt])
+    rel = np.abs(got - want) / want
+    print("e_sat (table) max rel err vs oracle", rel.max(), "at T =", tt[np.argmax(rel)])
     assert rel.max() < 6e-15

@@ -3,18 +3,23 @@
 
     F_M(s) = psi_m of Kansas / Paulson as a function of s = LOG(y), y = |1 - a zeta|   (tools/gen_poly.py section 6),  0 <= s < 6.6875
     F_C(L) = COARE's convective psi as a function of L = LOG(y)                          (tools/gen_poly.py section 7),  0 <= L < 7.4453125
-Both are analytic with the nearest singularities at +-2 pi i.  The range is cut into 32 equal intervals; on each the function is
-replaced by its degree-7 Chebyshev interpolant (60-digit arithmetic), stored as monomial coefficients in the local variable
-u in [-1, 1).  Half-width 0.105 / 0.116 against a distance of 2 pi: the interpolation error is below 1e-16 absolute.
-Layout: coefficient-major, tab[k * 32 + i] = coefficient of u^k on interval i: the 64 lanes of a wave read one k at a time, lanes
-on different intervals hit different LDS banks (32 intervals x 8 B = the 64 banks), lanes on the same interval the same address.
+    E(T)   = e_sat_sclr of the reference (Goff 1957; mod_phymbl.f90:792-798) in Pa,                                          265 <= T < 312 K
+The psi functions are analytic with the nearest singularities at +-2 pi i.  Each range is cut into equal intervals (28 / 28 / 24);
+on each the function is replaced by its degree-7 Chebyshev interpolant (60-digit arithmetic), stored as monomial coefficients in
+the local variable u in [-1, 1).  Half-width 0.12 / 0.13 against a distance of 2 pi: the interpolation error is below 1e-16
+absolute; e_sat: 8.8e-17 relative (the rounding of the coefficients).
+Layout: coefficient-major, tab[k * nint + i] = coefficient of u^k on interval i: the 64 lanes of a wave read one k at a time, lanes
+on different intervals hit different LDS banks (8 B per interval, at most 32 intervals = the 64 banks), lanes on the same interval
+the same address.  The fp32 tables (psi_m, psi_h, convective psi): 32 intervals, degree 3.
 Prints the C initialisers and the measured error.
 """
 import mpmath as mp
 import numpy as np
 
 mp.mp.dps = 60
-NINT, DEG = 32, 7
+DEG = 7
+NINT = 32                 # fp32 tables
+NINT_PSI, NINT_ESAT = 28, 24   # fp64 tables: intervals per function
 RPI = mp.mpf(float("3.141592653589793"))      # rpi of the reference (mod_const.f90:39), as the double it is
 S3 = mp.mpf("1.7320508")
 # table ranges: just beyond LOG(1 + 16*50) = 6.68586 and LOG(1 + 34.15*50) = 7.44337 (the callers clamp zeta at -50: a clamped cell
@@ -50,10 +55,22 @@ def local_fit(f, a, b, deg=None):
     return [float(c[j]) for j in range(n)]
 
 
-def table(f, xmax, deg=None):
+T0 = mp.mpf("273.15")
+
+
+def e_sat(T):
+    """e_sat_sclr of the reference (src/mod_phymbl.f90:792-798), Goff 1957, in Pa"""
+    z, x = T0 / T, T / T0
+    A = (mp.mpf("10.79574") * (1 - z) - mp.mpf("5.028") * mp.log10(x) + mp.mpf("1.50475e-4") * (1 - mp.power(10, mp.mpf("-8.2969") * (x - 1)))
+         + mp.mpf("0.42873e-3") * (mp.power(10, mp.mpf("4.76955") * (1 - z)) - 1) + mp.mpf("0.78614"))
+    return 100 * mp.power(10, A)
+
+
+def table(f, xmax, deg=None, nint=None, x0=0, rel=False):
+    nint = NINT if nint is None else nint
     rows, worst = [], mp.mpf(0)
-    for i in range(NINT):
-        a, b = xmax * i / NINT, xmax * (i + 1) / NINT
+    for i in range(nint):
+        a, b = x0 + (xmax - x0) * mp.mpf(i) / nint, x0 + (xmax - x0) * mp.mpf(i + 1) / nint
         c = local_fit(f, a, b, deg)
         rows.append(c)
         for k in range(41):
@@ -61,24 +78,28 @@ def table(f, xmax, deg=None):
             p = mp.mpf(0)
             for cc in reversed(c):
                 p = p * u + mp.mpf(cc)
-            worst = max(worst, abs(p - f((a + b) / 2 + (b - a) / 2 * u)))
+            fx = f((a + b) / 2 + (b - a) / 2 * u)
+            worst = max(worst, abs(p - fx) / (abs(fx) if rel else 1))
     return rows, float(worst)
 
 
 def emit(name, rows, err, what):
-    print(f"// {what}: max |table - function| = {err:.2e}")
-    print(f"AB_TAB double {name}[{(DEG + 1) * NINT}] = {{")
-    flat = [rows[i][k] for k in range(DEG + 1) for i in range(NINT)]
+    nint = len(rows)
+    print(f"// {what}: {nint} intervals, max |table - function| = {err:.2e}")
+    print(f"AB_TAB double {name}[{(DEG + 1) * nint}] = {{")
+    flat = [rows[i][k] for k in range(DEG + 1) for i in range(nint)]
     for j in range(0, len(flat), 4):
         print("    " + ", ".join(repr(v) for v in flat[j:j + 4]) + ("," if j + 4 < len(flat) else "};"))
 
 
 def main():
-    print(f"// SMAX = {float(SMAX)!r}, LMAX = {float(LMAX)!r}, {NINT} intervals, degree {DEG}")
-    rows, err = table(psik_m, SMAX)
+    print(f"// SMAX = {float(SMAX)!r}, LMAX = {float(LMAX)!r}, degree {DEG}")
+    rows, err = table(psik_m, SMAX, nint=NINT_PSI)
     emit("kPsiTabM", rows, err, "psi_m (Kansas / Paulson) in s = LOG(y)")
-    rows, err = table(psic_L, LMAX)
+    rows, err = table(psic_L, LMAX, nint=NINT_PSI)
     emit("kPsiTabC", rows, err, "COARE convective psi in L = LOG(y)")
+    rows, err = table(e_sat, mp.mpf(312), nint=NINT_ESAT, x0=mp.mpf(265), rel=True)
+    emit("kEsatTab", rows, err, "e_sat(T) [Pa] on 265 K <= T < 312 K, RELATIVE error")
     # fp32 kernels: degree 3 on the same intervals (5e-9 of interpolation error), float entries: psi_m, psi_h, convective psi
     flat, errs = [], []
     for f, xmax in ((psik_m, SMAX), (psik_h, SMAX), (psic_L, LMAX)):
