@@ -69,14 +69,15 @@ template <class R> struct K {  // constants, mod_const.f90:38-114
 //                             + 0.42873e-3 (10^(4.76955(1-T0/T)) - 1) + 0.78614
 // The formula is evaluated 13x per cell in the skin configuration (3 exp10 + log10 + a division each time), always at
 // sea-surface-like temperatures.  On 265 K <= T <= 312 K the exponent A(T) is therefore taken from its degree-14
-// near-minimax polynomial in x = (T-288.5)/23.5 (60-digit Chebyshev fit of the formula above, tools/gen_poly.py;
-// |dA| <= 9.2e-17, i.e. below the rounding of the direct evaluation); outside that range (polar air, masked cells)
-// the formula itself is evaluated.
-AB_TAB double kGoffA[fm::ab_pad4(15)] = {1.2415921763001385, 0.6554537644583072, -0.06042150514551698, 0.0052061867921480934,
-                                  -0.0004389902243182716, 4.0181440214509234e-05, -4.299303765658193e-06,
-                                  5.668664093041563e-07, -8.717077199072555e-08, 1.3977187155429886e-08,
-                                  -2.167668513463531e-09, 3.147964597951566e-10, -4.254827005592513e-11,
-                                  5.6079820609247194e-12, -6.519141017660851e-13};
+// near-minimax polynomial in x = (T-288.5)/23.5 (60-digit Chebyshev fit of the formula above WITH ITS LITERALS AS THE DOUBLES THEY
+// ARE AT RUN TIME — rt0 = 273.15 is 2.3e-14 below 273.15, seven ulp of e_sat: the first fit used the decimal values and sat
+// 1.3e-15 below the reference — tools/gen_poly.py; |dA| <= 9.2e-17, i.e. below the rounding of the direct evaluation); outside
+// that range (polar air, masked cells) the formula itself is evaluated.
+AB_TAB double kGoffA[fm::ab_pad4(15)] = {
+    1.2415921763001392, 0.6554537644583072, -0.060421505145516974, 0.005206186792148093,
+    -0.00043899022431827153, 4.018144021450923e-05, -4.2993037656581925e-06, 5.668664093041562e-07,
+    -8.717077199072552e-08, 1.3977187155429884e-08, -2.167668513463531e-09, 3.1479645979515667e-10,
+    -4.254827005592515e-11, 5.607982060924723e-12, -6.519141017660857e-13};
 __device__ __forceinline__ double goff_poly(double x)
 {
     return fm::horner_coefs<15, fm::kC_Goff13>(kGoffA, x);
@@ -85,9 +86,7 @@ __device__ __forceinline__ float goff_poly(float x)
 {
     // fp32: the first 9 terms leave < 2e-8 in A; the coefficients as float LITERALS (read from the fp64 table each of them cost a
     // v_cvt_f32_f64, a full issue slot, i.e. more than the polynomial's own FMAs)
-    constexpr float c[9] = {1.2415921763001385f, 0.6554537644583072f, -0.06042150514551698f, 0.0052061867921480934f,
-                            -0.0004389902243182716f, 4.0181440214509234e-05f, -4.299303765658193e-06f, 5.668664093041563e-07f,
-                            -8.717077199072555e-08f};
+    constexpr float c[9] = {1.2415921763001392f, 0.6554537644583072f, -0.060421505145516974f, 0.005206186792148093f, -0.00043899022431827153f, 4.018144021450923e-05f, -4.2993037656581925e-06f, 5.668664093041562e-07f, -8.717077199072552e-08f};
     float p = c[8];
 #pragma unroll
     for (int i = 7; i >= 0; --i) p = __builtin_fmaf(p, x, c[i]);
@@ -230,56 +229,56 @@ AB_TAB double kPsiTabC[224] = {
     1.3095994457039944e-13, 1.446353058102738e-13, 1.466787304650988e-13, 1.4052952720324492e-13,
     1.2913291761216073e-13, 1.1484012642507805e-13, 9.94124486272133e-14, 8.408555406772081e-14,
     6.966118885884548e-14, 5.6604317094079784e-14, 4.513279603485118e-14, 3.529332826378247e-14};
-// e_sat(T) [Pa] on 265 K <= T < 312 K, RELATIVE error: 24 intervals, max |table - function| = 8.78e-17
+// e_sat(T) [Pa] on 265 K <= T < 312 K, RELATIVE error: 24 intervals, max |table - function| = 7.82e-17
 AB_TAB double kEsatTab[192] = {
-    357.2473193130473, 414.99422650940124, 480.89879968552964, 555.9404053510848,
-    641.193756944363, 737.8357614239685, 847.1526368401525, 970.5472954120968,
-    1109.546985510079, 1265.8111848316844, 1441.139735976542, 1637.4812145717008,
-    1856.9415190867264, 2101.7926705105347, 2374.4818091471448, 2677.6403749307447,
-    3014.093456867087, 3386.8692964830925, 3799.208929513944, 4254.575949480656,
-    4756.666376314284, 5309.418612768136, 5917.023471028621, 6583.934251690093,
-    26.986008246361397, 30.83506241256419, 35.15106987493428, 39.98003818371885,
-    45.37132966983021, 51.377798113790305, 58.055922961622855, 65.46594052089891,
-    73.67197157702778, 82.742144880563, 92.74871597066488, 103.76818081780259,
-    115.88138379013216, 129.17361947257095, 143.73472789519766, 159.65918275801153,
-    177.04617227203855, 195.99967227201748, 216.62851129315396, 239.04642734342102,
-    263.3721161433104, 289.72927064651367, 318.24661169743365, 349.0579097244075,
-    0.907525583565605, 1.0187838881623963, 1.1411362466431223, 1.2754041017436164,
-    1.4224433225964472, 1.5831436626506878, 1.758428075352492, 1.9492518888283727,
-    2.1566018417699566, 2.3814949836560606, 2.6249774433571615, 2.8881230710411536,
-    3.172031959130745, 3.4778288488456357, 3.806661429590969, 4.1596985391226085,
-    4.5381282730252055, 4.94315601257733, 5.376002380546362, 5.83790113485231,
-    6.330097010363011, 6.8538435193325125, 7.4104007211700855, 8.00103297232984,
-    0.017662733441308524, 0.019445219272153237, 0.021361719184827543, 0.023418008163795714,
-    0.02561978272878074, 0.0279726371784461, 0.03048203996056908, 0.03315331032937133,
-    0.035991595448065884, 0.039001848090695304, 0.04218880509204964, 0.04555696668795754,
-    0.04911057688063653, 0.052853604955179975, 0.056789728263760005, 0.060922316383859206,
-    0.06525441674592955, 0.06978874181443896, 0.07452765789442758, 0.07947317562357822,
-    0.08462694219752889, 0.08999023536383384, 0.0955639592077234, 0.10134864174072697,
-    0.00021467733159965372, 0.00023106562811270342, 0.00024817971197498424, 0.00026601126007818373,
-    0.0002845489786084486, 0.0003037786087524401, 0.0003236829525898746, 0.0003442419189358377,
-    0.00036543258871942635, 0.00038722929931755414, 0.0004096037471055955, 0.00043252510734128604,
-    0.00045596017036606467, 0.00047987349298974274, 0.0005042275638207016, 0.0005289829812152407,
-    0.0005540986424464857, 0.0005795319426355102, 0.0006052389819449223, 0.0006311747795078368,
-    0.0006572934925524941, 0.0006835486391842012, 0.0007098933233011101, 0.0007362804601477862,
-    1.602336891035799e-06, 1.6752330203033473e-06, 1.7474450578751448e-06, 1.8186763230346066e-06,
-    1.8886296930256124e-06, 1.957009627454928e-06, 2.023524178117305e-06, 2.0878869661764966e-06,
-    2.1498191094520063e-06, 2.2090510835434227e-06, 2.2653245016509664e-06, 2.318393799200849e-06,
-    2.3680278107354875e-06, 2.41401122795973e-06, 2.4561459293236684e-06, 2.4942521730494786e-06,
-    2.5281696470542003e-06, 2.557758370763515e-06, 2.5828994453359132e-06, 2.603495650305908e-06,
-    2.6194718860945453e-06, 2.6307754632123036e-06, 2.6373762402821345e-06, 2.6392666142291488e-06,
-    6.0947654464108995e-09, 6.050062482498647e-09, 5.9807122686975955e-09, 5.886593610941404e-09,
-    5.767754092812698e-09, 5.624409632847216e-09, 5.456942507409448e-09, 5.265897899720514e-09,
-    5.051979050248024e-09, 4.816041096603773e-09, 4.5590837022653705e-09, 4.282242582801332e-09,
-    3.98678004582405e-09, 3.6740746666373754e-09, 3.345610225525678e-09, 3.0029640349119706e-09,
-    2.647794785275628e-09, 2.281830037863602e-09, 1.9068534899643302e-09, 1.5246921349629106e-09,
-    1.1372034346896617e-09, 7.462626158472491e-10, 3.537501956924897e-10, -3.846016520331592e-11,
-    -2.3186442213180708e-12, -4.070853390546014e-12, -5.837729791075412e-12, -7.607239227392809e-12,
-    -9.367323170999561e-12, -1.1106010151343443e-11, -1.2811523380341068e-11, -1.4472383507402099e-11,
-    -1.6077505519413973e-11, -1.7616288924063598e-11, -1.9078700482838034e-11, -2.045534888986772e-11,
-    -2.173755092241504e-11, -2.2917388716405885e-11, -2.3987757944278737e-11, -2.4942406791111382e-11,
-    -2.5775965737211713e-11, -2.6483968260063418e-11, -2.706286266484236e-11, -2.7510015340004322e-11,
-    -2.7823705812219213e-11, -2.8003114042898774e-11, -2.804830046660785e-11, -2.7960179319789003e-11};
+    357.24731931304785, 414.99422650940187, 480.8987996855304, 555.9404053510857,
+    641.1937569443639, 737.8357614239696, 847.1526368401537, 970.5472954120983,
+    1109.5469855100807, 1265.8111848316862, 1441.139735976544, 1637.4812145717033,
+    1856.9415190867292, 2101.792670510538, 2374.4818091471484, 2677.6403749307483,
+    3014.0934568670914, 3386.8692964830975, 3799.2089295139494, 4254.5759494806625,
+    4756.6663763142915, 5309.418612768144, 5917.02347102863, 6583.934251690103,
+    26.98600824636144, 30.83506241256424, 35.15106987493433, 39.98003818371891,
+    45.37132966983028, 51.37779811379038, 58.05592296162294, 65.465940520899,
+    73.67197157702789, 82.74214488056312, 92.74871597066502, 103.76818081780274,
+    115.88138379013232, 129.17361947257112, 143.7347278951979, 159.65918275801175,
+    177.0461722720388, 195.99967227201776, 216.62851129315428, 239.04642734342136,
+    263.3721161433108, 289.72927064651407, 318.24661169743405, 349.05790972440803,
+    0.9075255835656063, 1.0187838881623978, 1.1411362466431239, 1.2754041017436184,
+    1.4224433225964495, 1.58314366265069, 1.7584280753524943, 1.9492518888283756,
+    2.1566018417699597, 2.3814949836560637, 2.6249774433571655, 2.8881230710411576,
+    3.1720319591307495, 3.4778288488456406, 3.8066614295909744, 4.159698539122614,
+    4.538128273025212, 4.9431560125773375, 5.376002380546369, 5.837901134852318,
+    6.33009701036302, 6.853843519332522, 7.410400721170095, 8.001032972329853,
+    0.01766273344130855, 0.019445219272153265, 0.021361719184827575, 0.023418008163795745,
+    0.02561978272878078, 0.027972637178446138, 0.030482039960569127, 0.033153310329371376,
+    0.03599159544806593, 0.03900184809069535, 0.042188805092049704, 0.0455569666879576,
+    0.049110576880636594, 0.052853604955180045, 0.05678972826376008, 0.06092231638385929,
+    0.06525441674592963, 0.06978874181443905, 0.07452765789442768, 0.07947317562357832,
+    0.084626942197529, 0.08999023536383395, 0.09556395920772352, 0.1013486417407271,
+    0.00021467733159965402, 0.00023106562811270372, 0.00024817971197498457, 0.00026601126007818406,
+    0.00028454897860844897, 0.0003037786087524405, 0.00032368295258987503, 0.00034424191893583814,
+    0.0003654325887194268, 0.00038722929931755463, 0.00040960374710559606, 0.0004325251073412866,
+    0.00045596017036606527, 0.00047987349298974334, 0.0005042275638207023, 0.0005289829812152414,
+    0.0005540986424464864, 0.000579531942635511, 0.0006052389819449231, 0.0006311747795078377,
+    0.0006572934925524949, 0.000683548639184202, 0.000709893323301111, 0.000736280460147787,
+    1.602336891035801e-06, 1.6752330203033494e-06, 1.7474450578751469e-06, 1.8186763230346087e-06,
+    1.8886296930256147e-06, 1.9570096274549308e-06, 2.0235241781173077e-06, 2.087886966176499e-06,
+    2.149819109452009e-06, 2.2090510835434253e-06, 2.265324501650969e-06, 2.318393799200852e-06,
+    2.3680278107354905e-06, 2.414011227959733e-06, 2.4561459293236713e-06, 2.4942521730494816e-06,
+    2.5281696470542032e-06, 2.557758370763518e-06, 2.582899445335916e-06, 2.603495650305911e-06,
+    2.6194718860945483e-06, 2.6307754632123066e-06, 2.6373762402821375e-06, 2.6392666142291517e-06,
+    6.094765446410906e-09, 6.050062482498653e-09, 5.980712268697602e-09, 5.88659361094141e-09,
+    5.767754092812704e-09, 5.624409632847222e-09, 5.456942507409454e-09, 5.265897899720519e-09,
+    5.051979050248029e-09, 4.816041096603777e-09, 4.5590837022653754e-09, 4.282242582801336e-09,
+    3.986780045824054e-09, 3.6740746666373787e-09, 3.3456102255256808e-09, 3.002964034911973e-09,
+    2.64779478527563e-09, 2.2818300378636038e-09, 1.906853489964331e-09, 1.5246921349629112e-09,
+    1.137203434689662e-09, 7.462626158472489e-10, 3.5375019569248907e-10, -3.8460165203316975e-11,
+    -2.318644221318079e-12, -4.070853390546024e-12, -5.837729791075424e-12, -7.607239227392822e-12,
+    -9.367323170999578e-12, -1.110601015134346e-11, -1.2811523380341088e-11, -1.447238350740212e-11,
+    -1.6077505519413996e-11, -1.761628892406362e-11, -1.907870048283806e-11, -2.0455348889867745e-11,
+    -2.1737550922415065e-11, -2.2917388716405914e-11, -2.3987757944278766e-11, -2.494240679111141e-11,
+    -2.5775965737211742e-11, -2.6483968260063447e-11, -2.706286266484239e-11, -2.7510015340004354e-11,
+    -2.7823705812219242e-11, -2.8003114042898803e-11, -2.804830046660788e-11, -2.7960179319789032e-11};
 constexpr double kPsiTabSMax = 6.6875, kPsiTabLMax = 7.4453125, kEsatTabT0 = 265., kEsatTabT1 = 312.;
 constexpr int kTabPsikM = 0, kTabPsic = 1, kTabEsat = 2;
 constexpr int kTabNint[3] = {28, 28, 24}, kTabOff[3] = {0, 224, 448}, kTabTotal = 640;

@@ -91,14 +91,20 @@ for name, v in (("ln2", ln2), ("log10_2", ln2 / mp.log(10))):
 
 # 4) Goff (1957) exponent A(T) of e_sat = 100*10^A(T) (reference: src/mod_phymbl.f90:792-798) on T in [265, 312] K,
 #    x = (T - 288.5)/23.5 in [-1, 1]: polynomial surrogate of the SAME analytic function (3 exp10 + log10 + division -> 14 FMAs)
-T0 = mp.mpf("273.15")
+def D(x):
+    """a literal of the reference as the double it is at run time (rt0 = 273.15 is 2.3e-14 below 273.15, which is seven ulp of e_sat:
+    the round-1 fit used the decimal values and sat 1.3e-15 below the reference, profiles/r2_notes.md)"""
+    return mp.mpf(float(x))
+
+
+T0 = D(273.15)
 
 
 def goff_A(T):
     z, x = T0 / T, T / T0
-    return (mp.mpf("10.79574") * (1 - z) - mp.mpf("5.028") * mp.log10(x)
-            + mp.mpf("1.50475e-4") * (1 - mp.power(10, mp.mpf("-8.2969") * (x - 1)))
-            + mp.mpf("0.42873e-3") * (mp.power(10, mp.mpf("4.76955") * (1 - z)) - 1) + mp.mpf("0.78614"))
+    return (D(10.79574) * (1 - z) - D(5.028) * mp.log10(x)
+            + D(1.50475) * mp.mpf(10) ** -4 * (1 - mp.power(10, D(-8.2969) * (x - 1)))
+            + D(0.42873) * mp.mpf(10) ** -3 * (mp.power(10, D(4.76955) * (1 - z)) - 1) + D(0.78614))
 
 
 for deg in (13, 14, 15):

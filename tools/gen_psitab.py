@@ -55,14 +55,19 @@ def local_fit(f, a, b, deg=None):
     return [float(c[j]) for j in range(n)]
 
 
-T0 = mp.mpf("273.15")
+def D(x):
+    """a literal of the reference as the double it is at run time (rt0 = 273.15 is 2.3e-14 below 273.15: seven ulp of e_sat)"""
+    return mp.mpf(float(x))
+
+
+T0 = D(273.15)
 
 
 def e_sat(T):
-    """e_sat_sclr of the reference (src/mod_phymbl.f90:792-798), Goff 1957, in Pa"""
+    """e_sat_sclr of the reference (src/mod_phymbl.f90:792-798), Goff 1957, in Pa, with its literals as doubles"""
     z, x = T0 / T, T / T0
-    A = (mp.mpf("10.79574") * (1 - z) - mp.mpf("5.028") * mp.log10(x) + mp.mpf("1.50475e-4") * (1 - mp.power(10, mp.mpf("-8.2969") * (x - 1)))
-         + mp.mpf("0.42873e-3") * (mp.power(10, mp.mpf("4.76955") * (1 - z)) - 1) + mp.mpf("0.78614"))
+    A = (D(10.79574) * (1 - z) - D(5.028) * mp.log10(x) + D(1.50475) * mp.mpf(10) ** -4 * (1 - mp.power(10, D(-8.2969) * (x - 1)))
+         + D(0.42873) * mp.mpf(10) ** -3 * (mp.power(10, D(4.76955) * (1 - z)) - 1) + D(0.78614))
     return 100 * mp.power(10, A)
 
 

@@ -6,12 +6,14 @@ flux differs from the oracle's by more than 1e-10 relative (floor 1e-6 of the fi
 Each such cell is put through
   * the UNMODIFIED reference compiled with the flag sets of its own arch/ files (oracle/Makefile `refvariants`):
     -O0, -O2 (the pinned build), -O3, "-xHOST -O3" on an FMA host (contraction), the same with reassociation;
-  * the pinned reference build with every input moved by +-1 ulp (and +-4 ulp) in turn;
+  * the pinned reference build with every input moved by +-1 ulp (and +-2, +-4, +-8 ulp) in turn;
   * the C oracle with every input moved by +-1 ulp in turn, and the oracle compiled with FMA contraction.
-"Reference spread" of a value: S_ref = max |x - x_O2| over the reference builds and the +-1 ulp runs (S_ref4: +-4 ulp runs as well):
+"Reference spread" of a value: S_ref = max |x - x_O2| over the reference builds and the +-1 ulp runs (S_ref4 / S_ref8: the runs with
+moves of up to 4 / 8 ulp as well):
 what the reference itself leaves undefined.  Output: tests/golden/illcond_cells.npz (inputs, reference O2 values, spreads, the HIP
 error measured when the fixture was made) and a text report (profiles/r2_illcond_study.txt).  The GPU tests then demand of every
-fixture value |HIP - ref_O2| <= max(1e-10 bar, S_ref4), and of every other cell they meet the rule of oracle/parity.py.
+fixture value |HIP - ref_O2| <= max(1e-10 bar, S_ref8) — the backward clause of oracle/parity.py, evaluated on the reference itself —
+and of every other cell they meet that rule with the oracle's response.
 
     python tools/illcond_study.py gpurun_out/outliers_r2.npz [--write]
 """
@@ -94,18 +96,24 @@ def main():
         spread_orc = np.abs(oracle_records(algo, skin, zt, zu, niter, nt, f, variant="fma") - orc)
         spread_ulp = np.zeros_like(base)
         spread_ulp4 = np.zeros_like(base)
+        spread_ulp8 = np.zeros_like(base)
         for k in IN8[: (8 if skin else 6)]:
             for sgn in (+1, -1):
                 g = dict(f)
                 g[k] = np.nextafter(f[k], sgn * np.inf)
                 spread_orc = np.maximum(spread_orc, np.abs(oracle_records(algo, skin, zt, zu, niter, nt, g) - orc))
                 spread_ulp = np.maximum(spread_ulp, np.abs(reference_records(algo, skin, zt, zu, niter, nt, g) - base))
-                g4 = dict(f)
-                g4[k] = f[k] + sgn * 4 * np.abs(np.nextafter(f[k], np.inf) - f[k])
-                spread_ulp4 = np.maximum(spread_ulp4, np.abs(reference_records(algo, skin, zt, zu, niter, nt, g4) - base))
+                for ulps in (2, 4, 8):
+                    gk = dict(f)
+                    gk[k] = f[k] + sgn * ulps * np.abs(np.nextafter(f[k], np.inf) - f[k])
+                    mv = np.abs(reference_records(algo, skin, zt, zu, niter, nt, gk) - base)
+                    if ulps <= 4:
+                        spread_ulp4 = np.maximum(spread_ulp4, mv)
+                    spread_ulp8 = np.maximum(spread_ulp8, mv)
         spread_builds = spread_ref
         spread_ref = np.maximum(spread_builds, spread_ulp)       # S of oracle/parity.py, measured on the reference itself
         spread_ref4 = np.maximum(spread_ref, spread_ulp4)
+        spread_ref8 = np.maximum(spread_ref, spread_ulp8)
         err = np.abs(got - base)[:, :nf]
         bar6 = 1e-10 * np.maximum(np.abs(base[:, :nf]), 1e-6 * top)
         bar4 = 1e-10 * np.maximum(np.abs(base[:, :nf]), 1e-4 * top)
@@ -116,12 +124,13 @@ def main():
         cov_b = int((beyond6 & (spread_builds[:, :nf] >= err)).sum())
         cov_ref = int((beyond6 & (sr >= err)).sum())
         cov_ref4 = int((beyond6 & (spread_ref4[:, :nf] >= err)).sum())
+        cov_ref8 = int((beyond6 & (spread_ref8[:, :nf] >= err)).sum())
         ratio = err[beyond6] / np.maximum(sr[beyond6], 1e-300)
         ratio_o = err[beyond6] / np.maximum(so[beyond6], 1e-300)
         agree = so[beyond6] / np.maximum(sr[beyond6], 1e-300)
         lines.append(f"{tag} {algo} skin={int(skin)} zt={zt} zu={zu} n={niter} records={nt}: {n} flagged cells; values beyond 1e-10 with floor 1e-6: {nb6} "
                      f"(floor 1e-4: {nb4}); HIP error <= spread of the reference builds alone on {cov_b}, <= reference spread S_ref (builds + inputs +-1 ulp) on "
-                     f"{cov_ref}, <= S_ref4 (inputs within +-4 ulp) on {cov_ref4} of {nb6}; HIP error / S_ref: median {np.median(ratio):.2f}, p90 {np.quantile(ratio, 0.9):.2f}, "
+                     f"{cov_ref}, <= S_ref4 (inputs within +-4 ulp) on {cov_ref4}, <= S_ref8 (within +-8 ulp) on {cov_ref8} of {nb6}; HIP error / S_ref: median {np.median(ratio):.2f}, p90 {np.quantile(ratio, 0.9):.2f}, "
                      f"max {ratio.max():.2f}; HIP error / S_oracle max {ratio_o.max():.2f}; S_oracle / S_ref in [{agree.min():.2f}, {agree.max():.2f}]; "
                      f"largest HIP error {float((err / bar6).max()):.1f} bars; largest move of a reference build, in bars: "
                      + ", ".join(f"{v} {float((per_var[v][:, :nf] / bar6).max()):.1f}" for v in REF_VARIANTS))
@@ -131,6 +140,7 @@ def main():
         fixture[tag + "_spread_ref"] = spread_ref
         fixture[tag + "_spread_ref_ulp"] = spread_ulp            # the +-1 ulp part alone (pinned build)
         fixture[tag + "_spread_ref4"] = spread_ref4
+        fixture[tag + "_spread_ref8"] = spread_ref8
         fixture[tag + "_spread_oracle"] = spread_orc
         fixture[tag + "_hip_err_when_made"] = np.abs(got - base)
         fixture[tag + "_scale"] = scale
