@@ -185,7 +185,7 @@ template <int N, int CL = kC_None> AB_FM double horner_coefs(const double *g, do
 }
 #endif
 AB_TAB double kConstTab[kC_N] = {-0.16667855714108057, 0.04166670739519204, 0.03923165829558719, 6.446912234869585e-09,
-                                  4.251847861014437e-10, -7.386244013567452e-10, 7.426603654517993e-10, 5.607982060924723e-12,
+                                  4.251847861014437e-10, -7.386244013567441e-10, 7.426603654517986e-10, 5.607982060924723e-12,
                                   0.3333333333333333, 0.25, 0.2222222222222222, 0.15625};
 // T[j] = 2^(j/64) of qexp (tools/gen_exptab.py 64)
 constexpr int kExpN = 64;

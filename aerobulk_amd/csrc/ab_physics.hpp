@@ -173,62 +173,62 @@ AB_TAB double kPsiTabM[224] = {
     3.921197389904554e-14, 3.542059996000773e-14, 3.1387425990005986e-14, 2.7362220958820366e-14};
 // COARE convective psi in L = LOG(y): 28 intervals, max |table - function| = 2.95e-16
 AB_TAB double kPsiTabC[224] = {
-    0.04529948098209352, 0.14189234846792742, 0.2466101756786744, 0.3595535229864228,
-    0.48075504594608276, 0.610180876850435, 0.7477340893445559, 0.8932599224377806,
-    1.0465523549720697, 1.2073615824151536, 1.3754019521211005, 1.5503599530424756,
-    1.7319019204183703, 1.9196811936716718, 2.1133445462761236, 2.3125377816626242,
+    0.04529948098209365, 0.14189234846792753, 0.24661017567867455, 0.35955352298642296,
+    0.48075504594608287, 0.6101808768504351, 0.747734089344556, 0.8932599224377807,
+    1.0465523549720699, 1.2073615824151538, 1.3754019521211005, 1.5503599530424756,
+    1.7319019204183703, 1.9196811936716718, 2.113344546276124, 2.3125377816626242,
     2.5169104540305747, 2.726119724530255, 2.9398334011343463, 3.15773223557881,
     3.3795115648810437, 3.604882390379675, 3.833571986244687, 4.0653241240197735,
     4.299898991684401, 4.53707287629091, 4.776637669416922, 5.0184002451421135,
     0.046290391133633264, 0.050316467242499566, 0.05440974743396389, 0.05853630941680868,
     0.062662361968251, 0.06675534771018629, 0.07078491270516744, 0.07472368911604557,
     0.07854785976082436, 0.08223749630746098, 0.0857766829600353, 0.0891534527008305,
-    0.09235957258748725, 0.09539021844313389, 0.09824357845570657, 0.10092042103931514,
-    0.10342365618176914, 0.1057579126136941, 0.1079291464009916, 0.10994429057991162,
-    0.11181095053319257, 0.113537146035445, 0.11513109821496434, 0.11660105794022727,
-    0.1179551711590232, 0.11920137631095869, 0.12034732893257373, 0.12140034883900841,
-    0.0009953416310716696, 0.0010163212118455532, 0.0010289005559759729, 0.0010329678291042393,
-    0.0010286978168085044, 0.001016527027106686, 0.0009971127869080388, 0.0009712816343667031,
-    0.0009399728422009146, 0.000904182560910266, 0.0008649130587175914, 0.0008231301517304476,
-    0.0007797304571360984, 0.0007355187965635099, 0.000691195067971766, 0.0006473492443284129,
-    0.0006044628271567312, 0.0005629150207524989, 0.0005229920191157457, 0.0004848980349650175,
+    0.09235957258748725, 0.09539021844313389, 0.09824357845570655, 0.10092042103931513,
+    0.10342365618176914, 0.10575791261369409, 0.10792914640099159, 0.1099442905799116,
+    0.11181095053319257, 0.113537146035445, 0.11513109821496434, 0.11660105794022725,
+    0.1179551711590232, 0.11920137631095867, 0.12034732893257372, 0.12140034883900841,
+    0.0009953416310716694, 0.0010163212118455532, 0.0010289005559759726, 0.0010329678291042393,
+    0.0010286978168085042, 0.001016527027106686, 0.0009971127869080388, 0.000971281634366703,
+    0.0009399728422009144, 0.000904182560910266, 0.0008649130587175914, 0.0008231301517304475,
+    0.0007797304571360983, 0.0007355187965635099, 0.000691195067971766, 0.0006473492443284129,
+    0.0006044628271567311, 0.0005629150207524989, 0.0005229920191157457, 0.0004848980349650175,
     0.00044876698445599217, 0.0004146740260199319, 0.0003826464080686944, 0.00035267329357035137,
     0.0003247143955267429, 0.0002987073787023812, 0.00027457406568436716, 0.00025222553700215224,
-    4.178173373109641e-06, 2.803765721441124e-06, 1.3862571800150163e-06, -2.557357932599896e-08,
-    -1.3855228409764022e-06, -2.653002248822162e-06, -3.7952926549550493e-06, -4.788843658112981e-06,
-    -5.619607318037562e-06, -6.282526775530033e-06, -6.78038799110039e-06, -7.122279164248292e-06,
-    -7.321893631907095e-06, -7.39587173771854e-06, -7.3623210596974165e-06, -7.2395962415528935e-06,
-    -7.045369040101726e-06, -6.795980995001982e-06, -6.506046415283077e-06, -6.188260674115349e-06,
-    -5.853365355733585e-06, -5.510224575967214e-06, -5.165973105697561e-06, -4.826204686894181e-06,
-    -4.495176730529954e-06, -4.176014591556879e-06, -3.8709044366193895e-06, -3.581268262732922e-06,
-    -1.6708124301857217e-07, -1.7551635196022662e-07, -1.7783707608487505e-07, -1.7415157032601542e-07,
-    -1.64985382160261e-07, -1.5120009627595043e-07, -1.3388121118123845e-07, -1.1421501031742401e-07,
-    -9.33730343056178e-08, -7.241817033805637e-08, -5.224008552240641e-08, -3.352150100239719e-08,
-    -1.6731913636596045e-08, -2.142418713780187e-09, 1.0145754555907475e-08, 2.0165942500437135e-08,
-    2.8049591289711673e-08, 3.399256836955515e-08, 3.822653040840923e-08, 4.09962935856305e-08,
-    4.254318667536689e-08, 4.3093768784997036e-08, 4.2852996280071244e-08, 4.2000843520490476e-08,
-    4.069143992203817e-08, 3.9053917211777894e-08, 3.719431955880926e-08, 3.5198086280489954e-08,
-    -1.1415332950006078e-09, -5.397285986110226e-10, 7.372219848236811e-11, 6.544804842613599e-10,
-    1.1642061086916462e-09, 1.574550155027219e-09, 1.8692600045982588e-09, 2.044296530644463e-09,
-    2.106276243542072e-09, 2.069813582790475e-09, 1.954415844498125e-09, 1.781502571681103e-09,
-    1.571945775048792e-09, 1.3443260909518626e-09, 1.1139257064133314e-09, 8.923591921524777e-10,
-    6.876828340453736e-10, 5.04811129474378e-10, 3.4608906496142196e-10, 2.1190424759955593e-10,
-    1.0126147366414524e-10, 1.2276280138662402e-11, -5.7429966439500326e-11, -1.1043332422072651e-10,
-    -1.4929849148148553e-10, -1.7644285780776803e-10, -1.9405723511507826e-10, -2.0406828176125495e-10,
-    4.8362578112254345e-11, 5.123785237365567e-11, 5.031463438371543e-11, 4.5883241032265476e-11,
-    3.863218884233347e-11, 2.950847273492058e-11, 1.954999038506005e-11, 9.728300742858384e-12,
-    8.307714760785022e-13, -6.6037316694358056e-12, -1.2296428604148812e-11, -1.6199094906629782e-11,
-    -1.8439955934519478e-11, -1.926118717254953e-11, -1.8960464403963518e-11, -1.784401034458074e-11,
-    -1.6193957232734446e-11, -1.4249460096520059e-11, -1.2199057418830646e-11, -1.0181065663113648e-11,
-    -8.288918549044043e-12, -6.578930268935798e-12, -5.0786743815120455e-12, -3.794840206532353e-12,
-    -2.7199662344806123e-12, -1.8378322659166164e-12, -1.1275334275684914e-12, -5.663906051781826e-13,
-    3.3962374534011237e-13, 6.898763685989287e-14, -1.974083861208119e-13, -4.274734570264325e-13,
-    -5.971795865833129e-13, -6.939544771419252e-13, -7.172524390048276e-13, -6.766195955596589e-13,
-    -5.881820728387849e-13, -4.706881351354242e-13, -3.420610913229443e-13, -2.1702933343091422e-13,
-    -1.0597886679959869e-13, -1.485557025840927e-14, 5.421856617375942e-14, 1.019741178382386e-13,
-    1.3095994457039944e-13, 1.446353058102738e-13, 1.466787304650988e-13, 1.4052952720324492e-13,
-    1.2913291761216073e-13, 1.1484012642507805e-13, 9.94124486272133e-14, 8.408555406772081e-14,
-    6.966118885884548e-14, 5.6604317094079784e-14, 4.513279603485118e-14, 3.529332826378247e-14};
+    4.178173373109639e-06, 2.803765721441123e-06, 1.3862571800150156e-06, -2.5573579325999376e-08,
+    -1.3855228409764024e-06, -2.653002248822162e-06, -3.7952926549550493e-06, -4.78884365811298e-06,
+    -5.619607318037561e-06, -6.282526775530032e-06, -6.780387991100389e-06, -7.122279164248291e-06,
+    -7.321893631907094e-06, -7.395871737718539e-06, -7.362321059697416e-06, -7.239596241552893e-06,
+    -7.045369040101725e-06, -6.795980995001981e-06, -6.506046415283076e-06, -6.188260674115348e-06,
+    -5.853365355733584e-06, -5.510224575967214e-06, -5.165973105697561e-06, -4.826204686894181e-06,
+    -4.495176730529953e-06, -4.176014591556879e-06, -3.8709044366193895e-06, -3.5812682627329217e-06,
+    -1.6708124301857214e-07, -1.755163519602266e-07, -1.7783707608487502e-07, -1.741515703260154e-07,
+    -1.6498538216026096e-07, -1.512000962759504e-07, -1.3388121118123843e-07, -1.1421501031742399e-07,
+    -9.337303430561779e-08, -7.241817033805636e-08, -5.2240085522406406e-08, -3.3521501002397186e-08,
+    -1.673191363659604e-08, -2.1424187137801872e-09, 1.0145754555907471e-08, 2.016594250043713e-08,
+    2.804959128971167e-08, 3.399256836955514e-08, 3.822653040840922e-08, 4.0996293585630496e-08,
+    4.254318667536688e-08, 4.309376878499703e-08, 4.285299628007124e-08, 4.200084352049047e-08,
+    4.0691439922038166e-08, 3.905391721177789e-08, 3.7194319558809256e-08, 3.519808628048995e-08,
+    -1.1415332950006071e-09, -5.397285986110223e-10, 7.372219848236827e-11, 6.544804842613599e-10,
+    1.164206108691646e-09, 1.5745501550272189e-09, 1.8692600045982584e-09, 2.0442965306444627e-09,
+    2.1062762435420714e-09, 2.0698135827904745e-09, 1.9544158444981247e-09, 1.7815025716811025e-09,
+    1.5719457750487915e-09, 1.3443260909518624e-09, 1.1139257064133312e-09, 8.923591921524775e-10,
+    6.876828340453735e-10, 5.04811129474378e-10, 3.460890649614219e-10, 2.1190424759955593e-10,
+    1.0126147366414525e-10, 1.2276280138662427e-11, -5.7429966439500293e-11, -1.1043332422072647e-10,
+    -1.492984914814855e-10, -1.7644285780776798e-10, -1.940572351150782e-10, -2.040682817612549e-10,
+    4.836257811225434e-11, 5.123785237365566e-11, 5.0314634383715417e-11, 4.5883241032265463e-11,
+    3.863218884233346e-11, 2.9508472734920564e-11, 1.9549990385060043e-11, 9.72830074285838e-12,
+    8.307714760785015e-13, -6.603731669435805e-12, -1.2296428604148809e-11, -1.619909490662978e-11,
+    -1.8439955934519472e-11, -1.9261187172549524e-11, -1.8960464403963515e-11, -1.7844010344580736e-11,
+    -1.6193957232734443e-11, -1.4249460096520055e-11, -1.2199057418830645e-11, -1.0181065663113647e-11,
+    -8.288918549044041e-12, -6.578930268935796e-12, -5.078674381512045e-12, -3.794840206532353e-12,
+    -2.719966234480612e-12, -1.8378322659166164e-12, -1.1275334275684914e-12, -5.663906051781827e-13,
+    3.3962374534011216e-13, 6.898763685989277e-14, -1.9740838612081193e-13, -4.2747345702643247e-13,
+    -5.971795865833127e-13, -6.93954477141925e-13, -7.172524390048274e-13, -6.766195955596587e-13,
+    -5.881820728387847e-13, -4.706881351354241e-13, -3.420610913229442e-13, -2.1702933343091417e-13,
+    -1.0597886679959866e-13, -1.4855570258409276e-14, 5.4218566173759395e-14, 1.0197411783823857e-13,
+    1.309599445703994e-13, 1.4463530581027375e-13, 1.4667873046509878e-13, 1.405295272032449e-13,
+    1.291329176121607e-13, 1.1484012642507802e-13, 9.941244862721327e-14, 8.40855540677208e-14,
+    6.966118885884547e-14, 5.660431709407978e-14, 4.5132796034851175e-14, 3.5293328263782466e-14};
 // e_sat(T) [Pa] on 265 K <= T < 312 K, RELATIVE error: 24 intervals, max |table - function| = 7.82e-17
 AB_TAB double kEsatTab[192] = {
     357.24731931304785, 414.99422650940187, 480.8987996855304, 555.9404053510857,
@@ -758,22 +758,23 @@ __device__ __forceinline__ void wl_ecmwf(R &dT_wl, R zHwl, const WlEcmwfCell<R> 
 //    psi_c = 3 LOG(c) + G(w) = .9999 L + G(w),   G(w) = 1.5 LOG((w*w+w+1)/3) - 1.7320508 (pi/2 - ATAN(1.7320508 w/(w+2))) + 1.813799447
 // G is analytic on [0,1]; it is evaluated by its degree-20 near-minimax polynomial in x = 2w-1 (tools/gen_poly.py, fitted
 // to the reference's formula WITH its truncated literals; |dG| <= 3.2e-16) instead of a second log and an atan.
-AB_TAB double kPsicG[fm::ab_pad4(21)] = {-1.1378018661248832, 1.2857142823699836, -0.15306122324762675, -0.0029154522038313062,
-                                  0.012182424010797529, -0.005319212199747766, 0.001372727329966169, -0.00012957955060170255,
-                                  -8.228815772429666e-05, 5.619522847612674e-05, -1.9496010425207854e-05, 3.5584071875334317e-06,
-                                  4.569112576860545e-07, -6.688538104698402e-07, 2.9920447417445153e-07, -7.973350238907205e-08,
-                                  4.974190761282226e-09, 9.732585524385644e-09, -5.605322344298673e-09, 7.426603654517993e-10,
-                                  1.903681291004176e-10};
+AB_TAB double kPsicG[fm::ab_pad4(21)] = {-1.1378018661248832, 1.2857142823699836, -0.15306122324762672, -0.0029154522038313106,
+    0.012182424010797529, -0.005319212199747766, 0.0013727273299661688, -0.00012957955060170244,
+    -8.228815772429667e-05, 5.619522847612674e-05, -1.9496010425207848e-05, 3.55840718753343e-06,
+    4.569112576860549e-07, -6.688538104698402e-07, 2.992044741744515e-07, -7.973350238907201e-08,
+    4.974190761282214e-09, 9.732585524385646e-09, -5.605322344298672e-09, 7.426603654517986e-10,
+    1.9036812910041772e-10};
 // Round 2: the same convective term as a polynomial in ITS OWN log, L = LOG(y): psi_c is analytic in L (nearest singularities at
 // L = +-2 pi i), degree 24 on 0 <= L <= LMAX = LOG(1 + 34.15*50) reaches the rounding of its coefficients (3.8e-16 absolute on
 // values up to 6.6; tools/gen_poly.py section 7).  One log + 24 FMAs instead of a log, an exponential and the 20 FMAs of G.
 // Beyond LMAX (the unclamped zeta of the first guess on a very unstable cell) the form above.
-AB_TAB double kPsicL[fm::ab_pad4(25)] = {2.0150925272068325, 2.710495199372137, 0.5590871232010397, -0.16213149529306578,
-    0.002606559842464411, 0.02113263846338554, -0.00925777348479494, 0.00030099378954847087, 0.0016285542947419458,
-    -0.000813039719902679, 4.423480654812829e-05, 0.00015150397200069243, -8.181957400187386e-05, 5.998120165166443e-06,
-    1.5319367544130388e-05, -8.825168944553084e-06, 8.20341206092634e-07, 1.6890014539724033e-06, -1.0233606614380631e-06,
-    4.458163497401242e-08, 2.2237828297719965e-07, -7.86594884389353e-08, -1.6678750033618162e-08, 1.1728431071594043e-08,
-    -7.386244013567452e-10};
+AB_TAB double kPsicL[fm::ab_pad4(25)] = {2.0150925272068325, 2.710495199372137, 0.5590871232010396, -0.16213149529306575,
+    0.00260655984246441, 0.021132638463385537, -0.009257773484794939, 0.00030099378954847065,
+    0.0016285542947419454, -0.0008130397199026788, 4.4234806548128256e-05, 0.00015150397200069238,
+    -8.181957400187382e-05, 5.998120165166437e-06, 1.531936754413038e-05, -8.82516894455308e-06,
+    8.203412060926331e-07, 1.6890014539724024e-06, -1.0233606614380625e-06, 4.458163497401233e-08,
+    2.2237828297719952e-07, -7.865948843893524e-08, -1.6678750033618155e-08, 1.1728431071594033e-08,
+    -7.386244013567441e-10};
 template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
 {
     using M = Mth<R>;

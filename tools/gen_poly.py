@@ -117,8 +117,8 @@ for deg in (13, 14, 15):
 #    literals 1.7320508 and 1.813799447:
 #      psi_c(c) = 1.5 ln((1+c+c^2)/3) - 1.7320508 atan((1+2c)/1.7320508) + 1.813799447,  c = y^.3333 >= 1
 #    = 3 ln c + G(w), w = 1/c in (0,1]:  G(w) = 1.5 ln((w^2+w+1)/3) - S (pi/2 - atan(S w/(w+2))) + 1.813799447
-S3 = mp.mpf("1.7320508")
-G = lambda w: mp.mpf("1.5") * mp.log((w * w + w + 1) / 3) - S3 * (mp.pi / 2 - mp.atan(S3 * w / (w + 2))) + mp.mpf("1.813799447")
+S3 = D(1.7320508)          # the reference's literals as doubles (0.15 ulp of psi_c at most; D() above)
+G = lambda w: mp.mpf("1.5") * mp.log((w * w + w + 1) / 3) - S3 * (mp.pi / 2 - mp.atan(S3 * w / (w + 2))) + D(1.813799447)
 for deg in (9, 18, 20, 22, 24):     # 9: the fp32 path (3.4e-8 absolute)
     c = cheb_fit(lambda x: G((x + 1) / 2), mp.mpf(-1), mp.mpf(1), deg)
     err = max_err(lambda x: G((x + 1) / 2), c, mp.mpf(-1), mp.mpf(1), rel=False)
@@ -152,8 +152,8 @@ for name, f in (("PSIK_M", psik_m), ("PSIK_H", psik_h)):
 #    L in [0, LMAX], LMAX = ln(1 + 34.15*50); t = 2 L / LMAX - 1.
 LMAX = mp.log(1 + mp.mpf("34.15") * 50)
 def psic_L(L):
-    c = mp.exp(mp.mpf("0.3333") * L)
-    return mp.mpf("1.5") * mp.log((1 + c + c * c) / 3) - S3 * mp.atan((1 + 2 * c) / S3) + mp.mpf("1.813799447")
+    c = mp.exp(D(0.3333) * L)
+    return mp.mpf("1.5") * mp.log((1 + c + c * c) / 3) - S3 * mp.atan((1 + 2 * c) / S3) + D(1.813799447)
 print("LMAX =", repr(float(LMAX)))
 for deg in (24, 26, 28, 30):
     c = cheb_fit(lambda t: psic_L((t + 1) / 2 * LMAX), mp.mpf(-1), mp.mpf(1), deg)

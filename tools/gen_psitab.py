@@ -21,11 +21,15 @@ DEG = 7
 NINT = 32                 # fp32 tables
 NINT_PSI, NINT_ESAT = 28, 24   # fp64 tables: intervals per function
 RPI = mp.mpf(float("3.141592653589793"))      # rpi of the reference (mod_const.f90:39), as the double it is
-S3 = mp.mpf("1.7320508")
 # table ranges: just beyond LOG(1 + 16*50) = 6.68586 and LOG(1 + 34.15*50) = 7.44337 (the callers clamp zeta at -50: a clamped cell
 # must stay inside), binary-friendly
 SMAX = mp.mpf("6.6875")
 LMAX = mp.mpf("7.4453125")
+
+
+def D(x):
+    """a literal of the reference as the double it is at run time (rt0 = 273.15 is 2.3e-14 below 273.15: seven ulp of e_sat)"""
+    return mp.mpf(float(x))
 
 
 def psik_m(s):
@@ -37,8 +41,9 @@ def psik_h(s):
 
 
 def psic_L(L):
-    c = mp.exp(mp.mpf("0.3333") * L)
-    return mp.mpf("1.5") * mp.log((1 + c + c * c) / 3) - S3 * mp.atan((1 + 2 * c) / S3) + mp.mpf("1.813799447")
+    S3 = D(1.7320508)          # the reference's literals as doubles
+    c = mp.exp(D(0.3333) * L)
+    return mp.mpf("1.5") * mp.log((1 + c + c * c) / 3) - S3 * mp.atan((1 + 2 * c) / S3) + D(1.813799447)
 
 
 def local_fit(f, a, b, deg=None):
@@ -53,11 +58,6 @@ def local_fit(f, a, b, deg=None):
         y[i] = f((a + b) / 2 + (b - a) / 2 * u)
     c = mp.lu_solve(A, y)
     return [float(c[j]) for j in range(n)]
-
-
-def D(x):
-    """a literal of the reference as the double it is at run time (rt0 = 273.15 is 2.3e-14 below 273.15: seven ulp of e_sat)"""
-    return mp.mpf(float(x))
 
 
 T0 = D(273.15)
