@@ -64,7 +64,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     in.q_zt = q_zt;
     in.slp = slp;
     in.wnd = M::sqrt(uu * uu + vv * vv);                                       // :111
-    in.ssq = K<R>::rdct_qsat_salt * q_sat<R, (TILED && SKIN && kPsiTabDefault)>(sst, slp);   // :114 (e_sat from its LDS table in the tiled kernels with the skin schemes only)
+    in.ssq = rounded(K<R>::rdct_qsat_salt * q_sat<R, (TILED && SKIN && kPsiTabDefault)>(sst, slp));   // :114 (e_sat from its LDS table in the tiled kernels with the skin schemes only)
     in.qsw = qsw;
     in.rlw = rlw;
 

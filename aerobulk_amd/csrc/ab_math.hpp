@@ -10,6 +10,7 @@
 // (measured: tests/test_gpu_math.py, tests/test_gpu_golden.py).
 #pragma once
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #endif
 
@@ -117,6 +118,25 @@ template <class R> __device__ __forceinline__ R sfloor(R x, R eps)
 template <class R> __device__ __forceinline__ R sclamp(R x, R cap)
 {
     return Mth<R>::copysign(vmin(Mth<R>::abs(x), cap), x);
+}
+// A value the reference keeps in a variable of its own and subtracts from another in two places that must agree to the last bit
+// (q_s = 0.98 q_sat(T_s): Ce = (u*/Ub) q*/(q_zu - q_s) inside TURB_*, then E = rho Ub Ce (q_zu - q_s) in BULK_FORMULA: the ratio of
+// the two differences is exactly 1, however ill-conditioned each of them is).  Under -ffp-contract=fast the product would be fused
+// into whichever subtraction sees it as a product — q_zu - 0.98 q_sat unrounded in the iteration, the rounded loop-carried value
+// after it — and the two differences part by half an ulp of q_s: 3e-8 of Q_L where q_zu - q_s = 3e-11.  The empty asm makes the
+// value opaque: it is rounded once, as in the reference, and every difference sees the same number.
+template <class R> __device__ __forceinline__ R rounded(R x)
+{
+    if constexpr (std::is_floating_point<R>::value) {
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+        asm("" : "+v"(x));
+#elif defined(__x86_64__)
+        asm("" : "+x"(x));
+#else
+        asm("" : "+r"(x));
+#endif
+    }
+    return x;
 }
 // `0.5 + SIGN(0.5,x)` == 1  <=>  sign bit of x clear (SIGN(0.5,-0.) = -0.5 on IEEE processors)
 template <class R> __device__ __forceinline__ bool nonneg(R x) { return !__builtin_signbit(x); }

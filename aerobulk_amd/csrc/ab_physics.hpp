@@ -977,7 +977,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
     constexpr bool CS = (SKIN & kSkinCS) != 0, WL = (SKIN & kSkinWL) != 0;
     if (SKIN) {
         if (CS) T_s = T_s - R(0.25);                                   // :274
-        q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);  // :275
+        q_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp));  // :275
         zalpha = alpha_sw(xSST);                                       // hoisted from CS_COARE :81 / WL_COARE :153
         if (WL) {
             const R Rich0 = R(0.65);
@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             T_s = xSST + zdT_cs;
             if (WL) T_s = T_s + wl[0];                                 // :360-361
             // with the warm layer on, this q_s is only read by the UPDATE_QNSOL_TAU of a live WL_COARE call (below)
-            if (!WL || (nb_iter % jit) == 0) q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
+            if (!WL || (nb_iter % jit) == 0) q_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp));
         }
         if (WL) {
             // WL_COARE is called with iwait = MOD(nb_iter,jit) (:370) and writes its state (dT_wl, Hz_wl, Qnt_ac, Tau_ac)
@@ -1068,7 +1068,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             }
             T_s = xSST + wl[0];
             if (CS) T_s = T_s + zdT_cs;                                // :373-374
-            q_s = K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp);
+            q_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp));
         }
         if (!V36 || SKIN || !h.zt_eq_zu) {                             // :378-381 (3p0 :317-318 unconditional)
             zdt = sfloor(t_zu - T_s, R(1.E-09));
@@ -1160,7 +1160,7 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
     constexpr bool CS = (SKIN & kSkinCS) != 0, WL = (SKIN & kSkinWL) != 0;
     if (SKIN) {
         if (CS) zT_s = zT_s - R(0.25);                                  // :214
-        zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
+        zq_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp));
         zalpha = alpha_sw(zSST);
     }
     R zus, zts, zqs, zt_zu, zq_zu, zUbzu, zz0;
@@ -1227,7 +1227,7 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
             zdT_cs = cool_skin<R, false>(in.qsw, zQns, zus, zalpha, R(0.));  // :324
             zT_s = zSST + zdT_cs;
             if (WL) zT_s = zT_s + wl[0];
-            zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
+            zq_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp));
         }
         if (WL) {
             R zQns, zTau, zQlat;
@@ -1236,7 +1236,7 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
             wl_ecmwf(wl[0], wl[1], wlc, in.qsw, zQns, zus, zalpha);     // :335
             zT_s = zSST + wl[0];
             if (CS) zT_s = zT_s + zdT_cs;
-            zq_s = K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp);
+            zq_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp));
         }
         zdt = sfloor(zt_zu - zT_s, R(1.E-09));                          // :342-343
         zdq = sfloor(zq_zu - zq_s, R(1.E-12));

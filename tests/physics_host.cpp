@@ -34,7 +34,7 @@ static void cell(const Heights<double> &h, int nb_iter, int hum_type, const doub
     in.q_zt = q_zt;
     in.slp = slp;
     in.wnd = Mth<R>::sqrt(uu * uu + vv * vv);
-    in.ssq = K<R>::rdct_qsat_salt * q_sat(sst, slp);
+    in.ssq = rounded(K<R>::rdct_qsat_salt * q_sat(sst, slp));
     in.qsw = SKIN ? (R(1.) - K<R>::roce_alb0) * f[6][k] : R(0.);
     in.rlw = SKIN ? f[7][k] : R(0.);
     if (SKIN && !wl_load) { wl[0] = 0.; wl[1] = (ALGO == 4) ? 3. : 20.; wl[2] = 0.; wl[3] = 0.; }

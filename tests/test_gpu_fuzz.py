@@ -66,3 +66,35 @@ def test_random_inputs_match_oracle(oracle, seed, algo, skin, zt, zu, niter):
             assert ref["rc"] == 0
             assert_hot_parity({kr: got[k] for k, kr in keys}, ref, [kr for _, kr in keys], sens=sens, jt=jt,
                               label=f"fuzz {algo} skin={skin} seed={seed} jt={jt}")
+
+
+# Cells where the iteration drives q_zu - q_s below 1e-9 while q* is still that of the previous pass (found by the campaign of seeds
+# 400-499, profiles/r2_fuzz_wide.txt).  The reference forms Ce = (u*/Ub) q*/(q_zu - q_s) and then E = rho Ub Ce (q_zu - q_s) from
+# the SAME rounded q_s: the ratio of the two differences is exactly 1 and Q_L answers an ulp of SST by 2e-10 only.  With q_s =
+# 0.98 q_sat left to FMA contraction the kernel's two differences parted by half an ulp of q_s and Q_L was off by 3e-8 / 2e-9 /
+# 3e-10 here (18-177 times the reference's response to moves of 8 ulp); with q_s rounded once (ab_math.hpp rounded()) 2e-11.
+CANCELLING_CELLS = (
+    ("coare3p0", 3.5, 17.0, 4, (296.08674933131164, 300.2417895537066, 0.018445783738533606, 0.7660703762685862, 0.12639461254391587, 99827.32005680964, 921.6839261119418, 275.1876383337403)),
+    ("coare3p6", 18.0, 25.0, 5, (288.57742658389077, 298.56499391388843, 0.01153765827631025, 11.537479388544785, -9.01269754426534, 93907.81099990479, 487.8246181769313, 387.9927800917013)),
+    ("coare3p6", 18.0, 25.0, 5, (275.2042593141406, 283.87262320398906, 0.004168358513102504, 9.919691554677938, 8.547993371116158, 103606.81517975294, 106.68545125475167, 164.55827991957156)),
+    ("coare3p6", 18.0, 25.0, 5, (287.1460114387934, 287.456619042327, 0.009744414906212473, 0.6068199371412757, -4.191939855730995, 100696.93250237366, 996.5387726013536, 220.6918700473129)),
+)
+
+
+@pytest.mark.parametrize("case", range(len(CANCELLING_CELLS)))
+def test_both_humidity_differences_see_the_same_q_s(oracle, case):
+    import aerobulk_amd as ab
+    algo, zt, zu, niter, cell = CANCELLING_CELLS[case]
+    n = 1000                                               # the cell among ordinary neighbours (tiles, regrouping as in a real field)
+    f = _fields(7, n)
+    for i, k in enumerate(("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")):
+        f[k][::10] = cell[i]
+    ins = [f[k] for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")]
+    osess = oracle.OracleSession(algo, n, 3, True)
+    with ab.Session(algo, n, 1, 3, True) as s:
+        for jt in range(1, 4):
+            ref = osess.compute(jt, zt, zu, niter, *ins, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+            got = s.compute(jt, zt, zu, *ins, Niter=niter, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+            for k, kr in (("QL", "ql"), ("Evap", "evap")):
+                rel = np.abs(got[k][::10] - ref[kr][::10]) / np.abs(ref[kr][::10])
+                assert rel.max() < 2e-10, (algo, jt, k, rel.max())     # one ulp of SST moves the reference's value by 2e-10

@@ -18,6 +18,8 @@ from oracle import pyoracle as po  # noqa: E402
 from test_gpu_fuzz import _fields  # noqa: E402
 
 NFLAG = [0, 0]
+WORST = [0.0, 0.0]     # largest err / S(max over inputs, 8 ulp), err / S(sum over inputs, 8 ulp)
+THRESH = 2.0
 IN8 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")
 OUT = (("QL", "ql"), ("QH", "qh"), ("Tau_x", "tau_x"), ("Tau_y", "tau_y"), ("Evap", "evap"), ("T_s", "t_s"))
 
@@ -70,23 +72,34 @@ def main():
                 sub = {k: np.ascontiguousarray(v[bad]) for k, v in f.items()}
                 base = run_oracle(algo, skin, zt, zu, niter, nt, sub)[jt][kr]
                 sfma = np.abs(run_oracle(algo, skin, zt, zu, niter, nt, sub, variant="fma")[jt][kr] - base)
-                S = {}
+                S, per8 = {}, {}
                 for ulp in (1, 2, 3, 4, 8):
                     acc = sfma.copy()
                     for k in IN8[:8 if skin else 6]:
+                        rk = np.zeros_like(acc)
                         for sg in (1, -1):
                             p = dict(sub, **{k: move(sub[k], sg * ulp)})
-                            acc = np.maximum(acc, np.abs(run_oracle(algo, skin, zt, zu, niter, nt, p)[jt][kr] - base))
+                            rk = np.maximum(rk, np.abs(run_oracle(algo, skin, zt, zu, niter, nt, p)[jt][kr] - base))
+                        acc = np.maximum(acc, rk)
+                        per8[k] = np.maximum(per8.get(k, 0.0), rk)      # response to moves of <= 8 ulp of input k alone
                     S[ulp] = acc
                 cum = {u: np.maximum.reduce([S[v] for v in S if v <= u]) for u in S}
+                ssum = np.sum([per8[k] for k in per8], axis=0)           # all inputs moving at once (first order)
                 for i, b in enumerate(bad):
                     rat = {u: err[b] / max(cum[u][i], 1e-300) for u in cum}
-                    if rat[1] > 2.0:
+                    WORST[0] = max(WORST[0], rat[8])
+                    WORST[1] = max(WORST[1], err[b] / max(ssum[i], 1e-300))
+                    if rat[1] > THRESH:
                         print(f"seed {seed} {algo} skin={int(skin)} zt={zt} jt={jt + 1} {kr}[{b}]: ref {r[b]:.6e} err {err[b]:.3e} "
                               f"err/S(moves <= 1,2,3,4,8 ulp) = " + " ".join(f"{rat[u]:.2f}" for u in (1, 2, 3, 4, 8))
-                              + f" | sst {f['sst'][b]:.3f} t {f['t_zt'][b]:.3f} wind {np.hypot(f['u_zu'][b], f['v_zu'][b]):.3f}", flush=True)
+                              + f" err/sum over inputs (8 ulp) = {err[b] / max(ssum[i], 1e-300):.2f}"
+                              + " | response per input (8 ulp)/err: " + " ".join(f"{k}={per8[k][i] / err[b]:.2f}" for k in per8)
+                              + f" fma={sfma[i] / err[b]:.2f}"
+                              + f" | sst {f['sst'][b]:.3f} t {f['t_zt'][b]:.3f} q {f['hum_zt'][b]:.5f} wind {np.hypot(f['u_zu'][b], f['v_zu'][b]):.3f}"
+                              + (f" rsw {f['rad_sw'][b]:.1f}" if skin else ""), flush=True)
 
 
 if __name__ == "__main__":
     main()
-    print(f"values compared {NFLAG[1]}, beyond the forward bar {NFLAG[0]}")
+    print(f"values compared {NFLAG[1]}, beyond the forward bar {NFLAG[0]}; largest err / response to moves of <= 8 ulp: "
+          f"one input {WORST[0]:.2f}, all inputs {WORST[1]:.2f}")
