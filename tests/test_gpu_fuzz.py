@@ -42,6 +42,21 @@ if os.environ.get("AB_FUZZ_SEEDS"):          # wider campaigns: AB_FUZZ_SEEDS=20
                                                     ("andreas", False, 8.0, 12.0, 7),
                                                     ("coare3p6", True, 18.0, 25.0, 5), ("ncar", False, 30.0, 10.0, 6)])   # zt > 10 m
 def test_random_inputs_match_oracle(oracle, seed, algo, skin, zt, zu, niter):
+    _fuzz_case(oracle, seed, algo, skin, zt, zu, niter)
+
+
+# the corners of the parameter space the nine configurations above leave out: zt = zu with the skin schemes, zt > zu for COARE / ECMWF,
+# one and two passes, twenty passes, ten passes with the warm layer (it commits at jit = 1, 2, 5, 10: MOD(nb_iter, jit))
+@pytest.mark.parametrize("seed", SEEDS if os.environ.get("AB_FUZZ_SEEDS") else SEEDS[:4])
+@pytest.mark.parametrize("algo,skin,zt,zu,niter", [("coare3p6", True, 10.0, 10.0, 10), ("coare3p0", True, 25.0, 10.0, 3),
+                                                    ("ecmwf", True, 12.0, 4.0, 2), ("andreas", False, 2.0, 10.0, 1),
+                                                    ("coare3p0", False, 2.0, 10.0, 20), ("ecmwf", False, 10.0, 10.0, 8),
+                                                    ("ecmwf", True, 10.0, 10.0, 10), ("coare3p6", False, 15.0, 3.0, 2)])
+def test_random_inputs_match_oracle_corner_configurations(oracle, seed, algo, skin, zt, zu, niter):
+    _fuzz_case(oracle, seed, algo, skin, zt, zu, niter)
+
+
+def _fuzz_case(oracle, seed, algo, skin, zt, zu, niter):
     import aerobulk_amd as ab
     n = 60000 + 13 * seed                                  # ragged: not a multiple of any tile size
     f = _fields(seed, n)
