@@ -29,6 +29,7 @@ def adversarial_fields(po, algo, skin, zt, zu, niter, n, seed):
     which = r.integers(0, 3, n)
     dq_t = r.choice(TARGETS, n) * r.choice([-1.0, 1.0], n)
     dt_t = r.choice(TARGETS * 1e3, n) * r.choice([-1.0, 1.0], n)           # kelvin: 1e-10 ... 1e-4 (floors 1e-9, 1e-6)
+    f0 = {k: f[k].copy() for k in ("hum_zt", "t_zt")}
     prev = None
     for it in range(10):                                                   # secant iteration per cell on hum_zt and t_zt (oracle only)
         s = po.OracleSession(algo, n, 1, skin)
@@ -48,6 +49,10 @@ def adversarial_fields(po, algo, skin, zt, zu, niter, n, seed):
         mq, mt = which != 1, which != 0
         f["hum_zt"] = np.where(mq, np.maximum(f["hum_zt"] - rq / sq, 1e-5), f["hum_zt"])
         f["t_zt"] = np.where(mt, f["t_zt"] - rt / st, f["t_zt"])
+    # a cell whose secant iteration ran away (no root within reach: the clamps of a very unstable calm cell) keeps its original inputs
+    lost = ~np.isfinite(f["t_zt"]) | ~np.isfinite(f["hum_zt"]) | (np.abs(f["t_zt"] - f["sst"]) > 14.0) | (f["hum_zt"] <= 1e-5) | (f["hum_zt"] > 0.04)
+    for k in f0:
+        f[k] = np.where(lost, f0[k], f[k])
     return f, which
 
 
