@@ -56,7 +56,16 @@ def test_random_inputs_match_oracle_corner_configurations(oracle, seed, algo, sk
     _fuzz_case(oracle, seed, algo, skin, zt, zu, niter)
 
 
-def _fuzz_case(oracle, seed, algo, skin, zt, zu, niter):
+# relative humidity and dew point as the humidity input: e_sat enters the pre-processing (q_air_rh / q_air_dp)
+@pytest.mark.parametrize("seed", SEEDS if os.environ.get("AB_FUZZ_SEEDS") else SEEDS[:3])
+@pytest.mark.parametrize("algo,skin,zt,zu,niter,hum", [("coare3p6", True, 2.0, 10.0, 5, "rh"), ("coare3p6", True, 2.0, 10.0, 5, "dp"),
+                                                        ("ecmwf", False, 2.0, 10.0, 5, "rh"), ("andreas", False, 8.0, 12.0, 7, "dp"),
+                                                        ("coare3p0", True, 18.0, 25.0, 5, "rh"), ("ncar", False, 10.0, 10.0, 5, "dp")])
+def test_random_inputs_match_oracle_other_humidity_types(oracle, seed, algo, skin, zt, zu, niter, hum):
+    _fuzz_case(oracle, seed, algo, skin, zt, zu, niter, hum)
+
+
+def _fuzz_case(oracle, seed, algo, skin, zt, zu, niter, hum="sh"):
     import aerobulk_amd as ab
     n = 60000 + 13 * seed                                  # ragged: not a multiple of any tile size
     f = _fields(seed, n)
@@ -65,12 +74,18 @@ def _fuzz_case(oracle, seed, algo, skin, zt, zu, niter):
         f = {k: np.ascontiguousarray(v[keep]) for k, v in f.items()}
         n = int(keep.sum())
     nt = 3 if skin else 1
+    if hum == "rh":                                        # relative humidity [%] of the same air (mod_aerobulk_compute.f90:105)
+        es = 611.2 * np.exp(17.62 * (f["t_zt"] - 273.15) / (f["t_zt"] - 30.03))
+        f["hum_zt"] = np.clip(100.0 * f["hum_zt"] / (0.622 * es / (f["slp"] - 0.378 * es)), 5.0, 100.0)
+    elif hum == "dp":                                      # dew point [K] (:103)
+        f["hum_zt"] = f["t_zt"] - np.random.default_rng(seed + 7).uniform(0.0, 9.0, n)
     ins = [f[k] for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")]
     rad = dict(rad_sw=f["rad_sw"] if skin else None, rad_lw=f["rad_lw"] if skin else None)
-    osess = oracle.OracleSession(algo, n, nt, skin)
-    sens = sensitivity(oracle, algo, skin, zt, zu, niter, f, nt=nt)
+    osess = oracle.OracleSession(algo, n, nt, skin, hum)
+    sens = sensitivity(oracle, algo, skin, zt, zu, niter, f, nt=nt, hum_type=hum)
     keys = OUT if skin else OUT[:5]
     with ab.Session(algo, n, 1, nt, skin) as s:
+        s.set_humidity(hum)
         for jt in range(1, nt + 1):
             ref = osess.compute(jt, zt, zu, niter, *ins, **rad)
             try:
