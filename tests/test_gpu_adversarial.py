@@ -82,3 +82,18 @@ def test_vanishing_air_sea_differences_everywhere(oracle, algo, skin, zt, zu, ni
                 assert r.get("backward_ratio_max", 0.0) <= 1.0, (algo, jt, k, r)
                 flagged += r["n_gt_tol"]
     assert flagged > 200, flagged          # the field is what it is meant to be: hundreds of values no forward bar can hold
+
+
+def test_the_tuner_reaches_its_targets(oracle):
+    """CPU: the fields are what the GPU test says they are (oracle only)."""
+    algo, skin, zt, zu, niter = "coare3p6", True, 18.0, 25.0, 5
+    f, which = adversarial_fields(oracle, algo, skin, zt, zu, niter, 1500, 900)
+    n = f["sst"].size
+    o = oracle.OracleSession(algo, n, 1, skin).compute(1, zt, zu, niter, *[f[k] for k in IN8[:6]], rad_sw=f["rad_sw"], rad_lw=f["rad_lw"], diag=True)
+    L = oracle.lib()
+    L.abo_q_sat.restype, L.abo_q_sat.argtypes = C.c_double, [C.c_double, C.c_double]
+    q_s = 0.98 * np.array([L.abo_q_sat(float(a), float(b)) for a, b in zip(o["t_s"], f["slp"])])
+    dq, dt = np.abs(o["q_zu"] - q_s), np.abs(o["t_zu"] - o["t_s"])
+    assert np.median(dq[which != 1]) < 2e-9 and np.median(dt[which != 0]) < 2e-6, (np.median(dq[which != 1]), np.median(dt[which != 0]))
+    assert np.all(np.isfinite(o["ql"])) and np.all(np.isfinite(o["qh"]))
+    assert o["Ce"].max() > 10.0              # the transfer coefficient of a vanishing difference: q* of the pass before over 1e-9 ... 1e-13
