@@ -20,8 +20,8 @@ ALGOS = {"coare3p0": 1, "coare3p6": 2, "ncar": 3, "ecmwf": 4, "andreas": 5}
 HUM_TYPES = {0: "sh", 1: "dp", 2: "rh"}
 HUM_IDS = {v: k for k, v in HUM_TYPES.items()}
 AB_MEM_HOST, AB_MEM_DEVICE = 0, 1
-AB_F64, AB_F32, AB_F32_STORAGE = 0, 1, 2
-PRECISIONS = {"f64": AB_F64, "f32": AB_F32, "f32_storage": AB_F32_STORAGE}   # f32_storage: fp32 arrays, fp64 arithmetic
+AB_F64, AB_F32, AB_F32_STORAGE, AB_F32_MIXED = 0, 1, 2, 3
+PRECISIONS = {"f64": AB_F64, "f32": AB_F32, "f32_storage": AB_F32_STORAGE, "f32_mixed": AB_F32_MIXED}   # f32_storage: fp32 arrays, fp64 arithmetic; f32_mixed: fp32 arrays, fp64 anchors
 AB_ERR_TAU = 8
 IN_NAMES = ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp", "rad_sw", "rad_lw")
 OUT_NAMES = ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")

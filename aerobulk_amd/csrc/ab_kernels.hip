@@ -51,20 +51,23 @@ template <class S> struct DiagArgs {
 // loads and stores stay coalesced and each field is still read once and written once.
 // One cell from its pre-processed inputs to the six outputs of aerobulk_compute: TURB_<algo> (mod_aerobulk_compute.f90
 // :129-176), BULK_FORMULA and the stress vector (:184-194).  k: global cell index (warm-layer state, diagnostics, longitude).
-template <class R, int ALGO, bool SKIN, bool DIAG, bool TILED = false, class S = R>
-__device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const DiagArgs<S> &dg, const Heights<R> &hh, int nb_iter, long k, R sst,
-                                             R theta_zt, R q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
-                                             R &zEvap, R &T_s, lds_cvptr<R> pu = nullptr, lds_cvptr<R> pv = nullptr,
+// A: anchor type of SST, theta, q (ab_physics.hpp, "ANCHORS"): R, or double with R = float in the mixed mode.
+template <class R, int ALGO, bool SKIN, bool DIAG, bool TILED = false, class S = R, class A = R>
+__device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const DiagArgs<S> &dg, const Heights<R> &hh, int nb_iter, long k, A sst,
+                                             A theta_zt, A q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
+                                             R &zEvap, A &T_s, lds_cvptr<R> pu = nullptr, lds_cvptr<R> pv = nullptr,
                                              lds_vptr<R> park = nullptr, int pstride = 0)
 {
     using M = Mth<R>;
-    CellIn<R> in;
+    constexpr bool kMixed = !std::is_same<R, A>::value;
+    CellIn<R, A> in;
     in.sst = sst;
     in.theta_zt = theta_zt;
     in.q_zt = q_zt;
     in.slp = slp;
     in.wnd = M::sqrt(uu * uu + vv * vv);                                       // :111
-    in.ssq = rounded(K<R>::rdct_qsat_salt * q_sat<R, (TILED && SKIN && kPsiTabDefault)>(sst, slp));   // :114 (e_sat from its LDS table in the tiled kernels with the skin schemes only)
+    // :114 (e_sat from its LDS table in the tiled fp64 kernels with the skin schemes, and in every tiled mixed kernel)
+    in.ssq = rounded(K<A>::rdct_qsat_salt * q_sat<A, (TILED && (SKIN || kMixed) && kPsiTabDefault)>(sst, A(slp)));
     in.qsw = qsw;
     in.rlw = rlw;
 
@@ -81,15 +84,15 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
         if (ALGO != 4) dawn = a.lon ? wl_coare_dawn<R>((R)a.lon[k], a.isecday) : (a.dawn_uniform != 0);
     }
 
-    CellOut<R> o;
+    CellOut<R, A> o;
     constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
-    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG>(hh, in, nb_iter, wl, dawn, o, park, pstride);
-    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG>(hh, in, nb_iter, wl, dawn, o, park, pstride);
-    else if (ALGO == 3) turb_ncar<R, DIAG>(hh, in, nb_iter, o);
-    else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG>(hh, in, nb_iter, wl, o);
-    else turb_andreas<R, DIAG>(hh, in, nb_iter, o);
+    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG, A>(hh, in, nb_iter, wl, dawn, o, park, pstride);
+    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A>(hh, in, nb_iter, wl, dawn, o, park, pstride);
+    else if (ALGO == 3) turb_ncar<R, DIAG, A>(hh, in, nb_iter, o);
+    else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG, A>(hh, in, nb_iter, wl, o);
+    else turb_andreas<R, DIAG, A>(hh, in, nb_iter, o);
     if (DIAG) {
-        const R d[16] = {o.Cd, o.Ch, o.Ce, o.t_zu, o.q_zu, o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
+        const R d[16] = {o.Cd, o.Ch, o.Ce, R(o.t_zu), R(o.q_zu), o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
                          o.dT_cs, o.dT_wl, o.Hz_wl};
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -102,7 +105,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     }
 
     R zTaum;
-    bulk_formula(hh.zu, o.T_s, o.q_s, o.t_zu, o.q_zu, o.Cd, o.Ch, o.Ce, in.wnd, o.Ubzu, slp, zTaum, QH, QL, zEvap);
+    bulk_formula<R, A>(hh.zu, o.T_s, o.q_s, o.t_zu, o.q_zu, o.Cd, o.Ch, o.Ce, in.wnd, o.Ubzu, slp, zTaum, QH, QL, zEvap);
     if (zTaum > R(10.)) atomicOr(a.flags, 1);                                  // mod_phymbl.f90:1250-1253
     tx = R(0.);
     ty = R(0.);
@@ -120,25 +123,29 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     T_s = o.T_s;
 }
 
-template <class R, int ALGO, bool SKIN, bool DIAG, class S = R>
+// A: the anchor type (ab_physics.hpp, "ANCHORS").  A = R for the fp64 and fp32 sessions; AB_F32_MIXED is <R = float, S = float,
+// A = double>: fp32 arrays and fp32 hardware transcendentals, with SST, theta, q, T_s, q_s, their differences and q_sat in fp64.
+template <class R, int ALGO, bool SKIN, bool DIAG, class S = R, class A = R>
 // (the DIAG instantiations carry sixteen more live values: four waves per SIMD, on the tiles sized for Tile::kOcc)
-__global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO, SKIN>::kOcc)) flux_kernel(const FluxArgs<R, S> a, const DiagArgs<S> dg)
+__global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO, SKIN, !std::is_same<R, A>::value>::kOcc)) flux_kernel(const FluxArgs<R, S> a, const DiagArgs<S> dg)
 {
+    constexpr bool kMixed = !std::is_same<R, A>::value;
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
         const bool live = k < a.n;
         // the cell's loads are in flight while the block fills its math tables
         R slp = R(101000.), t_zt = R(290.), hum = R(0.01), sst = R(290.), uu = R(1.), vv = R(1.);
         if (live) { slp = (R)a.slp[k]; t_zt = (R)a.t_zt[k]; hum = (R)a.hum[k]; sst = (R)a.sst[k]; uu = (R)a.u[k]; vv = (R)a.v[k]; }
-        math_tables_init<R>();
+        math_tables_init<A>();
         if (!live) return;
-        R q_zt;
-        if (a.hum_type == 0) q_zt = hum;
-        else if (a.hum_type == 1) q_zt = q_air_dp<R, false>(hum, vmax(slp, R(50000.)));
-        else q_zt = q_air_rh<R, false>(hum, t_zt, vmax(slp, R(50000.)));
-        R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG, false, S>(a, dg, a.h, a.nb_iter, k, sst, theta_from_z_p0_t_q<R, false>(a.h.zt, slp, t_zt, q_zt), q_zt,
-                                                    uu, vv, slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
+        A q_zt;
+        if (a.hum_type == 0) q_zt = A(hum);
+        else if (a.hum_type == 1) q_zt = q_air_dp<A, false>(A(hum), A(vmax(slp, R(50000.))));
+        else q_zt = q_air_rh<A, false>(A(hum), A(t_zt), A(vmax(slp, R(50000.))));
+        R QL, QH, tx, ty, zEvap;
+        A T_s;
+        compute_cell<R, ALGO, SKIN, DIAG, false, S, A>(a, dg, a.h, a.nb_iter, k, A(sst), theta_from_z_p0_t_q<A, false>(A(a.h.zt), A(slp), A(t_zt), q_zt), q_zt,
+                                                       uu, vv, slp, R(0.), R(0.), QL, QH, tx, ty, zEvap, T_s);
         a.ql[k] = (S)QL;
         a.qh[k] = (S)QH;
         a.tau_x[k] = (S)tx;
@@ -147,7 +154,10 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
         if (a.t_s) a.t_s[k] = (S)T_s;
         return;
     }
-    using T = Tile<R, ALGO, SKIN>;
+    using T = Tile<R, ALGO, SKIN, kMixed>;
+    // field rows: sst theta q_zt u v slp [qsw rlw]; mixed: one more row at the end, the low part of theta (theta is an fp64 anchor
+    // parked as a float pair; sst and q_zt are fp32 numbers anyway, exactly in 'sh' mode and to half an fp32 ulp otherwise)
+    constexpr int kThLo = T::kFields - 1;
     __shared__ R s_f[T::kFields][T::kCells];
     __shared__ unsigned short s_inv[T::kCells];
     __shared__ unsigned s_cnt[kSortCounters], s_base[kSortCounters];
@@ -174,8 +184,9 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     tile_sort_reset(s_cnt, tid);
     if constexpr (sizeof(R) == 8) psi_tables_fill<SKIN>();   // (before the barrier of math_tables_init)
     else psi_tables_fill32();                             // (before the barrier below)
-    math_tables_init<R>();
-    if (sizeof(R) != 8) __syncthreads();                  // (fp64: the barrier of math_tables_init) counters zeroed before phase 1
+    if constexpr (kMixed) esat_table_fill();              // q_sat of the mixed mode is the fp64 one, through its LDS table
+    math_tables_init<A>();
+    if (sizeof(A) != 8) __syncthreads();                  // (fp64: the barrier of math_tables_init) counters zeroed before phase 1
 #pragma unroll 1
     for (int r = 0; r < rounds; ++r) {
         const int j = r * kBlock + tid;
@@ -185,12 +196,14 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
         int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
         if (k < a.n) {
             const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
-            R q_zt;
-            if (a.hum_type == 0) q_zt = hum;                                        // 'sh'
-            else if (a.hum_type == 1) q_zt = q_air_dp<R, SKIN && kPsiTabDefault>(hum, vmax(slp, R(50000.)));   // 'dp' :103
-            else q_zt = q_air_rh<R, SKIN && kPsiTabDefault>(hum, t_zt, vmax(slp, R(50000.)));                  // 'rh' :105
-            const R theta = theta_from_z_p0_t_q<R, SKIN && kPsiTabDefault>(a.h.zt, slp, t_zt, q_zt);           // :118
-            s_f[0][j] = sst; s_f[1][j] = theta; s_f[2][j] = q_zt; s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
+            constexpr bool kEsatTab = (SKIN || kMixed) && kPsiTabDefault;
+            A q_zt;
+            if (a.hum_type == 0) q_zt = A(hum);                                     // 'sh'
+            else if (a.hum_type == 1) q_zt = q_air_dp<A, kEsatTab>(A(hum), A(vmax(slp, R(50000.))));   // 'dp' :103
+            else q_zt = q_air_rh<A, kEsatTab>(A(hum), A(t_zt), A(vmax(slp, R(50000.))));              // 'rh' :105
+            const A theta = theta_from_z_p0_t_q<A, kEsatTab>(A(a.h.zt), A(slp), A(t_zt), q_zt);       // :118
+            s_f[0][j] = sst; s_f[1][j] = R(theta); s_f[2][j] = R(q_zt); s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
+            if constexpr (kMixed) s_f[kThLo][j] = R(theta - A(R(theta)));
             R qsw = R(0.), rlw = R(0.);
             if (SKIN) {
                 qsw = (R(1.) - K<R>::roce_alb0) * w.rsw;                            // :135,146,161
@@ -232,14 +245,17 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
         const long k = tile0 + j;
         if (k >= a.n) continue;
 
-        R QL, QH, tx, ty, zEvap, T_s;
-        compute_cell<R, ALGO, SKIN, DIAG, true, S>(a, dg, hh, nb_iter, k, s_f[0][j], s_f[1][j], s_f[2][j], s_f[3][j], s_f[4][j], s_f[5][j],
+        R QL, QH, tx, ty, zEvap;
+        A T_s;
+        A theta = A(s_f[1][j]);
+        if constexpr (kMixed) theta = theta + A(s_f[kThLo][j]);
+        compute_cell<R, ALGO, SKIN, DIAG, true, S, A>(a, dg, hh, nb_iter, k, A(s_f[0][j]), theta, A(s_f[2][j]), s_f[3][j], s_f[4][j], s_f[5][j],
                                           SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
                                           ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
                                           // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare
                                           (SKIN && sizeof(R) == 8) ? (lds_vptr<R>)&s_f[0][j] : (lds_vptr<R>)nullptr, T::kCells);
         // the cell's LDS slot is read by this lane only: reuse it for the results
-        s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = T_s;
+        s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = R(T_s);
     }
     __syncthreads();
 
@@ -258,8 +274,9 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     }
 }
 
-template <class R, int ALGO, bool SKIN, class S = R> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
+template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
 {
+    using T = Tile<R, ALGO, SKIN, !std::is_same<R, A>::value>;
     DiagArgs<S> dg;
     bool diag = false;
     for (int i = 0; i < 16; ++i) { dg.p[i] = (S *)c.diag[i]; diag = diag || (c.diag[i] != nullptr); }
@@ -277,30 +294,31 @@ template <class R, int ALGO, bool SKIN, class S = R> static hipError_t launch_t(
     a.isecday = c.isecday;
     a.dawn_uniform = dawn_at_lon0(c.isecday);
     a.regroup = c.regroup ? 1 : 0;
-    const long rounds = tile_rounds(c.n, Tile<R, ALGO, SKIN>::kRounds, Tile<R, ALGO, SKIN>::kOcc);
+    const long rounds = tile_rounds(c.n, T::kRounds, T::kOcc);
     a.rounds = (int)rounds;
     const long tile = (ALGO == 3) ? kBlock : rounds * kBlock;
     const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;
-    if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true, S>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
-    else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false, S>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
+    if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true, S, A>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
+    else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false, S, A>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     return hipGetLastError();
 }
 
-template <class R, class S = R> static hipError_t launch_r(const FluxCall &c, hipStream_t s)
+template <class R, class S = R, class A = R> static hipError_t launch_r(const FluxCall &c, hipStream_t s)
 {
     switch (c.algo) {
-    case 1: return c.skin ? launch_t<R, 1, true, S>(c, s) : launch_t<R, 1, false, S>(c, s);
-    case 2: return c.skin ? launch_t<R, 2, true, S>(c, s) : launch_t<R, 2, false, S>(c, s);
-    case 3: return launch_t<R, 3, false, S>(c, s);
-    case 4: return c.skin ? launch_t<R, 4, true, S>(c, s) : launch_t<R, 4, false, S>(c, s);
-    case 5: return launch_t<R, 5, false, S>(c, s);
+    case 1: return c.skin ? launch_t<R, 1, true, S, A>(c, s) : launch_t<R, 1, false, S, A>(c, s);
+    case 2: return c.skin ? launch_t<R, 2, true, S, A>(c, s) : launch_t<R, 2, false, S, A>(c, s);
+    case 3: return launch_t<R, 3, false, S, A>(c, s);
+    case 4: return c.skin ? launch_t<R, 4, true, S, A>(c, s) : launch_t<R, 4, false, S, A>(c, s);
+    case 5: return launch_t<R, 5, false, S, A>(c, s);
     default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_flux(const FluxCall &c, hipStream_t stream)
 {
+    if (c.f32 && c.compute64 == 2) return launch_r<float, float, double>(c, stream);   // AB_F32_MIXED
     if (c.f32 && c.compute64) return launch_r<double, float>(c, stream);   // AB_F32_STORAGE
     return c.f32 ? launch_r<float>(c, stream) : launch_r<double>(c, stream);
 }

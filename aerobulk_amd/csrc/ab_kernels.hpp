@@ -20,7 +20,7 @@ struct FluxCall {
     int algo;       // enum ab_algo
     int skin;       // cool-skin + warm-layer
     int f32;        // element type of the arrays
-    int compute64;  // with f32: fp64 arithmetic on fp32 arrays (AB_F32_STORAGE)
+    int compute64;  // with f32: 1 = fp64 arithmetic on fp32 arrays (AB_F32_STORAGE), 2 = fp64 anchors, fp32 elsewhere (AB_F32_MIXED)
     int nb_iter;
     int hum_type;   // enum ab_hum
     int wl_load;    // jt > 1: read state ; else initial values

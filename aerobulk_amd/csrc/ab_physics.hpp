@@ -299,6 +299,11 @@ template <bool ESAT = true> __device__ __forceinline__ void psi_tables_fill()
     if constexpr (ESAT)
         for (int t = (int)threadIdx.x; t < kTabTotal - kTabOff[2]; t += (int)blockDim.x) s_esattab[t] = kEsatTab[t];
 }
+// the e_sat table alone (the mixed kernels: fp32 psi tables, fp64 q_sat); all threads, before the barrier of math_tables_init()
+__device__ __forceinline__ void esat_table_fill()
+{
+    for (int t = (int)threadIdx.x; t < kTabTotal - kTabOff[2]; t += (int)blockDim.x) s_esattab[t] = kEsatTab[t];
+}
 template <int WHICH> __device__ __forceinline__ double psi_tab_coef(int k, int i)
 {
     if constexpr (WHICH == kTabEsat) return s_esattab[k * kTabNint[WHICH] + i];
@@ -509,41 +514,44 @@ template <class R> __device__ __forceinline__ R one_on_l(R pThta, R pqa, R pus, 
     return sclamp(r, R(200.));
 }
 // Ri_bulk_sclr :712-747 (layer arguments are never passed on this path)
-template <class R> __device__ __forceinline__ R ri_bulk(R pz, R psst, R pThta, R pssq, R pqa, R pub)
+// A: anchor type of the temperatures and humidities (A = R, or double with R = float in the mixed mode: the difference of the two
+// virtual temperatures is formed from the anchors, everything after it in R — see "anchors" at CellIn)
+template <class R, class A = R> __device__ __forceinline__ R ri_bulk(R pz, A psst, A pThta, A pssq, A pqa, R pub)
 {
     AB_REGION("ri_bulk");
-    const R zsstv = virt_temp(psst, pssq);
-    const R zdthv = virt_temp(pThta, pqa) - zsstv;
-    const R ztv = R(0.5) * (zsstv + virt_temp(pThta - K<R>::rgamma_dry * pz, pqa));
+    const A zsstv = virt_temp(psst, pssq);
+    const R zdthv = R(virt_temp(pThta, pqa) - zsstv);
+    const R ztv = R(0.5) * (R(zsstv) + virt_temp(R(pThta) - K<R>::rgamma_dry * pz, R(pqa)));
     return Mth<R>::div(K<R>::grav * zdthv * pz, ztv * pub * pub);
 }
 // BULK_FORMULA_SCLR :1149-1203 (open ocean: l_ice false)
-template <class R>
-__device__ __forceinline__ void bulk_formula(R pzu, R pts, R pqs, R pThta, R pqa, R pCd, R pCh, R pCe, R pwnd,
+template <class R, class A = R>
+__device__ __forceinline__ void bulk_formula(R pzu, A pts, A pqs, A pThta, A pqa, R pCd, R pCh, R pCe, R pwnd,
                                              R pUb, R pslp, R &pTau, R &pQsen, R &pQlat, R &pEvap)
 {
-    const R zta = pThta - K<R>::rgamma_dry * pzu;
+    const R zta = R(pThta) - K<R>::rgamma_dry * pzu;
     // rho_air twice (:1183-1184) with the same denominator: one reciprocal
-    const R zir = Mth<R>::rcp(K<R>::R_dry * zta * (R(1.) + K<R>::rctv0 * pqa));
+    const R zir = Mth<R>::rcp(K<R>::R_dry * zta * (R(1.) + K<R>::rctv0 * R(pqa)));
     R zrho = vmax(pslp * zir, R(0.8));
     zrho = vmax((pslp - zrho * K<R>::grav * pzu) * zir, R(0.8));
     const R zUrho = pUb * vmax(zrho, R(1.));
     pTau = zUrho * pCd * pwnd;
-    pEvap = zUrho * pCe * (pqa - pqs);
-    pQsen = zUrho * pCh * (pThta - pts) * (K<R>::rCp_dry + K<R>::rCp_vap * pqa);
-    pQlat = (R(2.501) - R(0.00237) * (pts - K<R>::rt0)) * R(1.e6) * pEvap;  // L_vap :590
+    pEvap = zUrho * pCe * R(pqa - pqs);
+    pQsen = zUrho * pCh * R(pThta - pts) * (K<R>::rCp_dry + K<R>::rCp_vap * R(pqa));
+    pQlat = (R(2.501) - R(0.00237) * (R(pts) - K<R>::rt0)) * R(1.e6) * pEvap;  // L_vap :590
 }
 // UPDATE_QNSOL_TAU_SCLR :1059-1103 (+ qlw_net_sclr :1291-1314).  The routine forms Ch = (u*/Ub) theta*/zdt and Ce = (u*/Ub) q*/zdq
 // with zdt, zdq the floored air-sea differences (:1076-1077) and hands them to BULK_FORMULA, which multiplies them by the
 // unfloored differences again (:1190-1191): Ch (theta - T_s) = (u*/Ub) theta* exactly unless |theta - T_s| < 1e-9 (likewise q
 // with 1e-12).  The two divisions are therefore only executed on those (rare) lanes.
-template <class R>
-__device__ __forceinline__ void update_qnsol_tau(R pzu, R pts, R pqs, R pThta, R pqa, R pust, R ptst, R pqst,
+template <class R, class A = R>
+__device__ __forceinline__ void update_qnsol_tau(R pzu, A pts_a, A pqs, A pThta_a, A pqa_a, R pust, R ptst, R pqst,
                                                  R pwnd, R pUb, R pslp, R prlw, R &pQns, R &pTau, R &pQlat)
 {
     AB_REGION("update_qnsol_tau");
     using M = Mth<R>;
-    const R dth = pThta - pts, dq = pqa - pqs;
+    const R dth = R(pThta_a - pts_a), dq = R(pqa_a - pqs);
+    const R pts = R(pts_a), pThta = R(pThta_a), pqa = R(pqa_a);
     const R zz0 = M::div(pust, pUb);
     R chdt = zz0 * ptst, cedq = zz0 * pqst;                        // Ch (theta - T_s), Ce (q - q_s)
     if (M::abs(dth) < R(1.E-09)) chdt = M::div(chdt, sfloor(dth, R(1.E-09))) * dth;
@@ -629,7 +637,22 @@ template <class R> __device__ __forceinline__ R wl_absorb(R zHwl)
     const R a1 = zHwl * R(1. / 0.014), a2 = zHwl * R(1. / 0.357);
     const R e1 = a1 > R(40.) ? R(1.) : R(1.) - M::exp(-a1);
     const R e2 = a2 > R(40.) ? R(1.) : R(1.) - M::exp(-a2);
-    const R e3 = R(1.) - M::exp(zHwl * R(-1. / 12.82));
+    // the deepest band: H/12.82 is 0.008 ... 1.6 and 1 - exp(-x) cancels for small x.  fp64 has the digits to spare; fp32 (also the
+    // mixed mode) would leave 6e-8/x = 1e-5 in the absorbed fraction of a shallow, strongly heated layer, i.e. in its dT_wl of 1-3 K:
+    // below x = 0.35 the series x (1 - x/2 + x^2/6 - ...) to x^7 (truncation 3e-9 relative)
+    R e3;
+    if constexpr (sizeof(R) == 4) {
+        const R x = zHwl * R(1. / 12.82);
+        if (x < R(0.35)) {
+            R p = R(-1. / 5040.);
+            p = p * x + R(1. / 720.); p = p * x + R(-1. / 120.); p = p * x + R(1. / 24.); p = p * x + R(-1. / 6.); p = p * x + R(0.5);
+            e3 = x - (p * x) * x;
+        } else {
+            e3 = R(1.) - M::exp(-x);
+        }
+    } else {
+        e3 = R(1.) - M::exp(zHwl * R(-1. / 12.82));
+    }
     return R(1.) - M::div(R(0.28 * 0.014) * e1 + R(0.27 * 0.357) * e2 + R(0.45 * 12.82) * e3, zHwl);
 }
 template <class R>
@@ -891,20 +914,20 @@ template <class R> struct Heights {  // wave-uniform, prepared on the host
     R zt, zu, log_zt, log_zu, log_10, log_ztu, log_zu10, fg_ca, inv_zu, zt_o_zu;
     int zt_eq_zu;  // ABS(zu-zt) < 0.01
 };
-template <class R>
-__device__ __forceinline__ void first_guess_coare(const Heights<R> &h, R psst, R t_zt, R pssq, R q_zt, R U_zu,
-                                                  R pcharn, R &pus, R &pts, R &pqs, R &t_zu, R &q_zu, R &Ubzu,
+template <class R, class A = R>
+__device__ __forceinline__ void first_guess_coare(const Heights<R> &h, A psst, A t_zt, A pssq, A q_zt, R U_zu,
+                                                  R pcharn, R &pus, R &pts, R &pqs, A &t_zu, A &q_zu, R &Ubzu,
                                                   R &pz0)
 {
     AB_REGION("first_guess_coare");
     using M = Mth<R>;
     const R vk = K<R>::vkarmn;
-    t_zu = vmax(t_zt, R(180.));
-    q_zu = vmax(q_zt, R(1.e-6));
+    t_zu = vmax(t_zt, A(180.));
+    q_zu = vmax(q_zt, A(1.e-6));
     const R zc_b = R(0.004 * 600. * 1.2 * 1.2 * 1.2);
-    R zdt = sfloor(t_zu - psst, R(1.E-09));
-    R zdq = sfloor(q_zu - pssq, R(1.E-12));
-    const R zNu_a = visc_air(t_zu);
+    R zdt = sfloor(R(t_zu - psst), R(1.E-09));
+    R zdq = sfloor(R(q_zu - pssq), R(1.E-12));
+    const R zNu_a = visc_air(R(t_zu));
     const R zUb = M::sqrt_pos(U_zu * U_zu + R(0.25));
     R zus = h.fg_ca * zUb;  // zc_a = 0.035*LOG(10/z0)/LOG(zu/z0), z0 = 1e-4 :107
     R zz0 = pcharn * zus * zus * R(1. / 9.8) + M::div(R(0.11) * zNu_a, zus);
@@ -913,7 +936,7 @@ __device__ __forceinline__ void first_guess_coare(const Heights<R> &h, R psst, R
     const R zdl = h.log_zu - zlog_z0;
     // z0t = 10/exp(kappa/(0.00115 (ln10-ln z0)/kappa)) :130, clamped to [1e-8,1]; only its log is used
     const R zlog_z0t = vmin(vmax(h.log_10 - M::div(vk, R(0.00115) * ((h.log_10 - zlog_z0) * K<R>::inv_vk)), R(-18.420680743952367)), R(0.));
-    const R zRib = ri_bulk(h.zu, psst, t_zu, pssq, q_zu, zUb);
+    const R zRib = ri_bulk<R, A>(h.zu, psst, t_zu, pssq, q_zu, zUb);
     // kappa^2/(Cd (ln zt - ln z0t)) Ri, Cd = (kappa/(ln zu - ln z0))^2  :126,138-139
     const R zcc_ri = M::div(zdl * zdl, h.log_zt - zlog_z0t) * zRib;
     R zzeta_u;
@@ -928,11 +951,11 @@ __device__ __forceinline__ void first_guess_coare(const Heights<R> &h, R psst, R
     if (!h.zt_eq_zu) {
         const R zzeta_t = zzeta_u * h.zt_o_zu;
         const R zprf = h.log_ztu + psh - psi_h_coare<R>(zzeta_t);
-        t_zu = t_zt - zts * K<R>::inv_vk * zprf;
-        q_zu = q_zt - zqs * K<R>::inv_vk * zprf;
-        q_zu = nonneg(q_zu) ? q_zu : R(0.) * q_zu;
-        zdt = sfloor(t_zu - psst, R(1.E-09));
-        zdq = sfloor(q_zu - pssq, R(1.E-12));
+        t_zu = t_zt - A(zts * K<R>::inv_vk * zprf);
+        q_zu = q_zt - A(zqs * K<R>::inv_vk * zprf);
+        q_zu = nonneg(q_zu) ? q_zu : A(0.) * q_zu;
+        zdt = sfloor(R(t_zu - psst), R(1.E-09));
+        zdq = sfloor(R(q_zu - pssq), R(1.E-12));
         zts = zdt * ztmp;
         zqs = zdq * ztmp;
     }
@@ -942,12 +965,22 @@ __device__ __forceinline__ void first_guess_coare(const Heights<R> &h, R psst, R
 }
 
 // ---------------------------------------------------------------- per-cell inputs / outputs of a TURB_* routine
-template <class R> struct CellIn {
-    R sst, theta_zt, ssq, q_zt, wnd, slp;  // after the pre-processing of aerobulk_compute :99-126
+// ANCHORS.  Temperatures and humidities — SST, theta, T_s, q, q_s — are the quantities whose DIFFERENCES drive the fluxes
+// (theta_zu - T_s ~ 1 K of 300, q_zu - q_s ~ 1e-3 of 1e-2): they are carried in the anchor type A, everything else (profile
+// functions, roughness lengths, scales, skin increments) in R.  A = R for the fp64 and the fp32 kernels.  The mixed mode
+// (AB_F32_MIXED: R = float, A = double) keeps the anchors, their differences and q_sat in fp64 and lets the hardware fp32
+// transcendentals do the rest: the fp32 kernels' speed without their 1e-3 errors (mod_blk_ecmwf.f90:556-561 warns about exactly
+// these differences in single precision).
+template <class R, class A = R> struct CellIn {
+    A sst, theta_zt, ssq, q_zt;            // after the pre-processing of aerobulk_compute :99-126
+    R wnd, slp;
     R qsw, rlw;                            // (1-albedo)*rad_sw, rad_lw   (skin only)
 };
-template <class R> struct CellOut {
-    R Cd, Ch, Ce, t_zu, q_zu, Ubzu, T_s, q_s;
+template <class R, class A = R> struct CellOut {
+    R Cd, Ch, Ce;
+    A t_zu, q_zu;
+    R Ubzu;
+    A T_s, q_s;
     // OPTIONAL outputs of the TURB_* routines (CdN ChN CeN xz0 xu_star xL xUN10 pdT_cs pdT_wl pHz_wl), filled only by the
     // DIAG instantiations (ab_session_set_diagnostics); dead code otherwise
     R CdN, ChN, CeN, z0, us, L, UN10, dT_cs, dT_wl, Hz_wl;
@@ -961,24 +994,24 @@ constexpr int kSkinCS = 1, kSkinWL = 2, kSkinBoth = 3;
 // park / pstride: optional per-lane scratch words park[i * pstride], i = 0,1,2,5,6 (LDS slots of the caller's tile).  The warm-layer state beyond dT_wl and the
 // two WL_COARE constants are only touched by the live WL_COARE calls (jit = 1 and the divisors of nb_iter): parked there they
 // do not hold ten VGPRs across the rest of the iteration (the COARE + skin kernels sit at the 128-VGPR limit).
-template <class R, bool V36, int SKIN, bool DIAG = false>
-__device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
-                                           bool dawn, CellOut<R> &o, lds_vptr<R> park = nullptr, int pstride = 0)
+template <class R, bool V36, int SKIN, bool DIAG = false, class A = R>
+__device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R, A> &in, int nb_iter, R (&wl)[4],
+                                           bool dawn, CellOut<R, A> &o, lds_vptr<R> park = nullptr, int pstride = 0)
 {
     using M = Mth<R>;
     const R vk = K<R>::vkarmn;
     const R Beta0 = V36 ? R(1.2) : R(1.25);
     const R zi0 = R(600.), zeta_max = R(50.);
     const R zUzu = in.wnd;
-    const R xSST = in.sst;
-    R T_s = in.sst, q_s = in.ssq;
+    const A xSST = in.sst;
+    A T_s = in.sst, q_s = in.ssq;
     R zalpha = R(0.);
     WlCoareCell<R> wc{R(0.), R(0.), dawn};
     constexpr bool CS = (SKIN & kSkinCS) != 0, WL = (SKIN & kSkinWL) != 0;
     if (SKIN) {
-        if (CS) T_s = T_s - R(0.25);                                   // :274
-        q_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp));  // :275
-        zalpha = alpha_sw(xSST);                                       // hoisted from CS_COARE :81 / WL_COARE :153
+        if (CS) T_s = T_s - A(0.25);                                   // :274
+        q_s = rounded(K<A>::rdct_qsat_salt * q_sat(vmax(T_s, A(200.)), A(in.slp)));  // :275
+        zalpha = alpha_sw(R(xSST));                                    // hoisted from CS_COARE :81 / WL_COARE :153
         if (WL) {
             const R Rich0 = R(0.65);
             wc.zcd1 = M::sqrt(M::div(R(2.) * Rich0 * K<R>::rCp0_w, zalpha * K<R>::grav * K<R>::rho0_w));   // :155
@@ -991,21 +1024,22 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
         park[0] = wl[1]; park[pstride] = wl[2]; park[2 * pstride] = wl[3];
         park[5 * pstride] = wc.zcd1; park[6 * pstride] = wc.zcd2;
     }
-    R zus, zts, zqs, t_zu, q_zu, Ubzu, zz0;
-    first_guess_coare(h, T_s, in.theta_zt, q_s, in.q_zt, zUzu, V36 ? charn_coare3p6(zUzu) : charn_coare3p0(zUzu),
-                      zus, zts, zqs, t_zu, q_zu, Ubzu, zz0);
+    R zus, zts, zqs, Ubzu, zz0;
+    A t_zu, q_zu;
+    first_guess_coare<R, A>(h, T_s, in.theta_zt, q_s, in.q_zt, zUzu, V36 ? charn_coare3p6(zUzu) : charn_coare3p0(zUzu),
+                            zus, zts, zqs, t_zu, q_zu, Ubzu, zz0);
     R zlog_z0 = M::log(zz0);
-    const R znu_a = visc_air(V36 ? t_zu : in.theta_zt);  // 3p6 :294 (first-guess t_zu) vs 3p0 :237 (t_zt)
+    const R znu_a = visc_air(R(V36 ? t_zu : in.theta_zt));  // 3p6 :294 (first-guess t_zu) vs 3p0 :237 (t_zt)
     const R zlog_nu = M::log(znu_a);
-    R zdt = sfloor(t_zu - T_s, R(1.E-09));
-    R zdq = sfloor(q_zu - q_s, R(1.E-12));
+    R zdt = sfloor(R(t_zu - T_s), R(1.E-09));
+    R zdq = sfloor(R(q_zu - q_s), R(1.E-12));
     R zdT_cs = R(0.);
     R d_1oL = R(0.), d_lz0t = R(0.);   // DIAG only
 
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
         const R zus2 = zus * zus;
-        const R z1oL = one_on_l(t_zu, q_zu, zus, zts, zqs);            // :307-308 (second clamp is idempotent)
+        const R z1oL = one_on_l(R(t_zu), R(q_zu), zus, zts, zqs);      // :307-308 (second clamp is idempotent)
         // gustiness :311-313: Ug^2 = Beta0^2 u*^2 (max(-zi0/(kappa L),0))^(2/3)
         const R zg = vmax(-zi0 * z1oL * K<R>::inv_vk, R(0.));
         const R zcb = M::cbrt(zg);
@@ -1035,21 +1069,21 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
         if (!h.zt_eq_zu) {                                             // :346-351 (3p0 :289-291 with zm_ztzu = 1)
             const R zzta_t = sclamp(h.zt * z1oL, zeta_max);
             ztmp1 = h.log_zt - h.log_zu + psh - psi_h_coare<R>(zzta_t);
-            t_zu = in.theta_zt - zts * K<R>::inv_vk * ztmp1;
-            q_zu = in.q_zt - zqs * K<R>::inv_vk * ztmp1;
+            t_zu = in.theta_zt - A(zts * K<R>::inv_vk * ztmp1);
+            q_zu = in.q_zt - A(zqs * K<R>::inv_vk * ztmp1);
         } else if (!V36) {                                             // 3p0: t_zu = t_zt - 0*...  (drops the 180 K floor)
             t_zu = in.theta_zt;
             q_zu = in.q_zt;
         }
         if (CS) {
             R zQns, zTau, zQlat;
-            update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
-                             zQlat);                                   // :355-356
+            update_qnsol_tau<R, A>(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
+                                   zQlat);                             // :355-356
             zdT_cs = cool_skin<R, true>(in.qsw, zQns, zus, zalpha, zQlat);  // :358
-            T_s = xSST + zdT_cs;
-            if (WL) T_s = T_s + wl[0];                                 // :360-361
+            T_s = xSST + A(zdT_cs);
+            if (WL) T_s = T_s + A(wl[0]);                              // :360-361
             // with the warm layer on, this q_s is only read by the UPDATE_QNSOL_TAU of a live WL_COARE call (below)
-            if (!WL || (nb_iter % jit) == 0) q_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp));
+            if (!WL || (nb_iter % jit) == 0) q_s = rounded(K<A>::rdct_qsat_salt * q_sat(vmax(T_s, A(200.)), A(in.slp)));
         }
         if (WL) {
             // WL_COARE is called with iwait = MOD(nb_iter,jit) (:370) and writes its state (dT_wl, Hz_wl, Qnt_ac, Tau_ac)
@@ -1057,8 +1091,8 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
             // iterations (jit = 2,3,4 of 5) the call and the UPDATE_QNSOL_TAU feeding it have no effect: skipped.
             if ((nb_iter % jit) == 0) {
                 R zQns, zTau, zQlat;
-                update_qnsol_tau(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
-                                 zQlat);                               // :367-368
+                update_qnsol_tau<R, A>(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
+                                       zQlat);                         // :367-368
                 if (parked) {
                     wl[1] = park[0]; wl[2] = park[pstride]; wl[3] = park[2 * pstride];
                     wc.zcd1 = park[5 * pstride]; wc.zcd2 = park[6 * pstride];
@@ -1066,13 +1100,13 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R> 
                 wl_coare(wl, wc, in.qsw, zQns, zTau, true);            // :370
                 if (parked) { park[0] = wl[1]; park[pstride] = wl[2]; park[2 * pstride] = wl[3]; }
             }
-            T_s = xSST + wl[0];
-            if (CS) T_s = T_s + zdT_cs;                                // :373-374
-            q_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(T_s, R(200.)), in.slp));
+            T_s = xSST + A(wl[0]);
+            if (CS) T_s = T_s + A(zdT_cs);                             // :373-374
+            q_s = rounded(K<A>::rdct_qsat_salt * q_sat(vmax(T_s, A(200.)), A(in.slp)));
         }
         if (!V36 || SKIN || !h.zt_eq_zu) {                             // :378-381 (3p0 :317-318 unconditional)
-            zdt = sfloor(t_zu - T_s, R(1.E-09));
-            zdq = sfloor(q_zu - q_s, R(1.E-12));
+            zdt = sfloor(R(t_zu - T_s), R(1.E-09));
+            zdq = sfloor(R(q_zu - q_s), R(1.E-12));
         }
     }
     if (parked) { wl[1] = park[0]; wl[2] = park[pstride]; wl[3] = park[2 * pstride]; }
@@ -1146,30 +1180,32 @@ template <class R> __device__ __forceinline__ R psi_h_ecmwf_z0(R z)
 }
 
 // turb_ecmwf :63-383
-template <class R, int SKIN, bool DIAG = false>
-__device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> &in, int nb_iter, R (&wl)[4],
-                                           CellOut<R> &o)
+template <class R, int SKIN, bool DIAG = false, class A = R>
+__device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R, A> &in, int nb_iter, R (&wl)[4],
+                                           CellOut<R, A> &o)
 {
     using M = Mth<R>;
     const R vk = K<R>::vkarmn;
     const R charn0 = R(0.018), zi0 = R(1000.), alpha_M = R(0.11), alpha_H = R(0.40), alpha_Q = R(0.62);
     const R zm_ztzu = h.zt_eq_zu ? R(0.) : R(1.);
-    const R zUzu = in.wnd, zSST = in.sst;
-    R zT_s = in.sst, zq_s = in.ssq;
+    const R zUzu = in.wnd;
+    const A zSST = in.sst;
+    A zT_s = in.sst, zq_s = in.ssq;
     R zalpha = R(0.);
     constexpr bool CS = (SKIN & kSkinCS) != 0, WL = (SKIN & kSkinWL) != 0;
     if (SKIN) {
-        if (CS) zT_s = zT_s - R(0.25);                                  // :214
-        zq_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp));
-        zalpha = alpha_sw(zSST);
+        if (CS) zT_s = zT_s - A(0.25);                                  // :214
+        zq_s = rounded(K<A>::rdct_qsat_salt * q_sat(vmax(zT_s, A(200.)), A(in.slp)));
+        zalpha = alpha_sw(R(zSST));
     }
-    R zus, zts, zqs, zt_zu, zq_zu, zUbzu, zz0;
-    first_guess_coare(h, zT_s, in.theta_zt, zq_s, in.q_zt, zUzu, charn0, zus, zts, zqs, zt_zu, zq_zu, zUbzu, zz0);
+    R zus, zts, zqs, zUbzu, zz0;
+    A zt_zu, zq_zu;
+    first_guess_coare<R, A>(h, zT_s, in.theta_zt, zq_s, in.q_zt, zUzu, charn0, zus, zts, zqs, zt_zu, zq_zu, zUbzu, zz0);
     R zlog_z0 = M::log(zz0);
-    const R znu_a = visc_air(in.theta_zt);                              // :238
-    R zdt = sfloor(zt_zu - zT_s, R(1.E-09));
-    R zdq = sfloor(zq_zu - zq_s, R(1.E-12));
-    R z1oL = one_on_l(zt_zu, zq_zu, zus, zts, zqs);                     // :245
+    const R znu_a = visc_air(R(in.theta_zt));                           // :238
+    R zdt = sfloor(R(zt_zu - zT_s), R(1.E-09));
+    R zdq = sfloor(R(zq_zu - zq_s), R(1.E-12));
+    R z1oL = one_on_l(R(zt_zu), R(zq_zu), zus, zts, zqs);               // :245
     R zzeta_u = h.zu * z1oL;
     // :249  z0t = 1/(0.1 exp(kappa/(0.00115/(kappa/(ln10 - ln z0)))))
     // :249  z0t = 1/(0.1 exp(kappa/(0.00115/(kappa/(ln10 - ln z0))))) clamped to [1e-9,1]; log and value both needed
@@ -1185,7 +1221,7 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
 
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
-        const R zRib = ri_bulk(h.zu, zT_s, zt_zu, zq_s, zq_zu, zUbzu);  // :261 (previous Ub, T_s, q_s)
+        const R zRib = ri_bulk<R, A>(h.zu, zT_s, zt_zu, zq_s, zq_zu, zUbzu);  // :261 (previous Ub, T_s, q_s)
         z1oL = sclamp(M::div(zRib * zFm * zFm, zFh) * h.inv_zu, R(200.));  // :264-266
         zzeta_u = h.zu * z1oL;
         psi_ecmwf<R>(zzeta_u, &zpsi_m_u, &zpsi_h_u);                    // :269-270
@@ -1212,34 +1248,34 @@ __device__ __forceinline__ void turb_ecmwf(const Heights<R> &h, const CellIn<R> 
         R ztmp1 = M::div(vk, h.log_zu - zlog_z0t - ztmp0);
         zts = zdt * ztmp1;
         ztmp1 = h.log_ztu + ztmp0 - zpsi_h_t + zpsi_h_z0t;
-        zt_zu = in.theta_zt - zm_ztzu * zts * K<R>::inv_vk * ztmp1;
+        zt_zu = in.theta_zt - A(zm_ztzu * zts * K<R>::inv_vk * ztmp1);
         ztmp0 = zpsi_h_u - zpsi_h_z0q;
         ztmp1 = M::div(vk, h.log_zu - zlog_z0q - ztmp0);
         zqs = zdq * ztmp1;
         ztmp1 = h.log_ztu + ztmp0 - zpsi_h_t + zpsi_h_z0q;
-        zq_zu = vmax(in.q_zt - zm_ztzu * zqs * K<R>::inv_vk * ztmp1, R(0.));
+        zq_zu = vmax(in.q_zt - A(zm_ztzu * zqs * K<R>::inv_vk * ztmp1), A(0.));
         zFm = h.log_zu - zlog_z0 - zpsi_m_u + zpsi_m_z0;                // :316-317
         zFh = h.log_zu - zlog_z0t - zpsi_h_u + zpsi_h_z0t;
         if (CS) {
             R zQns, zTau, zQlat;
-            update_qnsol_tau(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
-                             zQlat);                                    // :321-322
+            update_qnsol_tau<R, A>(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
+                                   zQlat);                              // :321-322
             zdT_cs = cool_skin<R, false>(in.qsw, zQns, zus, zalpha, R(0.));  // :324
-            zT_s = zSST + zdT_cs;
-            if (WL) zT_s = zT_s + wl[0];
-            zq_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp));
+            zT_s = zSST + A(zdT_cs);
+            if (WL) zT_s = zT_s + A(wl[0]);
+            zq_s = rounded(K<A>::rdct_qsat_salt * q_sat(vmax(zT_s, A(200.)), A(in.slp)));
         }
         if (WL) {
             R zQns, zTau, zQlat;
-            update_qnsol_tau(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
-                             zQlat);                                    // :333-334
+            update_qnsol_tau<R, A>(h.zu, zT_s, zq_s, zt_zu, zq_zu, zus, zts, zqs, zUzu, zUbzu, in.slp, in.rlw, zQns, zTau,
+                                   zQlat);                              // :333-334
             wl_ecmwf(wl[0], wl[1], wlc, in.qsw, zQns, zus, zalpha);     // :335
-            zT_s = zSST + wl[0];
-            if (CS) zT_s = zT_s + zdT_cs;
-            zq_s = rounded(K<R>::rdct_qsat_salt * q_sat(vmax(zT_s, R(200.)), in.slp));
+            zT_s = zSST + A(wl[0]);
+            if (CS) zT_s = zT_s + A(zdT_cs);
+            zq_s = rounded(K<A>::rdct_qsat_salt * q_sat(vmax(zT_s, A(200.)), A(in.slp)));
         }
-        zdt = sfloor(zt_zu - zT_s, R(1.E-09));                          // :342-343
-        zdq = sfloor(zq_zu - zq_s, R(1.E-12));
+        zdt = sfloor(R(zt_zu - zT_s), R(1.E-09));                       // :342-343
+        zdq = sfloor(R(zq_zu - zq_s), R(1.E-12));
     }
     const R zFq = h.log_zu - zlog_z0q - zpsi_h_u + zpsi_h_z0q;          // :356-359
     const R ziFm = M::div(K<R>::vkarmn2, zFm);
@@ -1284,12 +1320,12 @@ template <class R> __device__ __forceinline__ void psi_ncar(R z, R *pm, R *ph)
     }
 }
 // turb_ncar :57-240
-template <class R, bool DIAG = false>
-__device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &in, int nb_iter, CellOut<R> &o)
+template <class R, bool DIAG = false, class A = R>
+__device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R, A> &in, int nb_iter, CellOut<R, A> &o)
 {
     using M = Mth<R>;
     const R vk = K<R>::vkarmn;
-    const R sst = in.sst, ssq = in.ssq;
+    const A sst = in.sst, ssq = in.ssq;
     const R Ubzu = vmax(R(0.5), in.wnd);                                // :148
     bool stab = nonneg(virt_temp(in.theta_zt, in.q_zt) - virt_temp(sst, ssq));  // :158
     R zCdN = cd_n10_ncar(Ubzu);
@@ -1298,18 +1334,18 @@ __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &
     R Ce = vmax(R(1.e-3) * (R(34.6) * zsqrt_CdN), K<R>::Cx_min);         // ce_n10 :321
     R Ch = vmax(R(1.e-3) * zsqrt_CdN * (stab ? R(18.) : R(32.7)), K<R>::Cx_min);  // ch_n10 :301
     R zsqrt_Cd = zsqrt_CdN;
-    R t_zu = vmax(in.theta_zt, R(180.));
-    R q_zu = vmax(in.q_zt, R(1.e-6));
+    A t_zu = vmax(in.theta_zt, A(180.));
+    A q_zu = vmax(in.q_zt, A(1.e-6));
     R d_us = R(0.), d_1oL = R(0.), d_un10 = R(0.), d_chn = R(0.), d_cen = R(0.);   // DIAG only
 #pragma unroll 1
     for (int jit = 1; jit <= nb_iter; ++jit) {
-        const R zdt = t_zu - sst;                                       // :177-178 (not floored)
-        const R zdq = q_zu - ssq;
+        const R zdt = R(t_zu - sst);                                    // :177-178 (not floored)
+        const R zdq = R(q_zu - ssq);
         const R zus = zsqrt_Cd * Ubzu;
         const R zisq = M::rcp(zsqrt_Cd);
         const R zts = Ch * zisq * zdt;
         const R zqs = Ce * zisq * zdq;
-        const R z1oL = one_on_l(t_zu, q_zu, zus, zts, zqs);
+        const R z1oL = one_on_l(R(t_zu), R(q_zu), zus, zts, zqs);
         const R zeta_u = sclamp(h.zu * z1oL, R(10.));                   // :189-190
         R psm, psh;
         psi_ncar<R>(zeta_u, &psm, &psh);
@@ -1318,9 +1354,9 @@ __device__ __forceinline__ void turb_ncar(const Heights<R> &h, const CellIn<R> &
             R psht;
             psi_ncar<R>(zeta_t, nullptr, &psht);
             const R ztmp = h.log_ztu + psh - psht;
-            t_zu = in.theta_zt - zts * K<R>::inv_vk * ztmp;
-            q_zu = in.q_zt - zqs * K<R>::inv_vk * ztmp;
-            q_zu = vmax(R(0.), q_zu);
+            t_zu = in.theta_zt - A(zts * K<R>::inv_vk * ztmp);
+            q_zu = in.q_zt - A(zqs * K<R>::inv_vk * ztmp);
+            q_zu = vmax(A(0.), q_zu);
         }
         // UN10_from_CD mod_phymbl.f90:1545 with z0_from_Cd :1346:
         //   sqrt(Cd) Ub/kappa * ln(10/(zu exp(-(kappa/sqrt(Cd)+psi)))) = sqrt(Cd) Ub/kappa * (ln(10/zu) + kappa/sqrt(Cd) + psi)
@@ -1414,19 +1450,19 @@ template <class R> __device__ __forceinline__ void z0tq_lkb(R zrr, R pz0, R &z0t
     z0q = vmin(vmax(M::abs(rq), R(1.E-9)), R(0.05));
 }
 // turb_andreas :66-272
-template <class R, bool DIAG = false>
-__device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R> &in, int nb_iter, CellOut<R> &o)
+template <class R, bool DIAG = false, class A = R>
+__device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R, A> &in, int nb_iter, CellOut<R, A> &o)
 {
     using M = Mth<R>;
     const R vk = K<R>::vkarmn;
-    const R psst = in.sst, pssq = in.ssq;
+    const A psst = in.sst, pssq = in.ssq;
     const R pUbzu = vmax(R(0.25), in.wnd);                              // :157
     const R ziUb = M::rcp(pUbzu);
     R UN10 = pUbzu;
-    R pt_zu = in.theta_zt, pq_zu = in.q_zt;
-    R t_star = R(0.03316624790355400) * (pt_zu - psst);                 // Ch/SQRT(Cd), Cd=Ch=Ce=1.1e-3 :161-170
-    R q_star = R(0.03316624790355400) * (pq_zu - pssq);
-    R RiB = ri_bulk(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);             // :173
+    A pt_zu = in.theta_zt, pq_zu = in.q_zt;
+    R t_star = R(0.03316624790355400) * R(pt_zu - psst);                // Ch/SQRT(Cd), Cd=Ch=Ce=1.1e-3 :161-170
+    R q_star = R(0.03316624790355400) * R(pq_zu - pssq);
+    R RiB = ri_bulk<R, A>(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);       // :173
     R u_star = R(0.);
     R d_z0 = R(0.), d_zeta = R(0.);   // DIAG only
 #pragma unroll 1
@@ -1437,31 +1473,31 @@ __device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R
         } else {
             u_star = R(0.01) * pUbzu;                                   // SQRT(Cx_min) = 1e-2
         }
-        const R zeta_u = h.zu * one_on_l(pt_zu, pq_zu, u_star, t_star, q_star);  // :200
+        const R zeta_u = h.zu * one_on_l(R(pt_zu), R(pq_zu), u_star, t_star, q_star);  // :200
         R ztmp0 = u_star * ziUb;
         const R pCd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);                // :209
         const R psm = psi_m_andreas<R>(zeta_u);
         const R z0 = vmin(h.zu * M::exp(-(M::div(vk, M::sqrt_pos(pCd)) + psm)), K<R>::z0_sea_max);  // :214
         if (DIAG) { d_z0 = z0; d_zeta = zeta_u; }
-        ztmp0 = M::div(z0 * u_star, visc_air(pt_zu));                   // :219 Re_r
+        ztmp0 = M::div(z0 * u_star, visc_air(R(pt_zu)));                // :219 Re_r
         R z0t, z0q;
         z0tq_lkb(ztmp0, z0, z0t, z0q);                                  // :220-221
         const R psh = psi_h_andreas<R>(zeta_u);
-        t_star = M::div((pt_zu - psst) * vk, h.log_zu - M::log(z0t) - psh);  // :226-227
-        q_star = M::div((pq_zu - pssq) * vk, h.log_zu - M::log(z0q) - psh);
+        t_star = M::div(R(pt_zu - psst) * vk, h.log_zu - M::log(z0t) - psh);  // :226-227
+        q_star = M::div(R(pq_zu - pssq) * vk, h.log_zu - M::log(z0q) - psh);
         if ((!h.zt_eq_zu) && (jit > 1)) {                               // :229-236
             const R zeta_t = zeta_u * h.zt_o_zu;
             const R zp = h.log_ztu + psh - psi_h_andreas<R>(zeta_t);
-            pt_zu = in.theta_zt - t_star * K<R>::inv_vk * zp;
-            pq_zu = in.q_zt - q_star * K<R>::inv_vk * zp;
-            RiB = ri_bulk(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);
+            pt_zu = in.theta_zt - A(t_star * K<R>::inv_vk * zp);
+            pq_zu = in.q_zt - A(q_star * K<R>::inv_vk * zp);
+            RiB = ri_bulk<R, A>(h.zu, psst, pt_zu, pssq, pq_zu, pUbzu);
         }
         UN10 = vmax(R(0.1), pUbzu - u_star * K<R>::inv_vk * (h.log_zu10 - psm));  // :239 (UN10_from_ustar mod_phymbl.f90:1508)
     }
     const R ztmp0 = u_star * ziUb;                                      // :247-254
     o.Cd = vmax(ztmp0 * ztmp0, K<R>::Cx_min);
-    const R d1 = sfloor(pt_zu - psst, R(1.E-6));
-    const R d2 = sfloor(pq_zu - pssq, R(1.E-9));
+    const R d1 = sfloor(R(pt_zu - psst), R(1.E-6));
+    const R d2 = sfloor(R(pq_zu - pssq), R(1.E-9));
     o.Ch = vmax(M::div(ztmp0 * t_star, d1), R(0.35E-3));
     o.Ce = vmax(M::div(ztmp0 * q_star, d2), R(0.35E-3));
     o.t_zu = pt_zu; o.q_zu = pq_zu; o.Ubzu = pUbzu; o.T_s = psst; o.q_s = pssq;
@@ -1469,7 +1505,7 @@ __device__ __forceinline__ void turb_andreas(const Heights<R> &h, const CellIn<R
         const R zi = M::rcp(M::log(M::div(h.zu, d_z0)));
         o.CdN = vmax(K<R>::vkarmn2 * zi * zi, K<R>::Cx_min);
         R z0t, z0q;
-        z0tq_lkb(M::div(d_z0 * u_star, visc_air(pt_zu)), d_z0, z0t, z0q);
+        z0tq_lkb(M::div(d_z0 * u_star, visc_air(R(pt_zu))), d_z0, z0t, z0q);
         o.ChN = M::div(K<R>::vkarmn2 * zi, M::log(M::div(h.zu, z0t)));
         o.CeN = M::div(K<R>::vkarmn2 * zi, M::log(M::div(h.zu, z0q)));
         o.z0 = d_z0; o.us = u_star; o.L = M::div(h.zu, d_zeta);

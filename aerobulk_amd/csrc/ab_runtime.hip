@@ -128,7 +128,7 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     if (ni <= 0 || nj <= 0 || nt < 1) return fail(AB_ERR_ARG, "ab_session_create: bad shape %ld x %ld, nt=%d", ni, nj, nt);
     if (use_skin && !algo_has_skin(algo))
         return fail(AB_ERR_SKIN_ALGO, " AEROBULK_INIT => Only `COARE*` and `ECMWF` algorithms support cool-skin & warm/layer schemes");
-    if (precision != AB_F64 && precision != AB_F32 && precision != AB_F32_STORAGE) return fail(AB_ERR_ARG, "bad precision %d", precision);
+    if (precision != AB_F64 && precision != AB_F32 && precision != AB_F32_STORAGE && precision != AB_F32_MIXED) return fail(AB_ERR_ARG, "bad precision %d", precision);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(AB_ERR_HIP, "no HIP device visible: this engine has no CPU fallback");
@@ -141,7 +141,7 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     AB_HIP(hipSetDevice(device));
     ab_session *s = new ab_session;
     s->algo = algo; s->ni = ni; s->nj = nj; s->n = ni * nj; s->nt = nt; s->use_skin = use_skin ? 1 : 0;
-    s->f32 = (precision != AB_F64); s->compute64 = (precision == AB_F32_STORAGE); s->esz = s->f32 ? 4 : 8; s->device = device;
+    s->f32 = (precision != AB_F64); s->compute64 = (precision == AB_F32_STORAGE) ? 1 : (precision == AB_F32_MIXED ? 2 : 0); s->esz = s->f32 ? 4 : 8; s->device = device;
     if (const char *e = getenv("AEROBULK_AMD_REGROUP")) s->regroup = atoi(e) != 0;   // A/B measurements
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t x) { if (e == hipSuccess) e = x; };
@@ -681,7 +681,7 @@ int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int
         return fail(AB_ERR_SKIN_ALGO, "TURB_%s has no cool-skin / warm-layer scheme", ab_algo_name(s->algo));
     if (skin && (!f->Qsw || !f->rad_lw || !f->slp))   // mod_blk_coare3p6.f90:263-269
         return fail(AB_ERR_SKIN_NORAD, "you need to provide Qsw, rad_lw & slp to use cool-skin / warm-layer param!");
-    if (s->compute64) return fail(AB_ERR_ARG, "AB_F32_STORAGE sessions serve aerobulk_compute only (ab_session_compute)");
+    if (s->compute64) return fail(AB_ERR_ARG, "AB_F32_STORAGE / AB_F32_MIXED sessions serve aerobulk_compute only (ab_session_compute)");
     if (s->sharded()) return ab::sharded_turb(s, kt, zt, zu, use_cs, use_wl, nb_iter, f, mem, stream);
     AB_HIP(hipSetDevice(s->device));
     const size_t bytes = s->esz * (size_t)s->n;

@@ -10,7 +10,7 @@
 #include "../../include/aerobulk_amd.h"
 
 struct ab_session {
-    int algo = 0, nt = 1, use_skin = 0, f32 = 0, compute64 = 0, device = 0;   // f32: fp32 arrays; compute64: ... with fp64 arithmetic
+    int algo = 0, nt = 1, use_skin = 0, f32 = 0, compute64 = 0, device = 0;   // f32: fp32 arrays; compute64: 1 = ... with fp64 arithmetic (AB_F32_STORAGE), 2 = fp64 anchors + fp32 transcendentals (AB_F32_MIXED)
     long ni = 0, nj = 0, n = 0;
     size_t esz = 8;
     int hum_type = AB_HUM_SH;

@@ -89,7 +89,7 @@ int sharded_create(ab_session **out, int algo, long ni, long nj, int nt, int use
 {
     ab_session *p = new ab_session;
     p->algo = algo; p->ni = ni; p->nj = nj; p->n = ni * nj; p->nt = nt; p->use_skin = use_skin ? 1 : 0;
-    p->f32 = (precision != AB_F64); p->compute64 = (precision == AB_F32_STORAGE); p->esz = p->f32 ? 4 : 8; p->device = devices ? devices[0] : 0;
+    p->f32 = (precision != AB_F64); p->compute64 = (precision == AB_F32_STORAGE) ? 1 : (precision == AB_F32_MIXED ? 2 : 0); p->esz = p->f32 ? 4 : 8; p->device = devices ? devices[0] : 0;
     // contiguous j-blocks, the first (nj mod nshards) one row taller
     long j0 = 0;
     for (int r = 0; r < nshards; ++r) {

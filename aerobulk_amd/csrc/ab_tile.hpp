@@ -38,8 +38,10 @@ template <class R> __device__ __forceinline__ Heights<R> detached(const Heights<
 #endif
     return h;
 }     // 4 stability bins x 4 warm-layer bins
-template <class R, int ALGO, bool SKIN> struct Tile {
-    static constexpr int kFields = SKIN ? 8 : 6;                       // flux: sst theta q_zt u v slp [qsw rlw] ; turb: 8 / 6 too
+// MIXED: the AB_F32_MIXED flux kernels (R = float with fp64 anchors): one more field (the low part of theta), the fp64 math tables
+// and the e_sat table next to the fp32 psi tables
+template <class R, int ALGO, bool SKIN, bool MIXED = false> struct Tile {
+    static constexpr int kFields = (SKIN ? 8 : 6) + (MIXED ? 1 : 0);   // flux: sst theta q_zt u v slp [qsw rlw] [theta_lo] ; turb: 8 / 6 too
     // Waves per SIMD (= resident blocks per CU) a kernel is built for.  The fp64 kernels with the skin schemes need 107-127 VGPRs:
     // four.  Without them 72-95 VGPRs: five, on two-round tiles (-3...-4 % COARE, -1 % ECMWF; config 2 -3 %).  The fp32 kernels,
     // at 36-69 VGPRs once their psi functions come from the LDS tables: seven with the skin schemes (ECMWF: six), eight without,
@@ -56,7 +58,19 @@ template <class R, int ALGO, bool SKIN> struct Tile {
 #ifndef AB_F32_NOSKIN_OCC
 #define AB_F32_NOSKIN_OCC 8
 #endif
-    static constexpr int kOcc = sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : AB_NOSKIN_OCC)
+    // The mixed kernels (fp32 work, fp64 anchors): ECMWF + skin 78 VGPRs: six; COARE + skin 80 with scratch at six: five; without the
+    // skin schemes 54-59: seven (the LDS of the fp64 math tables and the e_sat table leaves room for seven two-round tiles, not eight).
+#ifndef AB_MIXED_OCC
+#define AB_MIXED_OCC 6
+#endif
+#ifndef AB_MIXED_COARE_OCC
+#define AB_MIXED_COARE_OCC 5
+#endif
+#ifndef AB_MIXED_NOSKIN_OCC
+#define AB_MIXED_NOSKIN_OCC 7
+#endif
+    static constexpr int kOcc = MIXED ? (SKIN ? (ALGO == 4 ? AB_MIXED_OCC : AB_MIXED_COARE_OCC) : AB_MIXED_NOSKIN_OCC)
+                                : sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : AB_NOSKIN_OCC)
                                                : (SKIN ? (ALGO == 4 ? AB_F32_ECMWF_OCC : AB_F32_OCC) : AB_F32_NOSKIN_OCC);
     static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
     // The kWaves blocks of a CU share its 160 KB of LDS.  Per block, besides the tile (fields + a 2-byte index per cell): the sort's
@@ -65,11 +79,11 @@ template <class R, int ALGO, bool SKIN> struct Tile {
     // piecewise psi / e_sat tables (ab_physics.hpp: 5 120 B in fp64 with the skin schemes, 3 584 B without, 1 536 B in fp32).  The fp64
     // flux kernels with the skin schemes come out at exactly two rounds with 280 B to spare: nothing is left in LDS.
 #ifdef AB_PSI_LDS_TABLES
-    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? (SKIN ? 5120 : 3584) : 1536;   // (the e_sat table: kernels with the skin schemes only)
+    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? (SKIN ? 5120 : 3584) : (MIXED ? 3072 : 1536);   // (the e_sat table: fp64 kernels with the skin schemes, mixed kernels)
 #else
     static constexpr int kPsiTabBytes = 0;
 #endif
-    static constexpr int kBudget = 160 * 1024 / kWaves - 256 - (sizeof(R) == 8 ? 1792 : 0) - kPsiTabBytes;
+    static constexpr int kBudget = 160 * 1024 / kWaves - 256 - ((sizeof(R) == 8 || MIXED) ? 1792 : 0) - kPsiTabBytes;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 2)); // f64: 2 (skin, 4 blocks) / 2 (5 blocks); f32: 2
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;

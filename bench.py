@@ -164,7 +164,7 @@ def resolve_config(a):
         passes = [(al, bool(a.skin) and al in SKIN_ALGOS) for al in ALL_ALGOS]
         grid, prec, niter = "4320x3600", "f64", 5
     elif a.config == 5:
-        passes, grid, prec, niter = [("ecmwf", True)], "12960x10800", "f32", 5
+        passes, grid, prec, niter = [("ecmwf", True)], "12960x10800", "f32_mixed", 5
     else:
         skin = (not a.no_skin) and a.algo in SKIN_ALGOS
         passes, grid, prec, niter = [(a.algo, skin)], "4320x3600", "f64", 5
@@ -188,8 +188,9 @@ def main():
     ap.add_argument("--skin", action="store_true", help="config 4: switch the skin scheme on for the three algorithms that have one")
     ap.add_argument("--niter", type=int, default=None)
     ap.add_argument("--grid", default=None)
-    ap.add_argument("--precision", default=None, choices=["f64", "f32", "f32_storage"],
-                    help="f32_storage: fp32 arrays with fp64 arithmetic (AB_F32_STORAGE)")
+    ap.add_argument("--precision", default=None, choices=["f64", "f32", "f32_storage", "f32_mixed"],
+                    help="f32_storage: fp32 arrays with fp64 arithmetic (AB_F32_STORAGE); f32_mixed: fp32 arrays, fp64 anchors (SST, theta, "
+                         "T_s, q, q_s, their differences, q_sat), fp32 transcendentals (AB_F32_MIXED: config 5's mode, inside the restated 1e-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resident", "--no-gather", dest="resident", action="store_true",
                     help="N>1: the fluxes stay on the GPU that computed them (what a GPU-resident ocean model consumes): no gather "
@@ -241,7 +242,8 @@ def main():
     zt, zu = 2.0, 10.0
     esz = 8 if precision == "f64" else 4
     tdt = torch.float64 if precision == "f64" else torch.float32
-    dtype_label = {"f64": "f64", "f32": "f32", "f32_storage": "f32 arrays / f64 arithmetic"}[precision]
+    dtype_label = {"f64": "f64", "f32": "f32", "f32_storage": "f32 arrays / f64 arithmetic",
+                   "f32_mixed": "f32 arrays / f64 anchors + f32 transcendentals (AB_F32_MIXED)"}[precision]
     nout = 6 if any_skin else 5
     names = ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")[:nout]
     ngat = nout if a.gather_ts else 5            # fields that travel to rank 0

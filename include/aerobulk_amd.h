@@ -30,9 +30,13 @@ enum ab_algo { AB_ALGO_OTHER = 0, AB_ALGO_COARE3P0 = 1, AB_ALGO_COARE3P6 = 2, AB
 /* ctype_humidity 'sh' | 'dp' | 'rh', mod_const.f90:27 */
 enum ab_hum { AB_HUM_SH = 0, AB_HUM_DP = 1, AB_HUM_RH = 2 };
 enum ab_mem { AB_MEM_HOST = 0, AB_MEM_DEVICE = 1 };
-/* AB_F32: fp32 arrays AND fp32 arithmetic (fastest; tolerance restated).  AB_F32_STORAGE: fp32 arrays (half the
- * HBM footprint and traffic) with the fp64 arithmetic of AB_F64: results = the fp64 path on the rounded inputs, rounded once. */
-enum ab_precision { AB_F64 = 0, AB_F32 = 1, AB_F32_STORAGE = 2 };
+/* AB_F32: fp32 arrays AND fp32 arithmetic (fastest; errors up to 1e-3 where theta - T_s or q - q_s is small).
+ * AB_F32_STORAGE: fp32 arrays (half the HBM footprint and traffic) with the fp64 arithmetic of AB_F64: results = the fp64 path
+ * on the rounded inputs, rounded once.  AB_F32_MIXED: fp32 arrays; SST, theta, T_s, q, q_s, every difference of them and q_sat in
+ * fp64, everything else (profile functions, roughness lengths, cool skin, warm layer) in fp32 with the hardware transcendentals:
+ * within 1e-4 of the fp64 reference (the single-precision hazard mod_blk_ecmwf.f90:556-561 warns about is exactly those
+ * differences) at about twice the speed of AB_F32_STORAGE.  BASELINE config 5 runs in this mode. */
+enum ab_precision { AB_F64 = 0, AB_F32 = 1, AB_F32_STORAGE = 2, AB_F32_MIXED = 3 };
 
 /* Error codes.  The reference has none: it prints and STOPs (mod_const.f90:238-278).  Each code
  * below names the reference condition it replaces; the Fortran host turns a non-zero code

@@ -14,7 +14,8 @@ arch/ files (FMA contraction), by more than the bar (tools/illcond_study.py, tes
                             (backward clause, the componentwise backward error of numerical analysis to first order: got is what
                             the reference computes for inputs that are EACH within 8 ulp, 1.8e-15 relative, of the given ones)
 
-and the number of values that need the second clause is budgeted (ILLCOND_BUDGET) so that it cannot become a blanket excuse.
+and the number of values that need the second clause is budgeted (illcond_allowance(): ILLCOND_BUDGET of the values, at least one per 512 up to 4 on small fields) so that it cannot become
+a blanket excuse; the error may not exceed ONE_INPUT_CEILING times the largest response to ONE input either (below).
 The counts with the round-1 floor (1e-4) are reported next to those with the 1e-6 floor, and the error in units of the ONE-ulp
 response next to the verdict.
 
@@ -42,6 +43,13 @@ FLOOR_FRAC_R1 = 1e-4       # the floor round 1 asserted; still counted and repor
 BACKWARD_ULPS = 8             # largest single-input move of the backward clause
 ULP_MOVES = (1, 2, 4, 8)      # the moves sampled
 ILLCOND_BUDGET = 2e-4      # largest tolerated share of values that pass by the backward clause only (measured: <= 5e-5)
+ILLCOND_MIN_COUNT = 1      # ... but at least this many values of a field, one more per ILLCOND_SMALL_N values up to ILLCOND_MAX_SMALL
+ILLCOND_SMALL_N = 512      #     (round 2 allowed 4 whatever the size: four of a 64-cell test could skip the forward clause; the golden
+ILLCOND_MAX_SMALL = 4      #     sweeps of 2 048 cells, which cross theta_zu = T_s on purpose, hold up to 3 such values per field)
+ONE_INPUT_CEILING = 1.25   # largest tolerated error / largest response to a move of ONE input (the stricter, sufficient form of the
+#                            clause; measured over 1.9e9 values: 1.10, profiles/r2_fuzz_wide.txt entry 15): asserted since round 3
+# FROZEN (round 3): tests/test_parity_metric.py pins every constant above and the formula of S below, and shows with injected errors
+# that the metric fails.  A new failure is a kernel bug until the reference rebuilt under its own flags shows otherwise.
 IN8 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")
 OUT6 = ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")
 
@@ -138,6 +146,11 @@ def parity_report(got, ref, keys, tol=TOL_REL, sens=None, jt=1, scales=None):
     return rep
 
 
+def illcond_allowance(n, budget=ILLCOND_BUDGET):
+    """Largest number of values of an n-value field that may pass by the backward clause only."""
+    return max(int(budget * n), min(ILLCOND_MAX_SMALL, max(ILLCOND_MIN_COUNT, n // ILLCOND_SMALL_N)))
+
+
 def check_parity(got, ref, keys, tol=TOL_REL, sens=None, jt=1, label="", budget=ILLCOND_BUDGET, scales=None, quiet=False):
     rep = parity_report(got, ref, keys, tol, sens, jt, scales)
     if not quiet:
@@ -146,5 +159,7 @@ def check_parity(got, ref, keys, tol=TOL_REL, sens=None, jt=1, label="", budget=
         r = rep[k]
         assert r["n_nonfinite"] == 0, (label, k, r)
         assert r["n_unexplained"] == 0, (label, k, r)          # every value: forward clause, or backward clause (moves <= 8 ulp)
-        assert r["n_gt_tol"] <= max(4, int(budget * r["n"])), (label, k, r)   # ... and only a handful may need the latter
+        assert r["n_gt_tol"] <= illcond_allowance(r["n"], budget), (label, k, r)   # ... and only a handful may need the latter
+        # ... none of them far beyond the stricter one-input form of the clause (so that form cannot regress silently)
+        assert r.get("backward_ratio_one_input_max", 0.0) <= ONE_INPUT_CEILING, (label, k, r)
     return rep
