@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Error of the two fp32 session kinds against fp64 (run on the GPU box): AB_F32 (fp32 arrays and fp32 arithmetic) and
-AB_F32_STORAGE (fp32 arrays, fp64 arithmetic), for the three algorithms with skin schemes.
+"""Error of the three fp32-array session kinds against fp64 (run on the GPU box): AB_F32_MIXED (fp32 arrays, fp64 anchors and
+differences, fp32 transcendentals: config 5's mode), AB_F32 (fp32 arithmetic throughout) and AB_F32_STORAGE (fp32 arrays, fp64
+arithmetic), for the three algorithms with skin schemes; every cell of the grid, and the share of cells beyond 1e-4.
+(Against the ORACLE instead of the fp64 HIP path: tests/test_gpu_mixed.py, on 360x180 and on a 4.5 M-cell subsample of 12960x10800.)
 
 The reference is the fp64 path fed with the SAME fp32-rounded inputs (converted exactly): the error measured is the one the fp32
 session adds, not the rounding of the caller's data.  Metric per flux x: |x32 - x64| / max(|x64|, 1 W/m2-equivalent floor)
@@ -30,7 +32,7 @@ def errors(algo, ni, nj, niter=5):
     out = {}
     with ab.Session(algo, ni, nj, 1, True) as s:
         ref = s.compute(1, 2.0, 10.0, *[f64[k] for k in IN6], Niter=niter, rad_sw=f64["rad_sw"], rad_lw=f64["rad_lw"])
-    for prec in ("f32", "f32_storage"):
+    for prec in ("f32_mixed", "f32", "f32_storage"):
         with ab.Session(algo, ni, nj, 1, True, precision=prec) as s:
             got = s.compute(1, 2.0, 10.0, *[f32[k] for k in IN6], Niter=niter, rad_sw=f32["rad_sw"], rad_lw=f32["rad_lw"])
         rows = {}
@@ -38,6 +40,7 @@ def errors(algo, ni, nj, niter=5):
             d = (got[k].double() - ref[k]).abs()
             e = d if fl is None else d / ref[k].abs().clamp_min(fl)
             rows[k] = [float(torch.quantile(e[:: max(1, e.numel() // 4_000_000)], q)) if q < 1.0 else float(e.max()) for q in QS]
+            rows[k].append(float((e > 1e-4).sum()) / e.numel())
         out[prec] = rows
     return out
 
@@ -49,10 +52,10 @@ def main():
         for algo in ("coare3p6", "coare3p0", "ecmwf"):
             res = errors(algo, ni, nj)
             for prec, rows in res.items():
-                print(f"{algo} + skin, {g}, nb_iter=5, {prec}: error vs fp64 on the same (fp32-rounded) inputs; quantiles " + " ".join(f"p{q * 100:g}" for q in QS))
+                print(f"{algo} + skin, {g}, nb_iter=5, {prec}: error vs fp64 on the same (fp32-rounded) inputs; quantiles " + " ".join(f"p{q * 100:g}" for q in QS) + " | share of cells beyond 1e-4")
                 for k, v in rows.items():
                     unit = "K (absolute)" if FLOOR[k] is None else f"relative, floor {FLOOR[k]:g}"
-                    print(f"   {k:6s} " + " ".join(f"{x:9.2e}" for x in v) + f"   [{unit}]")
+                    print(f"   {k:6s} " + " ".join(f"{x:9.2e}" for x in v[:-1]) + f" | {v[-1]:8.2e}   [{unit}]")
 
 
 if __name__ == "__main__":
