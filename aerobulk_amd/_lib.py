@@ -40,6 +40,18 @@ class IceFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in NAMES]
 
 
+class ShardArrays(C.Structure):
+    """ab_shard_arrays: one shard's device-resident rows (8 inputs, 6 outputs)."""
+    NAMES = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw", "ql", "qh", "tau_x", "tau_y", "evap", "t_s")
+    _fields_ = [(n, C.c_void_p) for n in NAMES]
+
+
+class FluxArrays(C.Structure):
+    """ab_flux_arrays: whole-grid destinations of ab_session_gather."""
+    NAMES = ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")
+    _fields_ = [(n, C.c_void_p) for n in NAMES]
+
+
 # every symbol include/aerobulk_amd.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ab_algo_from_string": (C.c_int, [C.c_char_p, C.c_int]),
@@ -67,6 +79,8 @@ SYMBOLS = {
     "ab_ice_algo_from_string": (C.c_int, [C.c_char_p]),
     "ab_session_compute": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int] + [vp] * 8 + [vp] * 6 + [C.c_int, vp]),
     "ab_session_check": (C.c_int, [vp]),
+    "ab_session_compute_shards": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(ShardArrays), C.POINTER(vp)]),
+    "ab_session_gather": (C.c_int, [vp, C.c_int, C.POINTER(ShardArrays), C.POINTER(FluxArrays), C.POINTER(vp), C.c_int]),
     "ab_session_set_regroup": (C.c_int, [vp, C.c_int]),
     "ab_session_set_solar_time": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     "ab_session_get_wl_state": (C.c_int, [vp, dp]),

@@ -228,6 +228,63 @@ class Session:
             self.check()
         return out
 
+    # -- device-resident fields of a sharded session, and the gather of the fluxes (the north_star's multi-GPU layout)
+    def _shard_structs(self, shard_fields, shard_out):
+        nsh = self._lib.ab_session_shard_count(self._h)
+        if len(shard_fields) != nsh or len(shard_out) != nsh:
+            raise ValueError(f"{nsh} shards: one dict of fields / outputs per shard")
+        arr = (_lib.ShardArrays * nsh)()
+        keep = []
+        for r, (j0, njl, dev) in enumerate(self.shards()):
+            n = self.Ni * njl
+            f, o = shard_fields[r], shard_out[r]
+            for name, key in (("sst", "sst"), ("t_zt", "t_zt"), ("hum_zt", "hum_zt"), ("u_zu", "U_zu"), ("v_zu", "V_zu"), ("slp", "slp"),
+                              ("rad_sw", "rad_sw"), ("rad_lw", "rad_lw")):
+                x = f.get(key)
+                if x is not None:
+                    ptr, k = _ptr(x, self.dtype, n)
+                    keep.append(k)
+                    setattr(arr[r], name, ptr.value if hasattr(ptr, "value") else ptr)
+            for name, key in (("ql", "QL"), ("qh", "QH"), ("tau_x", "Tau_x"), ("tau_y", "Tau_y"), ("evap", "Evap"), ("t_s", "T_s")):
+                x = o.get(key)
+                if x is not None:
+                    ptr, k = _ptr(x, self.dtype, n)
+                    keep.append(k)
+                    setattr(arr[r], name, ptr.value if hasattr(ptr, "value") else ptr)
+        return arr, keep
+
+    def compute_shards(self, jt, zt, zu, shard_fields, shard_out, Niter=5, streams=None, check=True):
+        """aerobulk_compute on device-resident fields, ONE DICT OF TORCH TENSORS PER SHARD (keys as compute(): sst t_zt hum_zt U_zu V_zu slp
+        [rad_sw rad_lw]; outputs QL QH Tau_x Tau_y [Evap T_s]), each holding that shard's rows on that shard's device."""
+        arr, keep = self._shard_structs(shard_fields, shard_out)
+        st = None
+        if streams is not None:
+            st = (C.c_void_p * len(streams))(*[C.c_void_p(x or 0) for x in streams])
+        rc = self._lib.ab_session_compute_shards(self._h, int(jt), float(zt), float(zu), int(Niter), arr, st)
+        if rc:
+            _raise(rc)
+        if check:
+            self.check()
+
+    def gather(self, shard_out, dst, root=0, streams=None, synchronize=True):
+        """The fluxes of every shard into whole-grid tensors `dst` (dict: QL QH Tau_x Tau_y [Evap T_s]; missing = not gathered) on the
+        device of shard `root`: RCCL send / recv inside the process for shards on other devices, device-to-device copies otherwise."""
+        nsh = self._lib.ab_session_shard_count(self._h)
+        arr, keep = self._shard_structs([{}] * nsh, shard_out)
+        d = _lib.FluxArrays()
+        for name, key in (("ql", "QL"), ("qh", "QH"), ("tau_x", "Tau_x"), ("tau_y", "Tau_y"), ("evap", "Evap"), ("t_s", "T_s")):
+            x = dst.get(key)
+            if x is not None:
+                ptr, k = _ptr(x, self.dtype, self.n)
+                keep.append(k)
+                setattr(d, name, ptr.value if hasattr(ptr, "value") else ptr)
+        st = None
+        if streams is not None:
+            st = (C.c_void_p * len(streams))(*[C.c_void_p(x or 0) for x in streams])
+        rc = self._lib.ab_session_gather(self._h, int(root), arr, C.byref(d), st, int(bool(synchronize)))
+        if rc:
+            _raise(rc)
+
     # -- TURB_<algo> itself (mod_blk_coare3p6.f90:123-131 and siblings)
     def turb(self, kt, zt, zu, T_s, theta_zt, q_s, q_zt, U_zu, l_use_cs=False, l_use_wl=False, Qsw=None, rad_lw=None, slp=None,
              nb_iter=5, stream=None):

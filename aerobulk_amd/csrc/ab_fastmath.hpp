@@ -463,6 +463,25 @@ AB_FM double qrqrt_mid(double x)
     const double h = p_fma(-x, u2 * u2, 1.0);
     return p_fma(u * h, p_fma(h, 0.15625, vconst(kC_Quarter, 0.25)), u);
 }
+// The cool skin's pair (mod_phymbl.f90:2030-2044): y = 1 + x^(3/4) and y^(-1/3), x in [2^-100, 2^100].  Both fp32 seeds come from ONE
+// conversion of x: u0 = x^(-1/4) by v_log_f32 / v_exp_f32, y0 = 1 + x u0 in fp32, r0 = y0^(-1/3) by a second log / exp — r0 is on its way
+// while the fp64 cubic step refines u0 (the chain of qrqrt_mid followed by qrcbrt_mid converted y back to fp32 first).  Same cubic steps,
+// same accuracy as qrqrt_mid / qrcbrt_mid (y0 is within 1e-6 of y: r0 within 4e-7 of y^(-1/3), h^3 terms below 1e-18).
+AB_FM void qskin_pair(double x, double &y, double &rc)
+{
+    const float xf = (float)x;
+    const float lx = p_log2f(xf);
+    const float uf = p_exp2f(lx * -0.25f);
+    const float rf = p_exp2f(p_log2f(__builtin_fmaf(xf, uf, 1.0f)) * -0.33333334f);
+    const double u = (double)uf;
+    const double u2 = u * u;
+    const double h = p_fma(-x, u2 * u2, 1.0);
+    const double uq = p_fma(u * h, p_fma(h, 0.15625, vconst(kC_Quarter, 0.25)), u);      // x^(-1/4)
+    y = p_fma(x, uq, 1.0);
+    const double r = (double)rf;
+    const double g = p_fma(-(y * (r * r)), r, 1.0);      // 1 - y r^3
+    rc = p_fma(r * g, p_fma(g, 0.2222222222222222, vconst(kC_Third, 0.3333333333333333)), r);
+}
 // cbrt(x), x >= 0.  Arguments below 2^-100 return 0 (callers add the square of it to O(1) terms).
 AB_FM double qcbrt(double x)
 {

@@ -36,6 +36,15 @@ template <class S> struct DiagArgs {
     S *p[16];   // Cd Ch Ce t_zu q_zu Ubzu | CdN ChN CeN z0 u_star L UN10 | dT_cs dT_wl Hz_wl ; nullptr = not wanted
 };
 
+// fields are read once and written once
+#ifdef AB_NT_FIELDS
+template <class T> __device__ __forceinline__ T ldnt(const T *p) { return __builtin_nontemporal_load(p); }
+template <class T> __device__ __forceinline__ void stnt(T *p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ __forceinline__ T ldnt(const T *p) { return *p; }
+template <class T> __device__ __forceinline__ void stnt(T *p, T v) { *p = v; }
+#endif
+
 // ---- lane regrouping ---------------------------------------------------------------------------------------------
 // The iteration takes divergent paths per cell: stable / unstable psi functions, warm layer gaining heat / idle.  On
 // spatially incoherent input (the quasi-random benchmark fields are the worst case) every wave holds all kinds of cells and
@@ -86,8 +95,9 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
 
     CellOut<R, A> o;
     constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
-    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG, A>(hh, in, nb_iter, wl, dawn, o, park, pstride);
-    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A>(hh, in, nb_iter, wl, dawn, o, park, pstride);
+    constexpr bool kCsgLds = TILED && SKIN && sizeof(R) == 8;      // flux_kernel filled the cool skin's g(u) table
+    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
+    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 3) turb_ncar<R, DIAG, A>(hh, in, nb_iter, o);
     else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG, A>(hh, in, nb_iter, wl, o);
     else turb_andreas<R, DIAG, A>(hh, in, nb_iter, o);
@@ -174,15 +184,22 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
         Raw w{R(290.), R(290.), R(0.01), R(1.), R(1.), R(101000.), R(0.), R(0.)};
         const long k = tile0 + r * kBlock + tid;
         if (r < rounds && k < a.n) {
-            w.sst = (R)a.sst[k]; w.t_zt = (R)a.t_zt[k]; w.hum = (R)a.hum[k]; w.uu = (R)a.u[k]; w.vv = (R)a.v[k]; w.slp = (R)a.slp[k];
-            if (SKIN) { w.rsw = (R)a.rad_sw[k]; w.rlw = (R)a.rad_lw[k]; }
+            // streamed once: non-temporal, so that the fields do not push the piecewise tables (ab_gtables.hpp) out of the L1
+            w.sst = (R)ldnt(a.sst + k); w.t_zt = (R)ldnt(a.t_zt + k); w.hum = (R)ldnt(a.hum + k); w.uu = (R)ldnt(a.u + k); w.vv = (R)ldnt(a.v + k);
+            w.slp = (R)ldnt(a.slp + k);
+            if (SKIN) { w.rsw = (R)ldnt(a.rad_sw + k); w.rlw = (R)ldnt(a.rad_lw + k); }
         }
         return w;
     };
     Raw nxt = fetch(0);
     if (tid == 0) s_next = 0;
     tile_sort_reset(s_cnt, tid);
-    if constexpr (sizeof(R) == 8) psi_tables_fill<SKIN>();   // (before the barrier of math_tables_init)
+    // (before the barrier of math_tables_init) fp64: COARE reads its psi tables through L1 (ab_gtables.hpp); ECMWF / ANDREAS keep the
+    // Kansas psi_m table in LDS; the e_sat table with the skin schemes
+    if constexpr (sizeof(R) == 8) {
+        if constexpr (ALGO == 1 || ALGO == 2) { if (SKIN) { esat_table_fill(); csg_table_fill(); } }
+        else psi_tables_fill<SKIN>();
+    }
     else psi_tables_fill32();                             // (before the barrier below)
     if constexpr (kMixed) esat_table_fill();              // q_sat of the mixed mode is the fp64 one, through its LDS table
     math_tables_init<A>();
@@ -265,12 +282,12 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
         const int j = r * kBlock + tid;
         const long k = tile0 + j;
         if (k >= a.n) break;
-        a.ql[k] = (S)s_f[0][j];
-        a.qh[k] = (S)s_f[1][j];
-        a.tau_x[k] = (S)s_f[2][j];
-        a.tau_y[k] = (S)s_f[3][j];
-        if (a.evap) a.evap[k] = (S)s_f[4][j];                                      // :208
-        if (a.t_s) a.t_s[k] = (S)s_f[5][j];                                        // :206
+        stnt(a.ql + k, (S)s_f[0][j]);
+        stnt(a.qh + k, (S)s_f[1][j]);
+        stnt(a.tau_x + k, (S)s_f[2][j]);
+        stnt(a.tau_y + k, (S)s_f[3][j]);
+        if (a.evap) stnt(a.evap + k, (S)s_f[4][j]);                                // :208
+        if (a.t_s) stnt(a.t_s + k, (S)s_f[5][j]);                                  // :206
     }
 }
 
@@ -505,3 +522,23 @@ hipError_t launch_math_test(int op, const double *x, const double *y, double *o,
 }
 
 }  // namespace ab
+
+// ------------------------------------------------------------------------------------------------
+// tools/isa_profile.py: basic-block execution counters of an INSTRUMENTED build of one kernel (the tool patches the device
+// assembly; every basic block adds 1 per wave and 1 per active lane to its pair of counters).  Never compiled into the library.
+#ifdef AB_ISA_PROFILE
+namespace ab {
+__device__ __attribute__((used)) unsigned ab_prof_counters[16384];
+}
+extern "C" int ab_prof_reset()
+{
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ab::ab_prof_counters)) != hipSuccess) return 1;
+    return hipMemset(p, 0, sizeof(unsigned) * 16384) == hipSuccess && hipDeviceSynchronize() == hipSuccess ? 0 : 2;
+}
+extern "C" int ab_prof_read(unsigned *out, int n)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ab::ab_prof_counters), sizeof(unsigned) * (size_t)n) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -289,13 +289,14 @@ constexpr bool kPsiTabDefault = false;
 #endif
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
 // two arrays: a kernel that never evaluates e_sat through its table (ESAT = false below) does not allocate the second
-static __shared__ double s_psitab[kTabOff[2]];
+static __shared__ double s_psitab[kTabOff[1]];     // Kansas psi_m (the fp64 kernels of ECMWF, ANDREAS; COARE reads its psi through L1, ab_gtables.hpp)
+static __shared__ double s_psitabc[kTabOff[2] - kTabOff[1]];   // convective psi (unused by the flux kernels since round 3; math_test_kernel)
 static __shared__ double s_esattab[kTabTotal - kTabOff[2]];
 // all threads of a block, BEFORE the barrier of math_tables_init().  ESAT: also the e_sat table (the kernels with the skin schemes,
 // where e_sat is evaluated a dozen times per cell; without them four times: not worth 1.5 KB of the LDS five blocks per CU share)
 template <bool ESAT = true> __device__ __forceinline__ void psi_tables_fill()
 {
-    for (int t = (int)threadIdx.x; t < kTabOff[2]; t += (int)blockDim.x) s_psitab[t] = t < kTabOff[1] ? kPsiTabM[t] : kPsiTabC[t - kTabOff[1]];
+    for (int t = (int)threadIdx.x; t < kTabOff[1]; t += (int)blockDim.x) s_psitab[t] = kPsiTabM[t];
     if constexpr (ESAT)
         for (int t = (int)threadIdx.x; t < kTabTotal - kTabOff[2]; t += (int)blockDim.x) s_esattab[t] = kEsatTab[t];
 }
@@ -307,7 +308,8 @@ __device__ __forceinline__ void esat_table_fill()
 template <int WHICH> __device__ __forceinline__ double psi_tab_coef(int k, int i)
 {
     if constexpr (WHICH == kTabEsat) return s_esattab[k * kTabNint[WHICH] + i];
-    else return s_psitab[kTabOff[WHICH] + k * kTabNint[WHICH] + i];
+    else if constexpr (WHICH == kTabPsic) return s_psitabc[k * kTabNint[WHICH] + i];
+    else return s_psitab[k * kTabNint[WHICH] + i];
 }
 #else
 template <int WHICH> inline double psi_tab_coef(int k, int i)
@@ -316,13 +318,22 @@ template <int WHICH> inline double psi_tab_coef(int k, int i)
     return tab[k * kTabNint[WHICH] + i];
 }
 #endif
+// position in a piecewise table: interval = trunc(xn), local variable = 2 fract(xn) - 1 (xn >= 0): v_cvt_i32_f64, v_fract_f64 and one FMA
+// (floor, subtract, FMA and the conversion were four)
+__device__ __forceinline__ double tab_fract(double xn)
+{
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+    return __builtin_amdgcn_fract(xn);
+#else
+    return xn - __builtin_floor(xn);
+#endif
+}
 // xn = position in units of intervals, 0 <= xn < kTabNint[WHICH]
 template <int WHICH> __device__ __forceinline__ double psi_tab_eval(double xn)
 {
     AB_COUNT(WHICH == kTabPsikM ? "tab_psik_m" : (WHICH == kTabPsic ? "tab_psic" : "tab_e_sat"), 12.);   // floor, sub, fma, cvt, shift + 7 FMAs; the coefficients arrive over the LDS pipe
-    const double fi = __builtin_floor(xn);
-    const int i = (int)fi;
-    const double u = __builtin_fma(xn - fi, 2., -1.);
+    const int i = (int)xn;
+    const double u = __builtin_fma(tab_fract(xn), 2., -1.);
     double p = psi_tab_coef<WHICH>(7, i);
 #pragma unroll
     for (int k = 6; k >= 0; --k) p = __builtin_fma(p, u, psi_tab_coef<WHICH>(k, i));
@@ -414,6 +425,58 @@ template <int WHICH> __device__ __forceinline__ float psi_tab_eval32(float x32)
     float p = psi_tab_coef32<WHICH>(3, i);
 #pragma unroll
     for (int k = 2; k >= 0; --k) p = __builtin_fmaf(p, u, psi_tab_coef32<WHICH>(k, i));
+    return p;
+}
+}  // namespace ab
+#include "ab_gtables.hpp"
+namespace ab {
+// ---- piecewise tables read through the vector-memory path (ab_gtables.hpp, tools/gen_gtab.py).  Interval-major: one address, four
+// 16-byte loads that hit L1 (measured equal to LDS for the e_sat table; LDS is full, the L1 is idle).  xn = position in units of
+// intervals, 0 <= xn < number of intervals.
+struct GtabPos {
+    int i;
+    double u;
+};
+__device__ __forceinline__ GtabPos gtab_pos(double xn)
+{
+    return GtabPos{(int)xn, __builtin_fma(tab_fract(xn), 2., -1.)};
+}
+__device__ __forceinline__ double gtab_at(const double *tab, const GtabPos &p)
+{
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 *q = (const d2 *)(tab + 8 * p.i);
+    const d2 c01 = q[0], c23 = q[1], c45 = q[2], c67 = q[3];
+    double r = c67[1];
+    r = __builtin_fma(r, p.u, c67[0]); r = __builtin_fma(r, p.u, c45[1]); r = __builtin_fma(r, p.u, c45[0]);
+    r = __builtin_fma(r, p.u, c23[1]); r = __builtin_fma(r, p.u, c23[0]); r = __builtin_fma(r, p.u, c01[1]);
+    return __builtin_fma(r, p.u, c01[0]);
+#else
+    const double *c = tab + 8 * p.i;
+    double r = c[7];
+    for (int k = 6; k >= 0; --k) r = fm::p_fma(r, p.u, c[k]);
+    return r;
+#endif
+}
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+static __shared__ double s_csgtab[8 * kCsGTabN];
+// the cool skin's g(u) table in LDS (tiled fp64 COARE kernels with the skin schemes); all threads, before the barrier of math_tables_init()
+__device__ __forceinline__ void csg_table_fill()
+{
+    for (int t = (int)threadIdx.x; t < 8 * kCsGTabN; t += (int)blockDim.x) s_csgtab[t] = kCsGTab[t];
+}
+__device__ __forceinline__ double csg_coef(int k, int i) { return s_csgtab[k * kCsGTabN + i]; }
+#else
+inline double csg_coef(int k, int i) { return kCsGTab[k * kCsGTabN + i]; }
+#endif
+// g(u) from the LDS table; xn = u * kCsGTabN / kCsGTabMax in [0, kCsGTabN)
+__device__ __forceinline__ double csg_lds_eval(double xn)
+{
+    const int i = (int)xn;
+    const double u = __builtin_fma(tab_fract(xn), 2., -1.);
+    double p = csg_coef(7, i);
+#pragma unroll
+    for (int k = 6; k >= 0; --k) p = __builtin_fma(p, u, csg_coef(k, i));
     return p;
 }
 template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R e_sat(R pTa)
@@ -580,7 +643,8 @@ template <class R> __device__ __forceinline__ R alpha_sw(R psst)
 // CS_COARE mod_skin_coare.f90:48-93 (c0 = 0.137, latent-heat term) and CS_ECMWF
 // mod_skin_ecmwf.f90:68-110 (c0 = 0.065) around delta_skin_layer_sclr mod_phymbl.f90:2010-2046.
 // palpha = alpha_sw(SST) is hoisted by the caller.
-template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R pQnsol, R pustar, R palpha, R pQlat)
+// GLDS: g(u) of the absorption profile from its LDS table (the caller's kernel filled it: csg_table_fill)
+template <class R, bool COARE, bool GLDS = false> __device__ __forceinline__ R cool_skin(R pQsw, R pQnsol, R pustar, R palpha, R pQlat)
 {
     AB_REGION("cool_skin");
     using M = Mth<R>;
@@ -596,26 +660,61 @@ template <class R, bool COARE> __device__ __forceinline__ R cool_skin(R pQsw, R 
     const R zql = COARE ? R(0.026 * 4190. / 2.46e+6) * vmin(pQlat, R(0.)) : R(0.);
     const R zdwarm = vmin(R(6.) * ztmp, R(0.007));
     const R ziz6 = zusw * R(1. / (6. * 1.e-6));                     // 1/(6 nu/u*w), K<R>::rnu0_w = 1e-6
-    // delta and, for the absorption profile below, 1/delta = (1 + x^0.75)^(1/3) / (6 nu/u*w) = y rcbrt(y)^2 u*w/(6 nu): no division
-    R zidelta;
+    // delta; 1/delta for the absorption profile below is (1 + x^0.75)^(1/3) / (6 nu/u*w) = y rcbrt(y)^2 u*w/(6 nu): no division.  Where
+    // the profile comes from its table (fp64 COARE) 1/delta is only wanted for a layer thicker than the table covers: formed then
+    // (LAZY: y and the cube root are kept instead — in the rare warm branch a pair that gives 1/delta by the same formula —; elsewhere
+    // the one number 1/delta is kept, which holds fewer registers)
+    constexpr bool LAZY = sizeof(R) == 8 && COARE;
+    R zy = R(1.), zrc = R(1.), zidelta = R(0.);
     auto delta = [&](R pQd) -> R {
         const R zQd = palpha * pQd + zql;                           // alpha (Qd + zql/alpha)
-        if (nonneg(zQd)) { zidelta = M::rcp(zdwarm); return zdwarm; }   // warming of the viscous layer (rare)
+        if (nonneg(zQd)) {                                          // warming of the viscous layer (rare)
+            if (LAZY) { zrc = R(1.); zy = M::rcp(zdwarm * ziz6); } else zidelta = M::rcp(zdwarm);
+            return zdwarm;
+        }
         // x^0.75 = x x^(-1/4), the fourth root from an fp32 seed and one cubic step.  The reference's floor of x at 0 becomes 1e-30
         // (fp32 range of the seed): below it x^0.75 < 6e-23 and 1 + x^0.75 is 1 either way
         const R x = vmax(zB * zQd, R(1.E-30));
-        const R y = R(1.) + x * M::rqrt(x);
-        const R rc = M::rcbrt(y);
-        zidelta = (y * rc) * (rc * ziz6);
+        R y, rc;
+        if constexpr (sizeof(R) == 8) {
+            AB_COUNT("qskin_pair", 24.);
+            double yy, rr;
+            fm::qskin_pair((double)x, yy, rr);                      // both fp32 seeds from one conversion of x
+            y = R(yy); rc = R(rr);
+        } else {
+            y = R(1.) + x * M::rqrt(x);
+            rc = M::rcbrt(y);
+        }
+        if (LAZY) { zy = y; zrc = rc; } else zidelta = (y * rc) * (rc * ziz6);
         return R(6.) * rc * ztmp;                                   // 6 (1 + x^0.75)^(-1/3) nu/u*w
     };
+    auto inv_delta = [&]() -> R { return LAZY ? (zy * zrc) * (zrc * ziz6) : zidelta; };
     R zQabs = pQnsol;
     R zdelta = delta(zQabs);
     // no insolation (night side): zQabs = pQnsol + zfr*0 never changes, the four sub-iterations reproduce zdelta exactly
     if (pQsw != R(0.))
 #pragma unroll 1
     for (int jc = 0; jc < 4; ++jc) {
-        const R zfr = vmax(c0 + R(11.) * zdelta - (R(6.6E-5) * zidelta) * (R(1.) - M::exp(zdelta * R(-1. / 8.E-4))), R(0.01));
+        R zabs;      // 6.6e-5/delta (1 - exp(-delta/8e-4))
+#ifndef AB_NO_GTABLES
+        if constexpr (sizeof(R) == 8 && COARE) {   // (ECMWF + skin sits at the 128-VGPR limit: eight more coefficients in flight would spill)
+            // = 0.0825 g(u), g(u) = (1 - exp(-u))/u, u = delta/8e-4: g from a piecewise table — in LDS where the kernel has one (twenty
+            // evaluations per cell in a dependent chain: the L1 round trip shows), else through L1 (ab_gtables.hpp) — instead of an
+            // exponential and the reciprocal thickness
+            const R zu8 = zdelta * R(1. / 8.E-4);
+            if (zu8 < R(GLDS ? kCsGTabMax : kGCsGMax)) {
+                AB_COUNT("gtab_cs_g", 11.5);
+                double g;
+                if constexpr (GLDS) g = csg_lds_eval((double)R(zu8 * R(kCsGTabN / kCsGTabMax)));
+                else g = gtab_at(kGCsG, gtab_pos((double)R(zu8 * R(kGCsGN / kGCsGMax))));
+                zabs = R(6.6E-5 / 8.E-4) * R(g);
+            } else {
+                zabs = (R(6.6E-5) * inv_delta()) * (R(1.) - M::exp(-zu8));
+            }
+        } else
+#endif
+            zabs = (R(6.6E-5) * inv_delta()) * (R(1.) - M::exp(zdelta * R(-1. / 8.E-4)));
+        const R zfr = vmax(c0 + R(11.) * zdelta - zabs, R(0.01));
         zQabs = pQnsol + zfr * pQsw;
         zdelta = delta(zQabs);
     }
@@ -798,7 +897,9 @@ AB_TAB double kPsicL[fm::ab_pad4(25)] = {2.0150925272068325, 2.710495199372137, 
     8.203412060926331e-07, 1.6890014539724024e-06, -1.0233606614380625e-06, 4.458163497401233e-08,
     2.2237828297719952e-07, -7.865948843893524e-08, -1.6678750033618155e-08, 1.1728431071594033e-08,
     -7.386244013567441e-10};
-template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
+// (TAB: the fp32 kernels' piecewise LDS tables; the fp64 kernels read theirs through L1 — ab_gtables.hpp — and reach this function
+// only beyond zeta = -50, where the polynomial / closed forms serve)
+template <class R, bool TAB = (sizeof(R) == 4 && kPsiTabDefault)> __device__ __forceinline__ R psic_coare(R y)   // y >= 1
 {
     using M = Mth<R>;
     const R L = M::log(y);
@@ -872,7 +973,9 @@ template <class R, bool TAB = kPsiTabDefault> __device__ __forceinline__ void ps
     if (ph) *ph = R(2.) * M::log(R(0.5) * (R(1.) + x2));
 }
 // psi_m_coare_sclr :217-254 and psi_h_coare_sclr :305-344 at the same zeta
-template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
+// SEQ: where psi_m and psi_h are both read from the L1 tables, the second table's loads wait for the first result (sixteen VGPRs of
+// coefficients in flight instead of 32: the kernels without the skin schemes run five waves per SIMD on 96 VGPRs)
+template <class R, bool SEQ = false> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
 {
     AB_REGION("psi_coare");
     using M = Mth<R>;
@@ -885,10 +988,30 @@ template <class R> __device__ __forceinline__ void psi_coare(R z, R *pm, R *ph)
             *ph = -(a * M::sqrt_pos(a) + t + R(8.525));
         }
     } else {  // unstable: Kansas / free-convection blend
+#ifndef AB_NO_GTABLES
+        if constexpr (sizeof(R) == 8) {
+            // the WHOLE blended functions of s = LOG(|1 - 15 zeta|), piecewise through L1 (ab_gtables.hpp): one log and two table
+            // evaluations on one index instead of three logs, the Kansas table / polynomial, two convective tables and the blend
+            const R sl = M::log(M::abs(R(1.) - R(15.) * z));
+            if (sl < R(kGPsiSMax)) {
+                AB_COUNT("gtab_psi_coare", (pm && ph) ? 19.5 : 12.5);
+                GtabPos gp = gtab_pos((double)R(sl * R(kGPsiCoareN / kGPsiSMax)));
+                if (pm) {
+                    double m = gtab_at(kGPsiCoareM, gp);
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+                    if (SEQ && ph) asm volatile("" : "+v"(gp.i), "+v"(m));
+#endif
+                    *pm = R(m);
+                }
+                if (ph) *ph = R(gtab_at(kGPsiCoareH, gp));
+                return;
+            }
+        }
+#endif
         R zf = z * z;
         zf = M::div(zf, R(1.) + zf);
         R psik_m = R(0.), psik_h = R(0.);
-        psik<R>(M::abs(R(1.) - R(15.) * z), pm ? &psik_m : nullptr, ph ? &psik_h : nullptr);
+        psik<R, (sizeof(R) == 4 && kPsiTabDefault)>(M::abs(R(1.) - R(15.) * z), pm ? &psik_m : nullptr, ph ? &psik_h : nullptr);
         if (pm) *pm = (R(1.) - zf) * psik_m + zf * psic_coare(M::abs(R(1.) - R(10.15) * z));
         if (ph) *ph = (R(1.) - zf) * psik_h + zf * psic_coare(M::abs(R(1.) - R(34.15) * z));
     }
@@ -914,7 +1037,7 @@ template <class R> struct Heights {  // wave-uniform, prepared on the host
     R zt, zu, log_zt, log_zu, log_10, log_ztu, log_zu10, fg_ca, inv_zu, zt_o_zu;
     int zt_eq_zu;  // ABS(zu-zt) < 0.01
 };
-template <class R, class A = R>
+template <class R, class A = R, bool SEQ = false>
 __device__ __forceinline__ void first_guess_coare(const Heights<R> &h, A psst, A t_zt, A pssq, A q_zt, R U_zu,
                                                   R pcharn, R &pus, R &pts, R &pqs, A &t_zu, A &q_zu, R &Ubzu,
                                                   R &pz0)
@@ -943,7 +1066,7 @@ __device__ __forceinline__ void first_guess_coare(const Heights<R> &h, A psst, A
     if (nonneg(zRib)) zzeta_u = zcc_ri + R(27. / 9.) * zRib * zRib;
     else zzeta_u = M::div(zcc_ri, R(1.) + zRib * (-zc_b * h.inv_zu));
     R psm, psh;
-    psi_coare<R>(zzeta_u, &psm, &psh);
+    psi_coare<R, SEQ>(zzeta_u, &psm, &psh);
     zus = vmax(M::div(zUb * vk, zdl - psm), R(1.E-9));
     const R ztmp = M::div(vk, h.log_zu - zlog_z0t - psh);
     R zts = zdt * ztmp;
@@ -994,7 +1117,8 @@ constexpr int kSkinCS = 1, kSkinWL = 2, kSkinBoth = 3;
 // park / pstride: optional per-lane scratch words park[i * pstride], i = 0,1,2,5,6 (LDS slots of the caller's tile).  The warm-layer state beyond dT_wl and the
 // two WL_COARE constants are only touched by the live WL_COARE calls (jit = 1 and the divisors of nb_iter): parked there they
 // do not hold ten VGPRs across the rest of the iteration (the COARE + skin kernels sit at the 128-VGPR limit).
-template <class R, bool V36, int SKIN, bool DIAG = false, class A = R>
+// CSGLDS: the caller's kernel keeps the cool skin's g(u) table in LDS (flux_kernel: csg_table_fill)
+template <class R, bool V36, int SKIN, bool DIAG = false, class A = R, bool CSGLDS = false>
 __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R, A> &in, int nb_iter, R (&wl)[4],
                                            bool dawn, CellOut<R, A> &o, lds_vptr<R> park = nullptr, int pstride = 0)
 {
@@ -1026,8 +1150,8 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R, 
     }
     R zus, zts, zqs, Ubzu, zz0;
     A t_zu, q_zu;
-    first_guess_coare<R, A>(h, T_s, in.theta_zt, q_s, in.q_zt, zUzu, V36 ? charn_coare3p6(zUzu) : charn_coare3p0(zUzu),
-                            zus, zts, zqs, t_zu, q_zu, Ubzu, zz0);
+    first_guess_coare<R, A, SKIN == 0>(h, T_s, in.theta_zt, q_s, in.q_zt, zUzu, V36 ? charn_coare3p6(zUzu) : charn_coare3p0(zUzu),
+                                       zus, zts, zqs, t_zu, q_zu, Ubzu, zz0);
     R zlog_z0 = M::log(zz0);
     const R znu_a = visc_air(R(V36 ? t_zu : in.theta_zt));  // 3p6 :294 (first-guess t_zu) vs 3p0 :237 (t_zt)
     const R zlog_nu = M::log(znu_a);
@@ -1061,7 +1185,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R, 
         if (DIAG) { d_1oL = z1oL; d_lz0t = zlog_z0t; }
         // turbulent scales :339-344
         R psm, psh;
-        psi_coare<R>(zzta_u, &psm, &psh);
+        psi_coare<R, SKIN == 0>(zzta_u, &psm, &psh);
         R ztmp1 = M::div(vk, h.log_zu - zlog_z0t - psh);
         zts = zdt * ztmp1;
         zqs = zdq * ztmp1;
@@ -1079,7 +1203,7 @@ __device__ __forceinline__ void turb_coare(const Heights<R> &h, const CellIn<R, 
             R zQns, zTau, zQlat;
             update_qnsol_tau<R, A>(h.zu, T_s, q_s, t_zu, q_zu, zus, zts, zqs, zUzu, Ubzu, in.slp, in.rlw, zQns, zTau,
                                    zQlat);                             // :355-356
-            zdT_cs = cool_skin<R, true>(in.qsw, zQns, zus, zalpha, zQlat);  // :358
+            zdT_cs = cool_skin<R, true, CSGLDS>(in.qsw, zQns, zus, zalpha, zQlat);  // :358
             T_s = xSST + A(zdT_cs);
             if (WL) T_s = T_s + A(wl[0]);                              // :360-361
             // with the warm layer on, this q_s is only read by the UPDATE_QNSOL_TAU of a live WL_COARE call (below)

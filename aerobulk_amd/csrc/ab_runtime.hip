@@ -19,6 +19,14 @@
 #include <thread>
 #include <vector>
 
+namespace ab {
+struct FusedShard {
+    FluxCall c;
+    void *hout[6], *dout[6];
+    size_t bytes;
+};
+}  // namespace ab
+
 namespace {
 
 thread_local std::string g_err;
@@ -138,6 +146,7 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     }
     if (device < 0) AB_HIP(hipGetDevice(&device));
     if (device >= ndev) return fail(AB_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    ab::DeviceGuard dguard_;      // the caller's current device is the caller's (round-2 advisory: torch allocated on the last shard's GPU afterwards)
     AB_HIP(hipSetDevice(device));
     ab_session *s = new ab_session;
     s->algo = algo; s->ni = ni; s->nj = nj; s->n = ni * nj; s->nt = nt; s->use_skin = use_skin ? 1 : 0;
@@ -150,6 +159,7 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     chk(hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking));
     chk(hipEventCreate(&s->ev0));
     chk(hipEventCreate(&s->ev1));
+    chk(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
     chk(hipMalloc((void **)&s->d_flags, sizeof(int)));
     chk(hipMalloc((void **)&s->d_partials, sizeof(double) * ab::kStatBlocks * ab::kStatStride));
     if (e == hipSuccess) chk(hipMemset(s->d_flags, 0, sizeof(int)));
@@ -191,10 +201,12 @@ int ab_session_destroy(ab_session *s)
 {
     if (!s) return AB_OK;
     if (s->sharded()) return ab::sharded_destroy(s);
+    ab::DeviceGuard dguard_;
     (void)hipSetDevice(s->device);
-    // device-mode calls run on the caller's stream and use session-owned buffers (WL state, flags, lon, diagnostics staging):
-    // drain it before they are freed
-    if (s->last_stream) (void)hipStreamSynchronize(s->last_stream);
+    // device-mode calls run on the caller's stream and use session-owned buffers (WL state, flags, lon, diagnostics staging): wait
+    // for the last of them before they are freed — through the session's own event, recorded behind that call: the caller's stream
+    // may be gone by now (a model that tears its streams down first)
+    if (s->done_pending && s->ev_done) (void)hipEventSynchronize(s->ev_done);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &p : s->wl) if (p) (void)hipFree(p);
     for (auto &p : s->stage_in) if (p) (void)hipFree(p);
@@ -205,6 +217,7 @@ int ab_session_destroy(ab_session *s)
     if (s->d_partials) (void)hipFree(s->d_partials);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->s_h2d) (void)hipStreamDestroy(s->s_h2d);
     if (s->s_d2h) (void)hipStreamDestroy(s->s_d2h);
@@ -266,6 +279,11 @@ struct FusedInit {
     int guess = AB_HUM_SH;
     int have_rad = 0;
     ab_init_report *report = nullptr;
+    // a shard of a sharded session (ab::sharded_model_first_record): the verdict is GLOBAL, so the shard hands its statistics back
+    // instead of applying them, and keeps what a redo with another humidity type needs
+    bool defer = false;
+    double stats[AB_INIT_NSTATS];
+    ab::FusedShard *keep = nullptr;
 };
 constexpr int kFusedBlocks = 128;
 
@@ -402,6 +420,7 @@ int ab_session_set_solar_time(ab_session *s, int isecday_utc, const void *lon, i
 {
     if (!s) return fail(AB_ERR_ARG, "NULL session");
     if (s->sharded()) return ab::sharded_set_solar_time(s, isecday_utc, lon, mem, stream);
+    ab::DeviceGuard dguard_;
     AB_HIP(hipSetDevice(s->device));
     s->isecday = isecday_utc;
     if (!lon) {
@@ -427,6 +446,7 @@ int ab_session_init_stats(ab_session *s, const void *sst, const void *t_zt, cons
     if (!sst || !t_zt || !hum_zt || !u_zu || !v_zu || !slp) return fail(AB_ERR_ARG, "ab_session_init: NULL input field");
     const void *host[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw};
     if (s->sharded()) return ab::sharded_init_stats(s, host, mem, stream, stats);
+    ab::DeviceGuard dguard_;
     AB_HIP(hipSetDevice(s->device));
     // device arrays: the reduction runs on the CALLER's stream, behind whatever is still producing the fields there (the
     // session's own stream is non-blocking and ordered with nothing)
@@ -542,6 +562,7 @@ static int compute_impl(ab_session *s, int jt, double zt, double zu, int niter, 
     }
     if (s->use_skin && s->nt > 1 && jt > 1 && s->last_jt != jt - 1 && s->last_jt != jt)
         return fail(AB_ERR_STATE, "warm-layer state: record jt=%d requested after jt=%d", jt, s->last_jt);
+    ab::DeviceGuard dguard_;
     AB_HIP(hipSetDevice(s->device));
 
     hipStream_t st = (mem == AB_MEM_HOST) ? s->stream : (hipStream_t)stream;
@@ -621,9 +642,19 @@ static int compute_impl(ab_session *s, int jt, double zt, double zu, int niter, 
             AB_HIP(e);
             double stats[AB_INIT_NSTATS];
             fold_partials(part.data(), nch * kFusedBlocks, s->n, stats);
+            if (fi->defer) {   // a shard: the verdict is taken on the statistics of ALL shards (ab::sharded_model_first_record)
+                memcpy(fi->stats, stats, sizeof stats);
+                fi->keep = new ab::FusedShard;
+                fi->keep->c = c;
+                for (int i = 0; i < 6; ++i) { fi->keep->hout[i] = hout[i]; fi->keep->dout[i] = dout[i]; }
+                fi->keep->bytes = bytes;
+                return AB_OK;
+            }
             int rc = ab_session_init_apply(s, stats, fi->have_rad, fi->report);
             if (rc) return rc;
             if (s->hum_type != fi->guess) {   // the first chunk misjudged the humidity type: redo the record from the resident inputs
+                fprintf(stderr, "aerobulk_amd: AEROBULK_INIT: the first 2^20 cells read as humidity type %d, the whole domain as %d: "
+                                "record 1 is computed again from the resident fields\n", fi->guess, s->hum_type);
                 c.hum_type = s->hum_type;
                 AB_HIP(hipMemsetAsync(s->d_flags, 0, sizeof(int), s->stream));   // whatever the misjudged pass flagged is void
                 AB_HIP(ab::launch_flux(c, s->stream));
@@ -653,6 +684,8 @@ static int compute_impl(ab_session *s, int jt, double zt, double zu, int niter, 
             if (hout[i]) AB_HIP(hipMemcpyAsync(hout[i], dout[i], bytes, hipMemcpyDeviceToHost, st));
         return ab_session_check(s);
     }
+    AB_HIP(hipEventRecord(s->ev_done, st));
+    s->done_pending = true;
     return AB_OK;
 }
 
@@ -683,6 +716,7 @@ int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int
         return fail(AB_ERR_SKIN_NORAD, "you need to provide Qsw, rad_lw & slp to use cool-skin / warm-layer param!");
     if (s->compute64) return fail(AB_ERR_ARG, "AB_F32_STORAGE / AB_F32_MIXED sessions serve aerobulk_compute only (ab_session_compute)");
     if (s->sharded()) return ab::sharded_turb(s, kt, zt, zu, use_cs, use_wl, nb_iter, f, mem, stream);
+    ab::DeviceGuard dguard_;
     AB_HIP(hipSetDevice(s->device));
     const size_t bytes = s->esz * (size_t)s->n;
     if (use_wl) {
@@ -746,6 +780,9 @@ int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int
             AB_HIP(hipMemcpyAsync(f->q_s, din[2], bytes, hipMemcpyDeviceToHost, st));
         }
         AB_HIP(hipStreamSynchronize(st));
+    } else {
+        AB_HIP(hipEventRecord(s->ev_done, st));
+        s->done_pending = true;
     }
     return AB_OK;
 }
@@ -754,6 +791,7 @@ int ab_session_check(ab_session *s)
 {
     if (!s) return fail(AB_ERR_ARG, "NULL session");
     if (s->sharded()) return ab::sharded_check(s);
+    ab::DeviceGuard dguard_;
     AB_HIP(hipSetDevice(s->device));
     hipStream_t st = s->last_stream;
     int flags = 0;
@@ -772,6 +810,7 @@ int ab_session_get_wl_state(ab_session *s, double *state4n)
     if (!s || !state4n) return fail(AB_ERR_ARG, "NULL argument");
     if (s->sharded()) return ab::sharded_get_wl_state(s, state4n);
     if (!s->wl[0]) return fail(AB_ERR_STATE, "session keeps no persistent warm-layer state (no skin scheme or nt == 1)");
+    ab::DeviceGuard dguard_;
     AB_HIP(hipSetDevice(s->device));
     AB_HIP(hipDeviceSynchronize());
     const size_t n = (size_t)s->n;
@@ -793,6 +832,7 @@ double ab_session_last_kernel_ms(ab_session *s)
 {
     if (s && s->sharded()) return ab::sharded_last_kernel_ms(s);
     if (!s || !s->timed) return -1.;
+    ab::DeviceGuard dguard_;
     if (hipSetDevice(s->device) != hipSuccess) return -1.;
     if (hipEventSynchronize(s->ev1) != hipSuccess) return -1.;
     float ms = -1.f;
@@ -825,6 +865,74 @@ int ab_test_math(int op, const double *x, const double *y, double *out, long n)
     AB_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dout);
     if (dy) (void)hipFree(dy);
+    return AB_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// One shard of a sharded session at AEROBULK_MODEL's jt == 1 (ab_sharded.hip, sharded_model_first_record): the shard's pipelined
+// pass with AEROBULK_INIT's statistics riding on it; the statistics are handed back (the verdict is global), `keep` holds what a
+// redo needs.  Called from the shard's worker thread.
+namespace ab {
+int leaf_fused_first_record(ab_session *leaf, double zt, double zu, int niter, const void *const in[8], void *const out[6], int have_rad,
+                            double stats[AB_INIT_NSTATS], int *guess, FusedShard **keep)
+{
+    FusedInit fi;
+    fi.have_rad = have_rad;
+    fi.defer = true;
+    int rc = compute_impl(leaf, 1, zt, zu, niter, in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], out[0], out[1], out[2], out[3],
+                          out[4], out[5], AB_MEM_HOST, nullptr, &fi);
+    if (rc) { delete fi.keep; return rc; }
+    memcpy(stats, fi.stats, sizeof fi.stats);
+    *guess = fi.guess;
+    *keep = fi.keep;
+    return AB_OK;
+}
+int leaf_fused_redo(ab_session *s, FusedShard *k)
+{
+    ab::DeviceGuard dguard_;
+    AB_HIP(hipSetDevice(s->device));
+    k->c.hum_type = s->hum_type;
+    AB_HIP(hipMemsetAsync(s->d_flags, 0, sizeof(int), s->stream));   // whatever the misjudged pass flagged is void
+    AB_HIP(ab::launch_flux(k->c, s->stream));
+    for (int i = 0; i < 6; ++i)
+        if (k->hout[i]) AB_HIP(hipMemcpyAsync(k->hout[i], k->dout[i], k->bytes, hipMemcpyDeviceToHost, s->stream));
+    AB_HIP(hipStreamSynchronize(s->stream));
+    return AB_OK;
+}
+void leaf_fused_release(FusedShard *k) { delete k; }
+}  // namespace ab
+
+extern "C" {
+
+// device-resident fields, one set of pointers per shard (include/aerobulk_amd.h)
+int ab_session_compute_shards(ab_session *s, int jt, double zt, double zu, int niter, const ab_shard_arrays *sh, void *const *streams)
+{
+    if (!s || !sh) return fail(AB_ERR_ARG, "ab_session_compute_shards: NULL argument");
+    if (s->sharded()) return ab::sharded_compute_shards(s, jt, zt, zu, niter, sh, streams);
+    return ab_session_compute(s, jt, zt, zu, niter, sh[0].sst, sh[0].t_zt, sh[0].hum_zt, sh[0].u_zu, sh[0].v_zu, sh[0].slp, sh[0].rad_sw,
+                              sh[0].rad_lw, sh[0].ql, sh[0].qh, sh[0].tau_x, sh[0].tau_y, sh[0].evap, sh[0].t_s, AB_MEM_DEVICE,
+                              streams ? streams[0] : nullptr);
+}
+
+int ab_session_gather(ab_session *s, int root_shard, const ab_shard_arrays *sh, const ab_flux_arrays *dst, void *const *streams,
+                      int synchronize)
+{
+    if (!s || !sh || !dst) return fail(AB_ERR_ARG, "ab_session_gather: NULL argument");
+    if (s->sharded()) return ab::sharded_gather(s, root_shard, sh, dst, streams, synchronize);
+    if (root_shard != 0) return fail(AB_ERR_ARG, "ab_session_gather: root shard %d of a one-shard session", root_shard);
+    ab::DeviceGuard dguard_;
+    AB_HIP(hipSetDevice(s->device));
+    hipStream_t st = streams ? (hipStream_t)streams[0] : nullptr;
+    const void *src[6] = {sh[0].ql, sh[0].qh, sh[0].tau_x, sh[0].tau_y, sh[0].evap, sh[0].t_s};
+    void *d[6] = {dst->ql, dst->qh, dst->tau_x, dst->tau_y, dst->evap, dst->t_s};
+    for (int f = 0; f < 6; ++f) {
+        if (!d[f]) continue;
+        if (!src[f]) return fail(AB_ERR_ARG, "ab_session_gather: field %d wanted but the shard has no such output", f);
+        if (d[f] != src[f]) AB_HIP(hipMemcpyAsync(d[f], src[f], s->esz * (size_t)s->n, hipMemcpyDeviceToDevice, st));
+    }
+    if (synchronize) AB_HIP(hipStreamSynchronize(st));
     return AB_OK;
 }
 
@@ -894,6 +1002,13 @@ int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double
             // rad present but l_use_skin false => no skin, T_s = sst (mod_aerobulk_compute.f90:132,206): handled by compute
             return compute_impl(g_sess, jt, zt, zu, g_nb_iter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, ql, qh, tau_x, tau_y,
                                 evap, lsrad ? t_s : nullptr, AB_MEM_HOST, nullptr, &fi);
+        }
+        // sharded: the same, every shard on its own device and PCIe link; the verdict is taken on the combined statistics
+        if (g_sess->sharded() && g_sess->shards[0]->n >= kPipeThreshold && !g_sess->shards[0]->diag_on && (!lsrad || use_skin) &&
+            !getenv("AEROBULK_AMD_NO_FUSED_INIT")) {
+            const void *in8[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw};
+            void *out6[6] = {ql, qh, tau_x, tau_y, evap, lsrad ? (void *)t_s : nullptr};
+            return ab::sharded_model_first_record(g_sess, zt, zu, g_nb_iter, in8, out6, lsrad ? 1 : 0, report);
         }
         // the reference hands rad_lw to BOTH prsw and prlw (mod_aerobulk.f90:248)
         int rc = ab_session_init(g_sess, sst, t_zt, hum_zt, u_zu, v_zu, slp, lsrad ? rad_lw : nullptr,

@@ -31,6 +31,8 @@ struct ab_session {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;  // copy streams of the pipelined host path
     hipStream_t last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_done = nullptr;     // recorded on the caller's stream at the end of every device-mode call: what destroy / state
+    bool done_pending = false;        // readers wait for (the caller may have destroyed its stream by then; the event is ours)
     bool timed = false;
     // AEROBULK_MODEL at jt == 1 (ab_model): the fields AEROBULK_INIT staged in HBM are the ones aerobulk_compute reads next.
     // staged_from[i] = the host array stage_in[i] was last filled from; reuse_staged = honour it in the next host compute
@@ -41,7 +43,21 @@ struct ab_session {
     std::vector<ab_session *> shards;
     std::vector<long> shard_j0, shard_njl;
     bool sharded() const { return !shards.empty(); }
+    void *pool = nullptr;             // ab_sharded.hip: persistent worker threads, one per shard (host-array calls)
+    void *gather = nullptr;           // ab_sharded.hip: RCCL communicator over the session's distinct devices (created at the first gather)
 };
+
+namespace ab {
+// The library switches the calling thread's current HIP device to the session's; callers (torch, a model's own HIP code) must find
+// theirs unchanged afterwards: every public entry point that calls hipSetDevice holds one of these.
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+}  // namespace ab
 
 namespace ab {
 // last-error plumbing across the worker threads of the sharding layer (ab_last_error() is per thread)
@@ -60,4 +76,15 @@ int sharded_set_solar_time(ab_session *s, int isecday_utc, const void *lon, int 
 int sharded_set_diagnostics(ab_session *s, const ab_diag *d, int mem);
 int sharded_get_wl_state(ab_session *s, double *state4n);
 double sharded_last_kernel_ms(ab_session *s);
+int sharded_compute_shards(ab_session *s, int jt, double zt, double zu, int niter, const ab_shard_arrays *sh, void *const *streams);
+int sharded_gather(ab_session *s, int root, const ab_shard_arrays *sh, const ab_flux_arrays *dst, void *const *streams, int synchronize);
+// AEROBULK_MODEL at jt == 1 through a sharded session: AEROBULK_INIT's statistics ride on every shard's pipelined pass
+int sharded_model_first_record(ab_session *s, double zt, double zu, int niter, const void *const in[8], void *const out[6], int have_rad,
+                               ab_init_report *report);
+// leaf side of it (ab_runtime.hip): one shard's fused pass (statistics returned, not applied), and its redo with another humidity type
+struct FusedShard;
+int leaf_fused_first_record(ab_session *leaf, double zt, double zu, int niter, const void *const in[8], void *const out[6], int have_rad,
+                            double stats[AB_INIT_NSTATS], int *guess, FusedShard **keep);
+int leaf_fused_redo(ab_session *leaf, FusedShard *keep);
+void leaf_fused_release(FusedShard *keep);
 }  // namespace ab

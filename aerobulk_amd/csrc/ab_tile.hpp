@@ -49,6 +49,9 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false> struct Tile {
 #ifndef AB_NOSKIN_OCC
 #define AB_NOSKIN_OCC 5
 #endif
+#ifndef AB_COARE3P0_NOSKIN_OCC   // COARE 3.0 without the skin schemes: 96 VGPRs + 36 B of scratch at five waves once its psi comes from the L1 tables; four waves, no scratch: -12 % against -8 %
+#define AB_COARE3P0_NOSKIN_OCC 4
+#endif
 #ifndef AB_F32_OCC
 #define AB_F32_OCC 7
 #endif
@@ -70,7 +73,7 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false> struct Tile {
 #define AB_MIXED_NOSKIN_OCC 7
 #endif
     static constexpr int kOcc = MIXED ? (SKIN ? (ALGO == 4 ? AB_MIXED_OCC : AB_MIXED_COARE_OCC) : AB_MIXED_NOSKIN_OCC)
-                                : sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : AB_NOSKIN_OCC)
+                                : sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : ((ALGO == 1 && AB_COARE3P0_NOSKIN_OCC) ? AB_COARE3P0_NOSKIN_OCC : AB_NOSKIN_OCC))
                                                : (SKIN ? (ALGO == 4 ? AB_F32_ECMWF_OCC : AB_F32_OCC) : AB_F32_NOSKIN_OCC);
     static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
     // The kWaves blocks of a CU share its 160 KB of LDS.  Per block, besides the tile (fields + a 2-byte index per cell): the sort's
@@ -79,7 +82,10 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false> struct Tile {
     // piecewise psi / e_sat tables (ab_physics.hpp: 5 120 B in fp64 with the skin schemes, 3 584 B without, 1 536 B in fp32).  The fp64
     // flux kernels with the skin schemes come out at exactly two rounds with 280 B to spare: nothing is left in LDS.
 #ifdef AB_PSI_LDS_TABLES
-    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? (SKIN ? 5120 : 3584) : (MIXED ? 3072 : 1536);   // (the e_sat table: fp64 kernels with the skin schemes, mixed kernels)
+    // fp64: the e_sat table (kernels with the skin schemes) + the Kansas psi_m table (ECMWF, ANDREAS; COARE reads its psi through L1);
+    // fp32: the three psi tables (+ e_sat: mixed)
+    // (COARE with the skin schemes: + the cool skin's g(u) table, 3 584 B)
+    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3584 : 0) : 1792) : (MIXED ? 3072 : 1536);
 #else
     static constexpr int kPsiTabBytes = 0;
 #endif

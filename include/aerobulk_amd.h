@@ -138,6 +138,39 @@ int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter,
                        int mem, void *stream);
 int ab_session_check(ab_session *s);
 
+/* ---- device-resident fields of a sharded session, and the gather of the fluxes ------------------------------------------------
+ * The north_star's multi-GPU layout: the global grid is cut by row blocks across the GPUs of a node, every GPU computes its rows
+ * from fields that already live in its HBM, and the output tau / Q_L / Q_H / E arrays are gathered over xGMI — "a trivial RCCL
+ * gather", no halo (the path is pointwise).  Call site served: AEROBULK_MODEL's coupling call, mod_aerobulk.f90:250-262, in a
+ * model whose fields are GPU-resident and sharded like the session (ab_session_shard_info gives each shard's rows and device).
+ *
+ * ab_session_compute_shards: ab_session_compute(AB_MEM_DEVICE) with ONE SET OF POINTERS PER SHARD: shard r's arrays hold its
+ * rows only (ni * nj_r elements) on its device.  `streams` (hipStream_t per shard, or NULL / NULL entries = the default stream of
+ * the shard's device): the kernels are enqueued there, asynchronously; ab_session_check() synchronises and collects AB_ERR_TAU.
+ * An ordinary session is a one-shard session here.
+ *
+ * ab_session_gather: copies the shards' flux arrays into whole-grid arrays `dst` (ni * nj elements each) on the device of shard
+ * `root_shard`; shard r's rows land at element offset ni * j0_r.  Members of `dst` that are NULL are not gathered (the north_star
+ * names tau, Q_L, Q_H, E: five arrays; T_s usually stays where it was computed).  Shards on other devices travel by RCCL inside the
+ * process: one communicator over the DISTINCT devices of the session (ncclCommInitAll, created at the first gather, kept), one
+ * ncclGroup of per-peer ncclSend / ncclRecv per call — RCCL has no native gather — straight from the shard's array into its place
+ * in `dst` (no packing, no staging copy); shards that share the root's device are device-to-device copies.  Each transfer is
+ * ordered behind the work already enqueued on its shard's stream (the compute that produced the fluxes), and the receives are
+ * enqueued on the root shard's stream: asynchronous unless `synchronize` != 0.  librccl.so is loaded on first use (dlopen);
+ * a session whose shards all live on one device never touches it.
+ * Measured on one GPU only (k shards on one device, 1-device communicator): no multi-device run has happened yet. */
+typedef struct ab_shard_arrays {
+    const void *sst, *t_zt, *hum_zt, *u_zu, *v_zu, *slp, *rad_sw, *rad_lw;   /* inputs: the shard's rows, on the shard's device */
+    void *ql, *qh, *tau_x, *tau_y, *evap, *t_s;                               /* outputs (evap, t_s may be NULL) */
+} ab_shard_arrays;
+typedef struct ab_flux_arrays {
+    void *ql, *qh, *tau_x, *tau_y, *evap, *t_s;
+} ab_flux_arrays;
+int ab_session_compute_shards(ab_session *s, int jt, double zt, double zu, int niter, const ab_shard_arrays *shards,
+                              void *const *streams);
+int ab_session_gather(ab_session *s, int root_shard, const ab_shard_arrays *shards, const ab_flux_arrays *dst,
+                      void *const *streams, int synchronize);
+
 /* Lane regrouping of the flux kernel (default on).  A thread block owns a tile of 512-1280 consecutive cells, parks their
  * pre-processed inputs in LDS and sorts them so that each 64-lane wave works on cells that take the same branches (stable /
  * unstable stratification, warm layer gaining heat / idle): on spatially incoherent input this removes most of the SIMT

@@ -15,7 +15,7 @@ def test_cost_model_builds_runs_and_matches_the_oracle(tmp_path, oracle):
     m = re.search(r"coare3p6 skin=1 nb_iter=5, (\d+) cells: (\d+) slots per cell \(sum QL ([-+0-9.e]+)\)", out)
     assert m, out[:300]
     ncell, slots, sum_ql = int(m.group(1)), int(m.group(2)), float(m.group(3))
-    assert 4000 < slots < 6500
+    assert 3000 < slots < 6500
     # the same cells through the oracle (the model samples the 4320 x 3600 benchmark fields at i = 6, 12, ..., j = 10, 20, ...):
     # the model executes the real arithmetic, so the checksum must agree
     import numpy as np

@@ -60,14 +60,15 @@ def oracle_parallel(algo, skin, niter, f64, nt=1):
     return [{k: np.concatenate([p[jt][k] for p in parts]) for k in parts[0][jt]} for jt in range(nt)]
 
 
-def check_restated(got, ref, label, tol=TOL, share=OUTLIER_SHARE, p99=None):
-    """Asserts the restated tolerance with its outlier budget; returns the report."""
+def check_restated(got, ref, label, tol=TOL, share=OUTLIER_SHARE, p99=None, tol_ts=None):
+    """Asserts the restated tolerance with its outlier budget; returns the report.  tol_ts: bar of T_s [K] if not `tol` (T_s is an fp32
+    number of about 300 K: its last bit is 3e-5 K)."""
     rep = {}
     for c, k in OUT:
         if c not in got:
             continue
         e = restated_error(got[c], ref[k], k)
-        n_out = int((e > tol).sum())
+        n_out = int((e > (tol_ts if (tol_ts is not None and FLOOR[k] is None) else tol)).sum())
         rep[k] = dict(p50=float(np.quantile(e, 0.5)), p99=float(np.quantile(e, 0.99)), p9999=float(np.quantile(e, 0.9999)), max=float(e.max()),
                       n=int(e.size), n_gt_tol=n_out)
     print(label, rep)
@@ -160,7 +161,7 @@ def test_orca36_fp32_sessions_against_the_oracle_on_a_subsample():
             check_restated(g, ref, "ORCA36 subsample f32_mixed", p99=3e-6)
             full = got
         elif prec == "f32_storage":
-            check_restated(g, ref, "ORCA36 subsample f32_storage", tol=1e-6, share=0.0)
+            check_restated(g, ref, "ORCA36 subsample f32_storage", tol=1e-6, share=0.0, tol_ts=2e-5)
         else:
             for c, k in OUT:
                 e = restated_error(g[c], ref[k], k)

@@ -61,7 +61,7 @@ def test_lds_of_the_resident_blocks_fits_the_cu(remarks):
             assert v["LDS"] < 4096            # NCAR: direct kernel, math tables only
             continue
         if r == "d":
-            occ = 4 if (skin or diag) else 5  # Tile::kOcc; the DIAG instantiations are launched for four waves
+            occ = 4 if (skin or diag or algo == 1) else 5  # Tile::kOcc; the DIAG instantiations are launched for four waves, COARE 3.0 without skin too
         elif a == "d":                        # mixed: fp32 work, fp64 anchors
             occ = 4 if diag else ((6 if algo == 4 else 5) if skin else 7)
         else:
