@@ -215,6 +215,7 @@ int ab_session_destroy(ab_session *s)
     if (s->d_lon) (void)hipFree(s->d_lon);
     if (s->d_flags) (void)hipFree(s->d_flags);
     if (s->d_partials) (void)hipFree(s->d_partials);
+    if (s->d_fused) (void)hipFree(s->d_fused);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev_done) (void)hipEventDestroy(s->ev_done);
@@ -628,7 +629,16 @@ static int compute_impl(ab_session *s, int jt, double zt, double zu, int niter, 
 
     if (pipelined) {
         const int nch = (int)((s->n + kPipeChunk - 1) / kPipeChunk);
-        if (fi) AB_HIP(hipMalloc((void **)&fi->d_part, sizeof(double) * (size_t)nch * kFusedBlocks * ab::kStatStride));
+        if (fi) {   // rows for the statistics: a session-owned buffer (allocated once; round 2 allocated and freed one per first record)
+            const size_t rows = (size_t)nch * kFusedBlocks;
+            if (s->d_fused_rows < rows) {
+                if (s->d_fused) AB_HIP(hipFree(s->d_fused));
+                s->d_fused = nullptr; s->d_fused_rows = 0;
+                AB_HIP(hipMalloc((void **)&s->d_fused, sizeof(double) * rows * ab::kStatStride));
+                s->d_fused_rows = rows;
+            }
+            fi->d_part = s->d_fused;
+        }
         hipError_t e = compute_host_pipelined(s, c, host_in, hout, fi);
         s->timed = true;
         s->last_stream = st;
@@ -636,8 +646,10 @@ static int compute_impl(ab_session *s, int jt, double zt, double zu, int niter, 
         if (fi) {
             // the global verdict: fold every chunk's rows, take AEROBULK_INIT's decisions (mod_aerobulk.f90:105-153)
             std::vector<double> part((size_t)nch * kFusedBlocks * ab::kStatStride);
-            if (e == hipSuccess) e = hipMemcpy(part.data(), fi->d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost);
-            (void)hipFree(fi->d_part);
+            // (on the session's stream: a synchronous hipMemcpy goes through the device's NULL stream — from the worker threads of a
+            // sharded session that left every later record 35 % slower, profiles/r3_host_path.txt)
+            if (e == hipSuccess) e = hipMemcpyAsync(part.data(), fi->d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
             fi->d_part = nullptr;
             AB_HIP(e);
             double stats[AB_INIT_NSTATS];
@@ -875,6 +887,32 @@ int ab_test_math(int op, const double *x, const double *y, double *out, long n)
 // pass with AEROBULK_INIT's statistics riding on it; the statistics are handed back (the verdict is global), `keep` holds what a
 // redo needs.  Called from the shard's worker thread.
 namespace ab {
+// staging buffers of the host path, allocated from the calling thread, one shard after the other (sharded_model_first_record: measured —
+// when the shards' worker threads allocate them concurrently inside their first pipelined pass, every record that follows moves
+// over PCIe at 63 GB/s instead of 85, profiles/r3_host_path.txt)
+int leaf_prepare_staging(ab_session *s, int with_rad, int with_ts, const void *host_in0, void *host_out0)
+{
+    ab::DeviceGuard dguard_;
+    AB_HIP(hipSetDevice(s->device));
+    const size_t bytes = s->esz * (size_t)s->n;
+    const bool first = !s->stage_in[0];
+    for (int i = 0; i < 8; ++i)
+        if ((i < 6 || with_rad) && !s->stage_in[i]) AB_HIP(hipMalloc(&s->stage_in[i], bytes));
+    for (int i = 0; i < 6; ++i)
+        if ((i < 5 || with_ts) && !s->stage_out[i]) AB_HIP(hipMalloc(&s->stage_out[i], bytes));
+    if (first && host_in0 && host_out0) {
+        // The shard's copy streams carry their FIRST transfer here, alone — one chunk in, one chunk out (the record overwrites both).
+        // Measured on k shards of one device (profiles/r3_host_path.txt): when the shards' very first transfers are the concurrent
+        // chunk pipelines of their workers, EVERY later record moves at 63 GB/s instead of 85 (20.7 -> 27.8 ms per ORCA12 record,
+        // sticky for the life of the process); with each shard's first transfer made alone it does not happen.
+        const size_t cb = bytes < (size_t)kPipeChunk * s->esz ? bytes : (size_t)kPipeChunk * s->esz;
+        AB_HIP(hipMemcpyAsync(s->stage_in[0], host_in0, cb, hipMemcpyHostToDevice, s->s_h2d));
+        AB_HIP(hipStreamSynchronize(s->s_h2d));
+        AB_HIP(hipMemcpyAsync(host_out0, s->stage_out[0], cb, hipMemcpyDeviceToHost, s->s_d2h));
+        AB_HIP(hipStreamSynchronize(s->s_d2h));
+    }
+    return AB_OK;
+}
 int leaf_fused_first_record(ab_session *leaf, double zt, double zu, int niter, const void *const in[8], void *const out[6], int have_rad,
                             double stats[AB_INIT_NSTATS], int *guess, FusedShard **keep)
 {

@@ -21,6 +21,8 @@ struct ab_session {
     void *wl[4] = {nullptr, nullptr, nullptr, nullptr};
     int *d_flags = nullptr;
     double *d_partials = nullptr;
+    double *d_fused = nullptr;        // partial rows of the statistics that ride on the pipelined first record (kept: no malloc / free per loop)
+    size_t d_fused_rows = 0;
     void *stage_in[8] = {nullptr};    // device staging for AB_MEM_HOST callers
     void *stage_out[6] = {nullptr};
     void *diag_user[16] = {nullptr};  // caller's diagnostic arrays (ab_session_set_diagnostics), host or device
@@ -86,5 +88,6 @@ struct FusedShard;
 int leaf_fused_first_record(ab_session *leaf, double zt, double zu, int niter, const void *const in[8], void *const out[6], int have_rad,
                             double stats[AB_INIT_NSTATS], int *guess, FusedShard **keep);
 int leaf_fused_redo(ab_session *leaf, FusedShard *keep);
+int leaf_prepare_staging(ab_session *leaf, int with_rad, int with_ts, const void *host_in0, void *host_out0);
 void leaf_fused_release(FusedShard *keep);
 }  // namespace ab

@@ -325,7 +325,11 @@ int sharded_model_first_record(ab_session *s, double zt, double zu, int niter, c
     std::vector<int> guess(n, AB_HUM_SH);
     std::vector<FusedShard *> keep(n, nullptr);
     auto release = [&] { for (auto &k : keep) { leaf_fused_release(k); k = nullptr; } };
-    int rc = for_shards(s, true, [&](int r) {
+    int rc = for_shards(s, false, [&](int r) {
+        return leaf_prepare_staging(s->shards[r], in[6] && in[7], out[5] != nullptr, off(s, in[0], s->shard_j0[r]), offw(s, out[0], s->shard_j0[r]));
+    });
+    if (rc) return rc;
+    rc = for_shards(s, true, [&](int r) {
         const long j0 = s->shard_j0[r];
         const void *cin[8];
         void *cout[6];

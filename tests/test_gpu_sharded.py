@@ -231,3 +231,108 @@ def test_two_ranks_each_with_a_sharded_session(oracle, tmp_path):
             o = s.compute(jt, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
             for i, k in enumerate(OUT):
                 np.testing.assert_array_equal(glob[jt - 1, i], o[k], err_msg=f"jt={jt} {k}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Device-resident shards and the gather of the fluxes (include/aerobulk_amd.h: ab_session_compute_shards / ab_session_gather): the
+# north_star's layout — rows sharded across GPUs, fields resident, "a trivial RCCL gather of the output tau/Q_L/Q_H/E arrays".  The
+# test box has ONE GPU: k shards on it exercise the shard bookkeeping, the per-shard launches, the placement of every shard's rows and
+# the stream ordering; AEROBULK_AMD_GATHER=rccl sends the same rows through ncclSend / ncclRecv on a one-device communicator (a rank
+# talking to itself).  No multi-device run has happened.
+def _shards_and_gather(ab, oracle, algo, skin, nsh, root, gather_ts, precision="f64"):
+    import torch
+    ni, nj, nt = 192, 100, 2
+    f = oracle.synth_fields(ni, nj)
+    dt = torch.float64 if precision == "f64" else torch.float32
+    names = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")
+    keys = ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp", "rad_sw", "rad_lw")
+    whole = {k: torch.from_numpy(f[n]).to(dt).cuda() for n, k in zip(names, keys)}
+    outs = ("QL", "QH", "Tau_x", "Tau_y", "Evap") + (("T_s",) if skin else ())
+    with ab.Session(algo, ni, nj, nt, skin, precision=precision) as s:
+        ref = []
+        for jt in range(1, nt + 1):
+            o = s.compute(jt, 2.0, 10.0, *[whole[k] for k in keys[:6]], Niter=5, rad_sw=whole["rad_sw"] if skin else None,
+                          rad_lw=whole["rad_lw"] if skin else None)
+            ref.append({k: v.clone() for k, v in o.items()})
+    dev_before = torch.cuda.current_device()
+    with ab.Session(algo, ni, nj, nt, skin, precision=precision, device=[0] * nsh) as s:
+        assert torch.cuda.current_device() == dev_before          # round-2 advisory: the caller's device is the caller's
+        sh = s.shards()
+        fields = [{k: whole[k][j0 * ni:(j0 + njl) * ni].clone() for k in (keys if skin else keys[:6])} for j0, njl, _ in sh]
+        for jt in range(1, nt + 1):
+            shard_out = [{k: torch.empty(ni * njl, dtype=dt, device="cuda") for k in outs} for _, njl, _ in sh]
+            s.compute_shards(jt, 2.0, 10.0, fields, shard_out, Niter=5)
+            want = outs if gather_ts else outs[:5]
+            dst = {k: torch.full((ni * nj,), float("nan"), dtype=dt, device="cuda") for k in want}
+            s.gather(shard_out, dst, root=root)
+            for k in want:
+                assert torch.equal(dst[k], ref[jt - 1][k]), (algo, jt, k)
+        assert torch.cuda.current_device() == dev_before
+
+
+@pytest.mark.parametrize("algo,skin,nsh,root,gather_ts", [("coare3p6", True, 3, 0, True), ("ecmwf", True, 4, 2, False), ("ncar", False, 2, 1, False),
+                                                          ("coare3p6", True, 1, 0, True)])
+def test_device_resident_shards_and_gather(oracle, algo, skin, nsh, root, gather_ts):
+    import aerobulk_amd as ab
+    _shards_and_gather(ab, oracle, algo, skin, nsh, root, gather_ts)
+
+
+def test_gather_through_rccl_on_a_one_device_communicator(oracle, tmp_path):
+    """The RCCL leg of ab_session_gather — dlopen of librccl, ncclCommInitAll, one group of ncclSend / ncclRecv per gather straight
+    into the rows of the destination — on the one GPU of the box: AEROBULK_AMD_GATHER=rccl makes every shard but the root's own travel
+    that way (rank 0 to rank 0).  fp64 and fp32 arrays; same bits as the unsharded session."""
+    script = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import aerobulk_amd as ab
+from oracle import pyoracle as po
+from test_gpu_sharded import _shards_and_gather
+_shards_and_gather(ab, po, "coare3p6", True, 3, 1, True)
+_shards_and_gather(ab, po, "ecmwf", True, 2, 0, False, precision="f32_mixed")
+print("GATHER_OK")
+'''
+    e = dict(os.environ, AEROBULK_AMD_GATHER="rccl")
+    pr = subprocess.run([sys.executable, "-c", script, ROOT], env=e, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0 and "GATHER_OK" in pr.stdout, pr.stdout[-2000:] + pr.stderr[-4000:]
+
+
+def test_first_record_of_aerobulk_model_is_fused_for_shards_too(oracle, tmp_path):
+    """AEROBULK_MODEL at jt == 1 through AEROBULK_AMD_DEVICES=0,0 on a grid large enough for the pipelined path (each shard >= 4 Mi
+    cells): AEROBULK_INIT's statistics ride on every shard's pass, the verdict is taken on the COMBINED statistics, and a shard whose
+    first chunk misjudged the humidity type computes its rows again from its resident fields — here the domain is relative humidity
+    and the first 2^20 cells of shard 1 alone read as specific humidity.  Same results and the same report as the two-pass path
+    (AEROBULK_AMD_NO_FUSED_INIT=1) and as one device."""
+    script = r'''
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+import aerobulk_amd as ab
+from oracle import pyoracle as po
+ni, nj = 2048, 4200                       # 8.6 M cells: two shards of 2100 rows = 4.3 M cells each
+f = po.synth_fields(ni, nj)
+rh = 30.0 + 60.0 * f["rad_sw"] / 900.0    # 30 .. 90 %
+o1 = ni * 2100
+rh[o1: o1 + (1 << 20)] = 0.05             # the first chunk of shard 1 alone reads as 'sh' (all < 0.08)
+F = {k: v.reshape((ni, nj), order="F") for k, v in dict(f, hum_zt=rh).items()}
+args = [F[k] for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")]
+r = ab.aerobulk_model(1, 1, "coare3p6", 2.0, 10.0, *args, Niter=4, l_use_skin=True, rad_sw=F["rad_sw"], rad_lw=F["rad_lw"])
+np.save(sys.argv[2], np.stack([r[k] for k in ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")]))
+print("REPORT " + json.dumps(r["init_report"]))
+'''
+    res, reps = {}, {}
+    for tag, extra in (("fused", {}), ("twopass", {"AEROBULK_AMD_NO_FUSED_INIT": "1"}), ("one", None)):
+        e = dict(os.environ)
+        e.pop("AEROBULK_AMD_DEVICES", None)
+        e.pop("AEROBULK_AMD_NO_FUSED_INIT", None)
+        if extra is not None:
+            e["AEROBULK_AMD_DEVICES"] = "0,0"
+            e.update(extra)
+        out = str(tmp_path / f"{tag}.npy")
+        pr = subprocess.run([sys.executable, "-c", script, ROOT, out], env=e, capture_output=True, text=True, timeout=900)
+        assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-4000:]
+        res[tag] = np.load(out)
+        reps[tag] = [ln for ln in pr.stdout.splitlines() if ln.startswith("REPORT ")][0]
+        if tag == "fused":
+            assert "computed again" in pr.stderr          # the recompute is announced (round-2 advisory)
+    assert reps["fused"] == reps["twopass"] == reps["one"] and '"hum_type": "rh"' in reps["fused"], reps
+    np.testing.assert_array_equal(res["fused"], res["twopass"])
+    np.testing.assert_array_equal(res["fused"], res["one"])
