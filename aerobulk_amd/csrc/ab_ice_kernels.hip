@@ -5,10 +5,6 @@
 // LU12, + 8 B per OPTIONAL output).  NEMO / LU12 are HBM-bound (no iteration), AN05 / LG15 VALU-bound like the open-ocean
 // algorithms.
 // these kernels keep four waves per SIMD on every instantiation (some would spill at five; next-tier rows, not tuned per kernel)
-#define AB_NOSKIN_OCC 4
-#define AB_F32_OCC 4
-#define AB_F32_ECMWF_OCC 4
-#define AB_F32_NOSKIN_OCC 4
 #include "ab_kernels.hpp"
 #include "ab_physics_ice.hpp"
 #include "ab_launch.hpp"
@@ -45,7 +41,7 @@ __device__ __forceinline__ void ice_cell(const IceArgs<R> &a, const Heights<R> &
 // NEMO / LU12 (no iteration, HBM-bound): one lane per cell.  AN05 / LG15 / EASY (nb_iter iterations with stable / unstable branches):
 // the LDS-staged, regrouped tiles of flux_kernel (ab_tile.hpp); the bucket is the sign of the air-ice virtual temperature
 // difference in four bins.
-template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, (Tile<R, ALGO, false>::kOcc)) ice_kernel(const IceArgs<R> a)
+template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, (Tile<R, ALGO, false, false, kTileFour>::kOcc)) ice_kernel(const IceArgs<R> a)
 {
     math_tables_init<R>();
     if (ALGO == 1 || ALGO == 3) {
@@ -62,7 +58,7 @@ template <class R, int ALGO> __global__ void __launch_bounds__(kBlock, (Tile<R, 
             if (a.out[i]) a.out[i][k] = d[i];
         return;
     }
-    using T = Tile<R, ALGO, false>;               // 6 fields: in Ts theta qs q U ; out the six mandatory results
+    using T = Tile<R, ALGO, false, false, kTileFour>;               // 6 fields: in Ts theta qs q U ; out the six mandatory results
     __shared__ R s_f[T::kFields][T::kCells];
     __shared__ unsigned short s_inv[T::kCells];
     __shared__ unsigned s_cnt[kSortCounters], s_base[kSortCounters];
@@ -143,7 +139,7 @@ template <class R, int ALGO> static hipError_t launch_t(const IceCall &c, hipStr
     a.nb_iter = c.nb_iter;
     for (int i = 0; i < 3; ++i) a.cxn[i] = (R)c.cxn[i];
     a.regroup = 1;
-    a.rounds = tile_rounds(c.n, Tile<R, ALGO, false>::kRounds, Tile<R, ALGO, false>::kOcc);
+    a.rounds = tile_rounds(c.n, Tile<R, ALGO, false, false, kTileFour>::kRounds, Tile<R, ALGO, false, false, kTileFour>::kOcc);
     const long tile = (ALGO == 1 || ALGO == 3) ? kBlock : (long)a.rounds * kBlock;
     const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;

@@ -2,6 +2,7 @@
 // budget of a block, forecast of a cell's divergent predicates, counting sort of a tile's cells by bucket, tile size on small grids.
 // The method is described at flux_kernel.  Internal; include after ab_physics.hpp and ab_launch.hpp.
 #pragma once
+#include <atomic>
 
 namespace ab {
 
@@ -40,7 +41,11 @@ template <class R> __device__ __forceinline__ Heights<R> detached(const Heights<
 }     // 4 stability bins x 4 warm-layer bins
 // MIXED: the AB_F32_MIXED flux kernels (R = float with fp64 anchors): one more field (the low part of theta), the fp64 math tables
 // and the e_sat table next to the fp32 psi tables
-template <class R, int ALGO, bool SKIN, bool MIXED = false> struct Tile {
+// POLICY: kTileFlux = the flux kernels of ab_kernels.hip (occupancies tuned per kernel family, piecewise tables in LDS); kTileFour = four
+// waves per SIMD and no LDS tables (turb_kernel, ice_kernel).  A template parameter, not a macro redefined per translation unit: the same
+// specialisation must mean the same thing everywhere (round-2 advisory: ODR).
+constexpr int kTileFlux = 0, kTileFour = 1;
+template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFlux> struct Tile {
     static constexpr int kFields = (SKIN ? 8 : 6) + (MIXED ? 1 : 0);   // flux: sst theta q_zt u v slp [qsw rlw] [theta_lo] ; turb: 8 / 6 too
     // Waves per SIMD (= resident blocks per CU) a kernel is built for.  The fp64 kernels with the skin schemes need 107-127 VGPRs:
     // four.  Without them 72-95 VGPRs: five, on two-round tiles (-3...-4 % COARE, -1 % ECMWF; config 2 -3 %).  The fp32 kernels,
@@ -72,7 +77,8 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false> struct Tile {
 #ifndef AB_MIXED_NOSKIN_OCC
 #define AB_MIXED_NOSKIN_OCC 7
 #endif
-    static constexpr int kOcc = MIXED ? (SKIN ? (ALGO == 4 ? AB_MIXED_OCC : AB_MIXED_COARE_OCC) : AB_MIXED_NOSKIN_OCC)
+    static constexpr int kOcc = POLICY == kTileFour ? 4
+                                : MIXED ? (SKIN ? (ALGO == 4 ? AB_MIXED_OCC : AB_MIXED_COARE_OCC) : AB_MIXED_NOSKIN_OCC)
                                 : sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : ((ALGO == 1 && AB_COARE3P0_NOSKIN_OCC) ? AB_COARE3P0_NOSKIN_OCC : AB_NOSKIN_OCC))
                                                : (SKIN ? (ALGO == 4 ? AB_F32_ECMWF_OCC : AB_F32_OCC) : AB_F32_NOSKIN_OCC);
     static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
@@ -81,14 +87,9 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false> struct Tile {
     // s_exptab 512 B, s_ctab 144 B: 1 792 B with alignment), and, in the translation units that define AB_PSI_LDS_TABLES, the
     // piecewise psi / e_sat tables (ab_physics.hpp: 5 120 B in fp64 with the skin schemes, 3 584 B without, 1 536 B in fp32).  The fp64
     // flux kernels with the skin schemes come out at exactly two rounds with 280 B to spare: nothing is left in LDS.
-#ifdef AB_PSI_LDS_TABLES
     // fp64: the e_sat table (kernels with the skin schemes) + the Kansas psi_m table (ECMWF, ANDREAS; COARE reads its psi through L1);
-    // fp32: the three psi tables (+ e_sat: mixed)
-    // (COARE with the skin schemes: + the cool skin's g(u) table, 3 584 B)
-    static constexpr int kPsiTabBytes = sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3584 : 0) : 1792) : (MIXED ? 3072 : 1536);
-#else
-    static constexpr int kPsiTabBytes = 0;
-#endif
+    // (COARE with the skin schemes: + the cool skin's g(u) table, 3 584 B); fp32: the three psi tables (+ e_sat: mixed)
+    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3584 : 0) : 1792) : (MIXED ? 3072 : 1536));
     static constexpr int kBudget = 160 * 1024 / kWaves - 256 - ((sizeof(R) == 8 || MIXED) ? 1792 : 0) - kPsiTabBytes;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 2)); // f64: 2 (skin, 4 blocks) / 2 (5 blocks); f32: 2
     static constexpr int kCells = kRounds * kBlock;
@@ -195,18 +196,20 @@ __device__ __forceinline__ void tile_sort_place(const unsigned *s_cnt, unsigned 
             s_inv[s_base[(key[r] >> kSortRankBits) * kSortSub + sub] + (key[r] & ((1u << kSortRankBits) - 1u))] = (unsigned short)(r * kBlock + tid);
 }
 
-// blocks the chip holds at once: AB_WAVES_PER_EU per CU (one wave of each block per SIMD)
+// blocks the chip holds at once: AB_WAVES_PER_EU per CU (one wave of each block per SIMD).  The CU count is cached per DEVICE, in atomics:
+// the shards of a sharded session call this from their worker threads, each with its own current device (round-2 advisory)
 static inline long resident_block_slots(int occ = AB_WAVES_PER_EU)
 {
-    if (occ != AB_WAVES_PER_EU) return resident_block_slots() / AB_WAVES_PER_EU * occ;
-    static long slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        slots = (long)cus * (AB_WAVES_PER_EU * 256 / kBlock);
+    static std::atomic<int> cus_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::atomic<int> &slot = cus_of[dev & 63];
+    int cus = slot.load(std::memory_order_relaxed);
+    if (cus <= 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slot.store(cus, std::memory_order_relaxed);
     }
-    return slots;
+    return (long)cus * (occ * 256 / kBlock);
 }
 
 // full tiles when the grid fills the chip several times over; smaller ones on small grids so that every CU gets work

@@ -7,10 +7,6 @@
 // station drivers use (tests/test_aerobulk_buoy_series_oce.f90:452-487), with the real solar time of WL_COARE.
 // Same per-cell physics (ab_physics.hpp) and the same LDS-staged, regrouped tiles as flux_kernel (ab_kernels.hip, ab_tile.hpp).
 // these kernels keep four waves per SIMD on every instantiation (some would spill at five; next-tier rows, not tuned per kernel)
-#define AB_NOSKIN_OCC 4
-#define AB_F32_OCC 4
-#define AB_F32_ECMWF_OCC 4
-#define AB_F32_NOSKIN_OCC 4
 #include "ab_kernels.hpp"
 #include "ab_physics.hpp"
 #include "ab_launch.hpp"
@@ -69,7 +65,7 @@ __device__ __forceinline__ void turb_cell(const TurbArgs<R> &a, const Heights<R>
 // Same four phases as flux_kernel (ab_kernels.hip): owners park the inputs of a tile in LDS and forecast each cell's
 // branches, the tile is sorted, waves fetch groups of like-behaved cells, owners store.  NCAR keeps one lane per cell.
 template <class R, int ALGO, int SKIN>
-__global__ void __launch_bounds__(kBlock, (Tile<R, ALGO, (SKIN != 0)>::kOcc)) turb_kernel(const TurbArgs<R> a)
+__global__ void __launch_bounds__(kBlock, (Tile<R, ALGO, (SKIN != 0), false, kTileFour>::kOcc)) turb_kernel(const TurbArgs<R> a)
 {
     math_tables_init<R>();
     constexpr bool ANYSKIN = SKIN != 0;
@@ -85,7 +81,7 @@ __global__ void __launch_bounds__(kBlock, (Tile<R, ALGO, (SKIN != 0)>::kOcc)) tu
         for (int i = 0; i < 6; ++i) a.out[i][k] = res[i];
         return;
     }
-    using T = Tile<R, ALGO, ANYSKIN>;
+    using T = Tile<R, ALGO, ANYSKIN, false, kTileFour>;
     __shared__ R s_f[T::kFields][T::kCells];       // in: T_s theta q_s q_zt U [slp] [qsw rlw] ; out: the 8 results (6 without skin)
     __shared__ unsigned short s_inv[T::kCells];
     __shared__ unsigned s_cnt[kSortCounters], s_base[kSortCounters];
@@ -179,7 +175,7 @@ template <class R, int ALGO, int SKIN> static hipError_t launch_t(const TurbCall
     a.nb_iter = c.nb_iter; a.wl_load = c.wl_load; a.wl_store = c.wl_store; a.isecday = c.isecday;
     a.dawn_uniform = dawn_at_lon0(c.isecday);
     a.regroup = c.regroup ? 1 : 0;
-    a.rounds = tile_rounds(c.n, Tile<R, ALGO, (SKIN != 0)>::kRounds, Tile<R, ALGO, (SKIN != 0)>::kOcc);
+    a.rounds = tile_rounds(c.n, Tile<R, ALGO, (SKIN != 0), false, kTileFour>::kRounds, Tile<R, ALGO, (SKIN != 0), false, kTileFour>::kOcc);
     const long tile = (ALGO == 3) ? kBlock : (long)a.rounds * kBlock;
     const long nblk = (c.n + tile - 1) / tile;
     if (nblk <= 0) return hipSuccess;

@@ -141,15 +141,32 @@ def cpu_baseline(algo, skin, niter, zt, zu):
         dt = time.perf_counter() - t0
         return {"value": round(n / dt / 1e6, 4), "unit": "Mcell/s", "cores": 1, "kind": "port",
                 "sample": f"{algo}{'+skin' if skin else ''} nb_iter={niter} on a {ni}x{nj} slab of the same synthetic fields, {dt:.1f} s wall"}
-    dt1 = po.run_reference_all_cores(algo, skin, niter, ni, nj, 1)[0]
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    # one process per PHYSICAL core where the topology can be read (SMT siblings share the fp64 units: two processes per core gave
+    # 13.5 x one core on 64 logical CPUs in round 2), each pinned to its own core; capped so that the sample stays bounded
+    logical = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, physical = set(), []
+    for c in logical:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                key = fh.read().strip()
+        except OSError:
+            key = str(c)
+        if key not in seen:
+            seen.add(key)
+            physical.append(c)
+    cap = 64
+    cpus = physical[:cap]
+    cores = len(cpus)
+    dt1 = po.run_reference_all_cores(algo, skin, niter, ni, nj, 1, cpus=cpus[:1])[0]
     rows = 360                      # per process: 2160x360 cells, ~3.3 s of reference work, 90 MB
-    secs = po.run_reference_all_cores(algo, skin, niter, ni, rows * cores, cores)
+    secs = po.run_reference_all_cores(algo, skin, niter, ni, rows * cores, cores, cpus=cpus)
     v_all = ni * rows * cores / max(secs) / 1e6
     return {"value": round(v_all, 4), "unit": "Mcell/s", "cores": cores, "kind": "reference",
             "one_core_value": round(n / dt1 / 1e6, 4),
+            "host": {"logical_cpus": os.cpu_count(), "usable_logical_cpus": len(logical), "physical_cores": len(physical), "process_cap": cap},
             "sample": f"{algo}{'+skin' if skin else ''} nb_iter={niter}, unmodified reference, one aerobulk_model(jt=1,Nt=1) call "
-                      f"incl. AEROBULK_INIT per process: {cores} concurrent single-threaded processes x {ni}x{rows} cells of the "
+                      f"incl. AEROBULK_INIT per process: {cores} concurrent single-threaded processes, each pinned to its own physical core "
+                      f"(host: {os.cpu_count()} logical CPUs, {len(physical)} physical cores; cap {cap} processes), x {ni}x{rows} cells of the "
                       f"same synthetic fields (slowest {max(secs):.1f} s); one process alone on {ni}x{nj}: {dt1:.1f} s"}
 
 
@@ -209,6 +226,8 @@ def main():
                          "compute against its peers' compute + transfer; -1 = equal split")
     ap.add_argument("--no-early-gather", action="store_true", help="N>1: rank 0 joins the gather of a chunk after computing its "
                                                                     "own chunk (instead of before)")
+    ap.add_argument("--no-pipeline-gather", action="store_true", help="N>1: every step waits for its own gathers (round 2's order) instead "
+                    "of letting them drain while the next step computes into the other buffer set")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row sub-blocks per rank (gather of one overlaps compute of the next)")
     a = ap.parse_args()
 
@@ -315,12 +334,16 @@ def main():
     # synthetic inputs generated straight into HBM; outputs packed [chunk, pass, field, cell]: ONE gather per
     # chunk and pass
     f = ab.synth_fields_device(ni, nj, j0, max(njl, 1), precision=precision, device=dev, with_rad=True)
-    outbuf = torch.zeros((chunks, npass, nout, n_cpad), dtype=tdt, device=dev)
+    # Two sets of output buffers (and of rank 0's receive buffers): step t computes into set t % 2 while the gathers of step t - 1 may
+    # still be draining set (t - 1) % 2 — in a time loop a step then costs max(compute, ingress of rank 0), not their sum; a set is
+    # only written again after its gathers of two steps ago were waited for (--no-pipeline-gather: wait at the end of every step)
+    nbuf = 2 if gathered else 1
+    outbuf = torch.zeros((nbuf, chunks, npass, nout, n_cpad), dtype=tdt, device=dev)
     gather_lists = None
     send0 = None
     if gathered and rank == 0:     # rank 0's rows stay where they are; it joins the collective with an empty payload
-        gather_lists = [[[torch.empty((ngat, n_gpad), dtype=tdt, device=cdev) for _ in range(world)] for _ in range(npass)]
-                        for _ in range(chunks)]
+        gather_lists = [[[[torch.empty((ngat, n_gpad), dtype=tdt, device=cdev) for _ in range(world)] for _ in range(npass)]
+                         for _ in range(chunks)] for _ in range(nbuf)]
         send0 = torch.zeros((ngat, n_gpad), dtype=tdt, device=cdev)
 
     work = []  # per chunk: None (no rows) or the list over passes of (session, inputs, rad, out, skin)
@@ -337,7 +360,7 @@ def main():
             sess = ab.Session(algo, ni, rows, 1, skin, precision=precision, device=dev_index)
             sess.set_humidity("sh")
             rad = (f["rad_sw"][lo:hi], f["rad_lw"][lo:hi]) if skin else (None, None)
-            out = {k: outbuf[c, p, i, :rows * ni] for i, k in enumerate(names) if (k != "T_s" or skin)}
+            out = [{k: outbuf[b, c, p, i, :rows * ni] for i, k in enumerate(names) if (k != "T_s" or skin)} for b in range(nbuf)]
             per_pass.append((sess, ins, rad, out, skin))
         work.append(per_pass)
 
@@ -348,30 +371,45 @@ def main():
     # stand-in (which moves host copies of the payloads): post / compute / wait.
     early = gathered and rank == 0 and not a.no_early_gather
 
-    def compute(c, p):
+    def compute(c, p, b=0, nit=None):
         w = work[c]
         if w is not None:
             sess, ins, rad, out, skin = w[p]
-            sess.compute(1, zt, zu, *ins, Niter=niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
+            sess.compute(1, zt, zu, *ins, Niter=niter if nit is None else nit, rad_sw=rad[0], rad_lw=rad[1], out=out[b], want_T_s=skin, check=False)
 
-    def step(with_gather=True):
-        pending = []
+    inflight = [[] for _ in range(nbuf)]     # per buffer set: the gathers still reading / filling it
+    nstep = [0]                              # steps taken so far: the set of the next step is nstep % nbuf
+
+    def drain(b=None):
+        for bb in (range(nbuf) if b is None else (b,)):
+            for w_ in inflight[bb]:
+                w_.wait()      # RCCL: stream-level wait (does not block the host); gloo: host wait
+            inflight[bb] = []
+
+    def step(with_gather=True, pipelined=True):
+        b = nstep[0] % nbuf
+        # --verify: consecutive steps compute DIFFERENT fields (one more pass of the iteration on odd steps), so that a gather that
+        # read or filled the wrong buffer set while two were in flight cannot pass the bit-identity check
+        nit = niter + (nstep[0] % 2) if a.verify else niter
+        nstep[0] += 1
+        drain(b)                              # the gathers of two steps ago (this set's): done before the set is written again
+        pending = inflight[b]
         for c in range(chunks):
             for p in range(npass):
                 g = gathered and with_gather
                 if g and early:
-                    pending.append(dist.gather(send0, gather_lists[c][p], dst=0, async_op=True))
-                compute(c, p)
+                    pending.append(dist.gather(send0, gather_lists[b][c][p], dst=0, async_op=True))
+                compute(c, p, b, nit)
                 if g and not early:
                     if rank == 0:
-                        pending.append(dist.gather(send0, gather_lists[c][p], dst=0, async_op=True))
+                        pending.append(dist.gather(send0, gather_lists[b][c][p], dst=0, async_op=True))
                     else:
-                        payload = outbuf[c, p, :ngat]
+                        payload = outbuf[b, c, p, :ngat]
                         if a.backend != "nccl":          # gloo moves host memory: the copy waits for the kernel
                             payload = payload.cpu()
                         pending.append(dist.gather(payload, None, dst=0, async_op=True))
-        for w_ in pending:
-            w_.wait()      # RCCL: stream-level wait (does not block the host); gloo: host wait
+        if not pipelined:
+            drain(b)                          # round 2's order: every step ends with its own gathers
 
     def sync():
         torch.cuda.synchronize()
@@ -379,10 +417,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(nsteps, with_gather):
+    def timed(nsteps, with_gather, pipelined=True):
+        drain()
+        sync()
         t0 = time.perf_counter()
         for _ in range(nsteps):
-            step(with_gather)
+            step(with_gather, pipelined)
+        drain()                               # the last steps' gathers belong to the timed region
         sync()
         el = time.perf_counter() - t0
         if world > 1:
@@ -394,18 +435,19 @@ def main():
     def assemble(p):
         """rank 0: global fields [ngat, ni*nj] of pass p: its own block (never gathered) + the peers' gathered chunk buffers."""
         glob = torch.empty((ngat, ni * nj), dtype=tdt, device=dev)
+        b = (nstep[0] - 1) % nbuf                                 # the set of the last step taken
         for c in range(chunks):                                   # own rows
             r0 = min(c * cr, njl)
             rows = max(min(cr, njl - r0), 0)
             if rows:
-                glob[:, r0 * ni:(r0 + rows) * ni] = outbuf[c, p, :ngat, :rows * ni]
+                glob[:, r0 * ni:(r0 + rows) * ni] = outbuf[b, c, p, :ngat, :rows * ni]
         for r in range(1, world):
             rj0, rnjl, _ = shard_rows_root_heavy(nj, world, r, rows_peer)
             for c in range(chunks):
                 r0 = min(c * cr_peer, rnjl)
                 rows = max(min(cr_peer, rnjl - r0), 0)
                 if rows:
-                    glob[:, (rj0 + r0) * ni:(rj0 + r0 + rows) * ni] = gather_lists[c][p][r][:, :rows * ni].to(dev)
+                    glob[:, (rj0 + r0) * ni:(rj0 + r0 + rows) * ni] = gather_lists[b][c][p][r][:, :rows * ni].to(dev)
         return glob
 
     # pre-roll, part of the setup: the GPU raises its clocks during the first ~100 ms of sustained work (the first
@@ -417,12 +459,19 @@ def main():
         step()
     sync()
     # timed region: EXACTLY K steps, no host sync inside
-    elapsed = timed(a.steps, True)
+    elapsed = timed(a.steps, True, not a.no_pipeline_gather)
+    verify_globs, verify_niter = None, niter
+    if a.verify and gathered:                 # what the last step gathered, before the other timed runs reuse the buffers
+        verify_niter = niter + ((nstep[0] - 1) % 2)
+        if rank == 0:
+            verify_globs = [assemble(p) for p in range(npass)]
     for w in work:
         if w is not None:
             for t in w:
                 t[0].check()
-    # second number of a gathered run: the same K steps with the fluxes left where they were computed
+    # further numbers of a gathered run: the same K steps with every step ending in its own gathers (round 2's order: compute and
+    # ingress exposed one after the other), and with the fluxes left where they were computed
+    elapsed_exposed = timed(a.steps, True, False) if (gathered and not a.no_pipeline_gather) else None
     elapsed_resident = timed(a.steps, False) if gathered else None
 
     # per-launch kernel duration: HIP events recorded by the library around each launch, on the launch stream.
@@ -433,7 +482,7 @@ def main():
         for w in work:
             if w is not None:
                 for p, (sess, ins, rad, out, skin) in enumerate(w):
-                    sess.compute(1, zt, zu, *ins, Niter=niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
+                    sess.compute(1, zt, zu, *ins, Niter=niter, rad_sw=rad[0], rad_lw=rad[1], out=out[0], want_T_s=skin, check=False)
                     kms[p] += sess.last_kernel_ms() / nrep
     k_ms = kms[0]
 
@@ -442,10 +491,10 @@ def main():
         ff = ab.synth_fields_device(ni, nj, precision=precision, device=dev, with_rad=True)
         bad = []
         for p, (algo, skin) in enumerate(passes):
-            glob = assemble(p)
+            glob = verify_globs[p]
             with ab.Session(algo, ni, nj, 1, skin, precision=precision, device=dev_index) as s1:
                 s1.set_humidity("sh")
-                one = s1.compute(1, zt, zu, *[ff[k] for k in IN6], Niter=niter, rad_sw=ff["rad_sw"] if skin else None,
+                one = s1.compute(1, zt, zu, *[ff[k] for k in IN6], Niter=verify_niter, rad_sw=ff["rad_sw"] if skin else None,
                                  rad_lw=ff["rad_lw"] if skin else None, want_T_s=skin)
             bad += [f"{algo}:{k}" for i, k in enumerate(names[:ngat]) if k in one and not torch.equal(glob[i], one[k])]
         verify_msg = "gathered == single-GPU (bit-identical)" if not bad else f"MISMATCH in {bad}"
@@ -505,6 +554,15 @@ def main():
             res["per_algorithm"] = {f"{al}{'+skin' if sk else ''}": {"kernel_ms": round(kms[p], 4),
                                                                         "Mcell_per_s": round(n_local / kms[p] / 1e3, 1) if kms[p] > 0 else None}
                                     for p, (al, sk) in enumerate(passes)}
+        if gathered:
+            res["gather"] = {"pipelined": not a.no_pipeline_gather,
+                             "note": ("two sets of output / receive buffers: the gathers of step t drain while step t + 1 computes; a set is "
+                                      "written again only after its gathers were waited for" if not a.no_pipeline_gather else
+                                      "every step ends with a wait for its own gathers")}
+        if elapsed_exposed is not None:
+            res["gather"]["unpipelined"] = {"value": round(npass * cells * a.steps / elapsed_exposed / 1e6, 2), "unit": "Mcell/s",
+                                            "ms_per_step": round(elapsed_exposed / a.steps * 1e3, 4),
+                                            "note": "the same K steps, every step waiting for its own gathers (round 2's order)"}
         if elapsed_resident is not None:
             res["resident"] = {"value": round(npass * cells * a.steps / elapsed_resident / 1e6, 2), "unit": "Mcell/s",
                                "ms_per_step": round(elapsed_resident / a.steps * 1e3, 4),

@@ -233,10 +233,11 @@ print("SECS", time.perf_counter() - t0, float(o[0].sum()))
 """
 
 
-def run_reference_all_cores(algo, use_skin, niter, ni, nj, nproc):
+def run_reference_all_cores(algo, use_skin, niter, ni, nj, nproc, cpus=None):
     """The reference is single-threaded and non-reentrant: to load every host core, `nproc` independent processes each run
-    aerobulk_model(jt=1,Nt=1) on their own j-block of the ni x nj synthetic grid, at the same time.  Returns the list of
-    seconds each spent inside the call (stdout of the reference is discarded)."""
+    aerobulk_model(jt=1,Nt=1) on their own j-block of the ni x nj synthetic grid, at the same time.  `cpus`: logical CPUs to pin
+    the processes to, one each, in this order (None: the scheduler places them).  Returns the list of seconds each spent inside
+    the call (stdout of the reference is discarded)."""
     per = -(-nj // nproc)
     procs = []
     for r in range(nproc):
@@ -244,9 +245,13 @@ def run_reference_all_cores(algo, use_skin, niter, ni, nj, nproc):
         njl = max(min(per, nj - j0), 0)
         if njl == 0:
             continue
+        pin = None
+        if cpus is not None and hasattr(os, "sched_setaffinity"):
+            cpu = cpus[r % len(cpus)]
+            pin = (lambda c: (lambda: os.sched_setaffinity(0, {c})))(cpu)
         procs.append(subprocess.Popen([sys.executable, "-c", _CHILD_SLAB, REF_SO, ORACLE_SO, algo, "1" if use_skin else "0",
                                        str(int(niter)), str(ni), str(nj), str(j0), str(njl)], stdout=subprocess.PIPE,
-                                      stderr=subprocess.DEVNULL, text=True))
+                                      stderr=subprocess.DEVNULL, text=True, preexec_fn=pin))
     secs = []
     for pr in procs:
         out = pr.communicate(timeout=3600)[0]

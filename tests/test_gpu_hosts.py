@@ -147,6 +147,7 @@ def test_init_checks_on_gpu_match_reference_conditions(oracle):
 
 
 @pytest.mark.parametrize("world,extra", [(2, []), (2, ["--peer-rows", "-1", "--no-early-gather"]), (3, ["--peer-rows", "40", "--gather-ts"]),
+                                         (2, ["--no-pipeline-gather"]), (3, ["--steps", "5", "--peer-rows", "60"]),
                                          (4, []), (2, ["--config", "4"]), (3, ["--config", "4", "--skin", "--no-early-gather", "--peer-rows", "50"]),
                                          (2, ["--config", "5"]), (2, ["--config", "5", "--no-early-gather", "--peer-rows", "-1"]),
                                          (2, ["--config", "2", "--peer-rows", "100"]), (2, ["--config", "1"])])
@@ -161,7 +162,7 @@ def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
         pytest.skip("no GPU")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(29533 + world + 7 * len(extra) + len("".join(extra))), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
-           "--steps", "2", "--warmup", "1", "--grid", "720x333", "--backend", "gloo", "--verify", "--chunks", "3", "--no-cpu-baseline", *extra]
+           "--steps", "3", "--warmup", "1", "--grid", "720x333", "--backend", "gloo", "--verify", "--chunks", "3", "--no-cpu-baseline", *extra]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -171,6 +172,11 @@ def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
     assert "rank 0 owns" in res["config"]["sharding"]
     assert ("after computing" if "--no-early-gather" in extra else "before computing") in res["config"]["sharding"]
     assert res["resident"]["value"] > 0                      # the second number: fluxes left distributed
+    # two buffer sets in flight (consecutive steps of a --verify run compute different fields: a gather through the wrong set fails the
+    # bit-identity above); both orders are reported
+    assert res["gather"]["pipelined"] == ("--no-pipeline-gather" not in extra)
+    if res["gather"]["pipelined"]:
+        assert res["gather"]["unpipelined"]["value"] > 0
     assert res["roofline"]["bound"] == "valu_fp64"
     if "--config" in extra and extra[extra.index("--config") + 1] == "4":
         assert len(res["per_algorithm"]) == 5 and all(v["Mcell_per_s"] > 0 for v in res["per_algorithm"].values())

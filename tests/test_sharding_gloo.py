@@ -98,3 +98,69 @@ def test_root_heavy_sharding_and_balance_formula():
     assert 300 < slow < 450
     nj0 = 3600 - 7 * slow                                                          # both sides take about the same time
     assert abs(nj0 * t_cell - slow * 40 / 60e9) / (nj0 * t_cell) < 0.02
+
+
+def _worker_pipelined(rank, world, port, ni, nj, nsteps, q):
+    """bench.py's gathered time loop with TWO buffer sets: step t fills set t % 2 and posts its gathers without waiting; a set is
+    written again only after its gathers of two steps ago were waited for (the order bench.py runs for RCCL and for gloo alike).
+    Every step computes different fields (its own pass count), so a gather through the wrong set cannot go unnoticed."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from bench import shard_rows
+    from oracle import pyoracle as po
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    j0, njl, per = shard_rows(nj, world, rank)
+    n_local, n_pad = ni * njl, ni * per
+    f = po.synth_fields(ni, nj, j0, njl)
+    names = ("ql", "qh", "tau_x", "tau_y", "evap")
+    sets = [torch.zeros((5, n_pad), dtype=torch.float64) for _ in range(2)]
+    recv = [[torch.empty((5, n_pad), dtype=torch.float64) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+    inflight = [None, None]
+    seen = {}
+
+    def harvest(b, t):
+        if inflight[b] is not None:
+            inflight[b].wait()
+            inflight[b] = None
+            if rank == 0:
+                seen[t] = [r.clone() for r in recv[b]]
+
+    for t in range(nsteps):
+        b = t % 2
+        harvest(b, t - 2)
+        o = po.OracleSession("coare3p6", n_local, 1, False).compute(1, 2.0, 10.0, 2 + t, f["sst"], f["t_zt"], f["hum_zt"], f["u_zu"], f["v_zu"], f["slp"])
+        for i, k in enumerate(names):
+            sets[b][i, :n_local] = torch.from_numpy(o[k])
+        inflight[b] = dist.gather(sets[b], recv[b], dst=0, async_op=True)
+    for t in (nsteps - 2, nsteps - 1):
+        harvest(t % 2, t)
+    if rank == 0:
+        out = {}
+        for t, parts in seen.items():
+            out[t] = np.concatenate([parts[r][0, :ni * shard_rows(nj, world, r)[1]].numpy() for r in range(world)])
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gathers_of_two_steps_in_flight_deliver_each_steps_fields(oracle):
+    import torch.multiprocessing as mp
+    ni, nj, world, nsteps = 24, 19, 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 977
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, ni, nj, nsteps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f = oracle.synth_fields(ni, nj)
+    assert sorted(got) == list(range(nsteps))
+    for t in range(nsteps):
+        ref = oracle.OracleSession("coare3p6", ni * nj, 1, False).compute(1, 2.0, 10.0, 2 + t, f["sst"], f["t_zt"], f["hum_zt"], f["u_zu"], f["v_zu"], f["slp"])
+        np.testing.assert_array_equal(got[t], ref["ql"], err_msg=f"step {t}")
