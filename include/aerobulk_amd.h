@@ -9,7 +9,7 @@
  * Data layout: every field is a flat, contiguous array of `ni*nj` cells (Fortran column-major
  * (Ni,Nj), i fastest — exactly what the reference's C shim sees as an (m,1) array,
  * mod_aerobulk_cxx.f90:40-44).  Element type is `double` for an AB_F64 session and `float`
- * for an AB_F32 / AB_F32_STORAGE session.  `mem` says where the caller's arrays live: AB_MEM_HOST (the
+ * for an AB_F32 / AB_F32_STORAGE / AB_F32_MIXED session.  `mem` says where the caller's arrays live: AB_MEM_HOST (the
  * reference's calling convention; the library stages H2D/D2H) or AB_MEM_DEVICE (arrays are
  * already resident in HBM; nothing is copied and the call is asynchronous on `stream`).
  */
@@ -292,7 +292,12 @@ int ab_test_math(int op, const double *x, const double *y, double *out, long n);
  * call protocol: INIT at jt==1, BYE at jt==nt.  Non-reentrant exactly like the reference.
  * rad_sw/rad_lw/t_s may be NULL (the Fortran OPTIONALs); niter <= 0 keeps the current nb_iter
  * (sticky, default 5: mod_const.f90:33, mod_aerobulk.f90:236).  Host arrays, fp64.
- * Returns an ab_status; `report` (may be NULL) is filled when jt==1. */
+ * Returns an ab_status; `report` (may be NULL) is filled when jt==1.
+ * jt == 1 on grids of 4 Mi cells and more (per shard): AEROBULK_INIT's statistics ride on the pipelined pass of the compute (one
+ * PCIe crossing of the inputs).  Consequence: when an AEROBULK_INIT error is returned (AB_ERR_ALL_MASKED, AB_ERR_HUM_TYPE,
+ * AB_ERR_UNITS) the output arrays already hold fluxes computed with a GUESSED humidity type — the reference aborts before it
+ * computes; the arrays mean nothing then.  If the first 2^20 cells misjudge the humidity type of the whole domain, record 1 is
+ * computed twice (a one-line notice on stderr).  AEROBULK_AMD_NO_FUSED_INIT=1 restores the reference's order (checks, then compute). */
 int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double zu,
              const double *sst, const double *t_zt, const double *hum_zt,
              const double *u_zu, const double *v_zu, const double *slp,
