@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run bench.py for every BASELINE.json configuration that fits one GPU and collect the JSON lines (SURVEY §8d "configs ->
-concrete runs"): writes gpurun_out/configs.jsonl (copy to profiles/r2_configs.jsonl)."""
+concrete runs"): writes gpurun_out/configs.jsonl (copy to profiles/r3_configs.jsonl)."""
 import json
 import os
 import subprocess
@@ -14,8 +14,9 @@ RUNS = [
     ("config 3: coare3p6 + skin, 4320x3600, nb_iter=8", ["--niter", "8"]),
     ("config 4 (1 GPU): five algorithms back-to-back, no skin", ["--config", "4"]),
     ("config 4 (1 GPU): five algorithms back-to-back, skin where supported", ["--config", "4", "--skin"]),
-    ("config 5 (1 GPU): ecmwf + skin, fp32, 12960x10800", ["--config", "5", "--steps", "5"]),
+    ("config 5 (1 GPU): ecmwf + skin, fp32 arrays in the mixed mode (AB_F32_MIXED: the timed path), 12960x10800", ["--config", "5", "--steps", "5"]),
     ("config 5 path on the 4320x3600 grid", ["--config", "5", "--grid", "4320x3600"]),
+    ("config 5 (1 GPU) with fp32 arithmetic throughout (AB_F32: outside the restated tolerance)", ["--config", "5", "--precision", "f32", "--steps", "5"]),
     ("config 5 (1 GPU) with fp64 arithmetic on the fp32 arrays (AB_F32_STORAGE)", ["--config", "5", "--precision", "f32_storage", "--steps", "5"]),
 ]
 
