@@ -57,6 +57,21 @@ KERNEL(k_lshl_b32, int, int, "v_lshlrev_b32 %0, 3, %1")
 KERNEL(k_bfi_b32, int, int, "v_bfi_b32 %0, %1, %1, %1")
 KERNEL(k_mul_lo_u32, int, int, "v_mul_lo_u32 %0, %1, %1")
 KERNEL(k_mul_u24, int, int, "v_mul_u32_u24 %0, %1, %1")
+KERNEL(k_max_i32, int, int, "v_max_i32 %0, %1, %1")
+KERNEL(k_min_i32, int, int, "v_min_i32 %0, %1, %1")
+KERNEL(k_max_u32, int, int, "v_max_u32 %0, %1, %1")
+KERNEL(k_min_f32, float, float, "v_min_f32 %0, %1, %1")
+KERNEL(k_med3_f32, float, float, "v_med3_f32 %0, %1, %1, %1")
+KERNEL(k_add_f32, float, float, "v_add_f32 %0, %1, %1")
+KERNEL(k_max_f32_abs, float, float, "v_max_f32_e64 %0, |%1|, %1")
+KERNEL(k_cvt_i32_f32, int, float, "v_cvt_i32_f32 %0, %1")
+KERNEL(k_floor_f32, float, float, "v_floor_f32 %0, %1")
+KERNEL(k_fract_f32, float, float, "v_fract_f32 %0, %1")
+KERNEL(k_xor_b32, int, int, "v_xor_b32 %0, %1, %1")
+KERNEL(k_lshr_b32, int, int, "v_lshrrev_b32 %0, 3, %1")
+KERNEL(k_cmp_i32, float, int, "v_cmp_gt_i32 vcc, %1, %1\n v_mov_b32 %0, 0")
+KERNEL(k_ldexp_f32, float, float, "v_ldexp_f32 %0, %1, 3")
+KERNEL(k_sqrt_f32, float, float, "v_sqrt_f32 %0, %1")
 KERNEL(k_lshl_b64, long long, long long, "v_lshlrev_b64 %0, 3, %1")
 KERNEL(k_lshl_add_u64, long long, long long, "v_lshl_add_u64 %0, %1, 3, %1")
 KERNEL(k_mad_u64_u32, long long, int, "v_mad_u64_u32 %0, vcc, %1, %1, 0")
@@ -82,6 +97,9 @@ int main()
         {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f32_i32", k_cvt_f32_i32}, {"v_frexp_exp_i32_f64", k_frexp_exp64},
         {"v_trunc_f64", k_trunc64}, {"v_floor_f64", k_floor64}, {"v_add_u32", k_add_u32}, {"v_and_b32", k_and_b32},
         {"v_lshlrev_b32", k_lshl_b32}, {"v_bfi_b32", k_bfi_b32}, {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_u32_u24", k_mul_u24},
+        {"v_max_i32", k_max_i32}, {"v_min_i32", k_min_i32}, {"v_max_u32", k_max_u32}, {"v_min_f32", k_min_f32}, {"v_med3_f32", k_med3_f32},
+        {"v_floor_f32", k_floor_f32}, {"v_fract_f32", k_fract_f32}, {"v_xor_b32", k_xor_b32}, {"v_lshrrev_b32", k_lshr_b32},
+        {"v_cmp_gt_i32 + v_mov_b32", k_cmp_i32}, {"v_ldexp_f32", k_ldexp_f32}, {"v_sqrt_f32", k_sqrt_f32},
         {"v_lshlrev_b64", k_lshl_b64}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_mad_u64_u32", k_mad_u64_u32},
         {"v_readlane_b32 + v_mov_b32", k_readlane}, {"v_fma_f32", k_fma32}, {"v_fma_f64 (sgpr src)", k_fmamk64},
         {"v_add_f64 (inline const)", k_addlit64}, {"v_rcp_f64", k_rcp64}};
