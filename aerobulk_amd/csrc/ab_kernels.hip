@@ -98,7 +98,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     constexpr bool kCsgLds = TILED && SKIN && sizeof(R) == 8;      // flux_kernel filled the cool skin's g(u) table
     if (ALGO == 1) turb_coare<R, false, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
-    else if (ALGO == 3) turb_ncar<R, DIAG, A>(hh, in, nb_iter, o);
+    else if (ALGO == 3) turb_ncar<R, DIAG, A, (sizeof(R) == 8 && kPsiTabDefault)>(hh, in, nb_iter, o);   // flux_kernel's direct path filled the pair of psi tables
     else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG, A>(hh, in, nb_iter, wl, o);
     else turb_andreas<R, DIAG, A>(hh, in, nb_iter, o);
     if (DIAG) {
@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
         // the cell's loads are in flight while the block fills its math tables
         R slp = R(101000.), t_zt = R(290.), hum = R(0.01), sst = R(290.), uu = R(1.), vv = R(1.);
         if (live) { slp = (R)a.slp[k]; t_zt = (R)a.t_zt[k]; hum = (R)a.hum[k]; sst = (R)a.sst[k]; uu = (R)a.u[k]; vv = (R)a.v[k]; }
+        if constexpr (sizeof(R) == 8) psi_tables_fill<false>();   // Kansas psi_m / psi_h (before the barrier of math_tables_init)
         math_tables_init<A>();
         if (!live) return;
         A q_zt;

@@ -89,7 +89,7 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFl
     // flux kernels with the skin schemes come out at exactly two rounds with 280 B to spare: nothing is left in LDS.
     // fp64: the e_sat table (kernels with the skin schemes) + the Kansas psi_m table (ECMWF, ANDREAS; COARE reads its psi through L1);
     // (COARE with the skin schemes: + the cool skin's g(u) table, 3 584 B); fp32: the three psi tables (+ e_sat: mixed)
-    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3584 : 0) : 1792) : (MIXED ? 3072 : 1536));
+    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3584 : 0) : 3584) : (MIXED ? 3072 : 1536));
     static constexpr int kBudget = 160 * 1024 / kWaves - 256 - ((sizeof(R) == 8 || MIXED) ? 1792 : 0) - kPsiTabBytes;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 2)); // f64: 2 (skin, 4 blocks) / 2 (5 blocks); f32: 2
     static constexpr int kCells = kRounds * kBlock;

@@ -52,7 +52,7 @@ def main():
     a = ap.parse_args()
     res = {t: {} for t in a.tags}
     for p in range(a.passes):
-        for t in a.tags:
+        for t in (a.tags if p % 2 == 0 else a.tags[::-1]):     # A B | B A | ...: whatever drifts with time (clocks, temperature) hits both
             env = dict(os.environ)
             if t != "cur":
                 env["AEROBULK_AMD_LIB"] = os.path.join(ROOT, "build", "var", f"libab_{t}.so")
@@ -72,9 +72,10 @@ def main():
         row = []
         for t in a.tags:
             v = sorted(res[t].get(c, [float('nan')]))
-            med = v[len(v) // 2]
+            med = sum(v) / len(v) if len(v) % 2 == 0 else v[len(v) // 2]      # even number of passes: the mean (order-balanced)
             b = sorted(res[base].get(c, [float('nan')]))
-            row.append(f"{med:8.3f} ms ({100 * (med / b[len(b) // 2] - 1):+5.1f} %)")
+            bm = sum(b) / len(b) if len(b) % 2 == 0 else b[len(b) // 2]
+            row.append(f"{med:8.3f} ms ({100 * (med / bm - 1):+5.1f} %)")
         print(f"{c:18s} " + " ".join(f"{r:>22s}" for r in row))
     print("passes:", json.dumps(res))
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""tools/gen_psitab.py — piecewise tables of two unstable profile functions in their log variables (ab_physics.hpp, kPsiTabM / kPsiTabC).
+"""tools/gen_psitab.py — piecewise tables of the unstable profile functions in their log variables (ab_physics.hpp, kPsiTabM / kPsiTabH / kPsiTabC).
 
     F_M(s) = psi_m of Kansas / Paulson as a function of s = LOG(y), y = |1 - a zeta|   (tools/gen_poly.py section 6),  0 <= s < 6.6875
+    F_H(s) = psi_h of Kansas / Paulson, same variable, same intervals (evaluated together with F_M at one table position)
     F_C(L) = COARE's convective psi as a function of L = LOG(y)                          (tools/gen_poly.py section 7),  0 <= L < 7.4453125
     E(T)   = e_sat_sclr of the reference (Goff 1957; mod_phymbl.f90:792-798) in Pa,                                          265 <= T < 312 K
 The psi functions are analytic with the nearest singularities at +-2 pi i.  Each range is cut into equal intervals (28 / 28 / 24);
@@ -101,6 +102,8 @@ def main():
     print(f"// SMAX = {float(SMAX)!r}, LMAX = {float(LMAX)!r}, degree {DEG}")
     rows, err = table(psik_m, SMAX, nint=NINT_PSI)
     emit("kPsiTabM", rows, err, "psi_m (Kansas / Paulson) in s = LOG(y)")
+    rows, err = table(psik_h, SMAX, nint=NINT_PSI)
+    emit("kPsiTabH", rows, err, "psi_h (Kansas / Paulson) in s = LOG(y)")
     rows, err = table(psic_L, LMAX, nint=NINT_PSI)
     emit("kPsiTabC", rows, err, "COARE convective psi in L = LOG(y)")
     rows, err = table(e_sat, mp.mpf(312), nint=NINT_ESAT, x0=mp.mpf(265), rel=True)

@@ -279,6 +279,8 @@ def cmd_build(a):
     lib = os.path.join(var, f"libab_{a.tag}.so")
     others = [os.path.join(CSRC, f) for f in ("ab_turb_kernels.o", "ab_ice_kernels.o", "ab_runtime.o", "ab_sharded.o", "ab_cxx.o")]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, host, *others])
+    for f in (s_out, obj, hsaco, fb, host):      # intermediates: tens of MB each, and build/var travels to the GPU box
+        os.remove(f)
     src_map = Sources()
     jb = []
     for b in blocks:
