@@ -159,7 +159,6 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     chk(hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking));
     chk(hipEventCreate(&s->ev0));
     chk(hipEventCreate(&s->ev1));
-    chk(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
     chk(hipMalloc((void **)&s->d_flags, sizeof(int)));
     chk(hipMalloc((void **)&s->d_partials, sizeof(double) * ab::kStatBlocks * ab::kStatStride));
     if (e == hipSuccess) chk(hipMemset(s->d_flags, 0, sizeof(int)));
@@ -206,7 +205,7 @@ int ab_session_destroy(ab_session *s)
     // device-mode calls run on the caller's stream and use session-owned buffers (WL state, flags, lon, diagnostics staging): wait
     // for the last of them before they are freed — through the session's own event, recorded behind that call: the caller's stream
     // may be gone by now (a model that tears its streams down first)
-    if (s->done_pending && s->ev_done) (void)hipEventSynchronize(s->ev_done);
+    if (s->done_pending && s->ev1) (void)hipEventSynchronize(s->ev1);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (auto &p : s->wl) if (p) (void)hipFree(p);
     for (auto &p : s->stage_in) if (p) (void)hipFree(p);
@@ -218,7 +217,6 @@ int ab_session_destroy(ab_session *s)
     if (s->d_fused) (void)hipFree(s->d_fused);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->s_h2d) (void)hipStreamDestroy(s->s_h2d);
     if (s->s_d2h) (void)hipStreamDestroy(s->s_d2h);
@@ -696,8 +694,7 @@ static int compute_impl(ab_session *s, int jt, double zt, double zu, int niter, 
             if (hout[i]) AB_HIP(hipMemcpyAsync(hout[i], dout[i], bytes, hipMemcpyDeviceToHost, st));
         return ab_session_check(s);
     }
-    AB_HIP(hipEventRecord(s->ev_done, st));
-    s->done_pending = true;
+    s->done_pending = true;      // ev1, recorded behind the kernel, is the last thing this call put on the caller's stream
     return AB_OK;
 }
 
@@ -793,8 +790,7 @@ int ab_session_turb(ab_session *s, int kt, double zt, double zu, int use_cs, int
         }
         AB_HIP(hipStreamSynchronize(st));
     } else {
-        AB_HIP(hipEventRecord(s->ev_done, st));
-        s->done_pending = true;
+        s->done_pending = true;  // (ev1: see ab_session_compute)
     }
     return AB_OK;
 }

@@ -33,8 +33,8 @@ struct ab_session {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;  // copy streams of the pipelined host path
     hipStream_t last_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_done = nullptr;     // recorded on the caller's stream at the end of every device-mode call: what destroy / state
-    bool done_pending = false;        // readers wait for (the caller may have destroyed its stream by then; the event is ours)
+    bool done_pending = false;        // a device-mode call is in flight on the caller's stream: destroy waits for ev1, recorded behind its
+                                      // kernel (the caller may have destroyed its stream by then; the event is ours)
     bool timed = false;
     // AEROBULK_MODEL at jt == 1 (ab_model): the fields AEROBULK_INIT staged in HBM are the ones aerobulk_compute reads next.
     // staged_from[i] = the host array stage_in[i] was last filled from; reuse_staged = honour it in the next host compute
