@@ -150,3 +150,23 @@ def test_fp32_psi_tables():
                 p = np.float32(p * u + t[w, k, i])
             worst = max(worst, abs(float(p) - float(f(g.mp.mpf(float(np.float32(x)))))))
         assert worst < 3e-6, (w, worst)     # fp32: values up to 6.6 (ulp 4.8e-7), the argument itself rounded to float
+
+
+def test_lkb_rows_in_the_log_domain_are_the_references_table():
+    """kLkbLog (ab_physics.hpp): {ln a_t, b_t - 1, ln a_q, b_q - 1} of the eight rows of z0tq_LKB (mod_phymbl.f90:1658-1667), the literals
+    taken as the doubles they are; the bin edges and clamps of z0tq_lkb_log are the logarithms of the reference's."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    phys = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_physics.hpp")).read()
+    m = re.search(r"AB_TAB double kLkbLog\[32\] = \{(.*?)\};", phys, re.S)
+    got = [float(x) for x in m.group(1).replace("\n", " ").split(",")]
+    rows = [(0.177, 0., 0.292, 0.), (1.376, 0.929, 1.808, 0.826), (1.026, -0.599, 1.393, -0.528), (1.625, -1.018, 1.956, -0.870),
+            (4.661, -1.475, 4.994, -1.297), (34.904, -2.067, 30.709, -1.845), (1667.19, -2.907, 1448.68, -2.682), (5.88e5, -3.935, 2.98e5, -3.616)]
+    want = []
+    for at, bt, aq, bq in rows:
+        want += [float(mp.log(mp.mpf(at))), float(mp.mpf(bt) - 1), float(mp.log(mp.mpf(aq))), float(mp.mpf(bq) - 1)]
+    assert got == want
+    body = phys[phys.index("void z0tq_lkb_log("):phys.index("lnz0q = lq;")]
+    for x in (0.11, 0.825, 3.0, 10.0, 30.0, 100., 300., 1000., 1e-9, 0.05):
+        assert repr(float(mp.log(mp.mpf(x)))) in body, x
+    assert repr(float(mp.log(mp.mpf(0.0025)))) in phys           # ln z0_sea_max in turb_andreas
