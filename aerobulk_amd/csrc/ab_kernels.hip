@@ -29,6 +29,7 @@ template <class R, class S = R> struct FluxArgs {
     int nb_iter, hum_type, wl_load, wl_store, isecday, dawn_uniform;
     int regroup;  // sort the tile's cells into like-behaved waves (see flux_kernel)
     int rounds;   // tile = rounds*256 cells (<= Tile<R,ALGO,SKIN>::kRounds)
+    long nfull;   // blocks [0, nfull) own tiles of `rounds` rounds; the blocks behind them, dispatched last, one round each (launch_t)
 };
 
 // optional per-cell diagnostics of TURB_* (ab_session_set_diagnostics); read only by the DIAG instantiations
@@ -174,8 +175,14 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     __shared__ unsigned s_cnt[kSortCounters], s_base[kSortCounters];
     __shared__ int s_next;
     const int tid = threadIdx.x;
-    const int rounds = a.rounds;                          // <= T::kRounds; fewer on small grids so that every CU gets blocks
-    const long tile0 = (long)blockIdx.x * ((long)rounds * kBlock);
+    // <= T::kRounds; fewer on small grids so that every CU gets blocks.  The LAST blocks of the grid own one-round tiles: the chip
+    // drains over the life of a short block instead of a long one (launch_t)
+    int rounds = a.rounds;
+    long tile0 = (long)blockIdx.x * ((long)rounds * kBlock);
+    if ((long)blockIdx.x >= a.nfull) {
+        tile0 = a.nfull * ((long)rounds * kBlock) + ((long)blockIdx.x - a.nfull) * kBlock;
+        rounds = 1;
+    }
 
     // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126.  The loads of a round are
     // issued one round ahead: those of round 0 are in flight while the block fills its math tables, those of round r+1 while
@@ -315,7 +322,17 @@ template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipErro
     const long rounds = tile_rounds(c.n, T::kRounds, T::kOcc);
     a.rounds = (int)rounds;
     const long tile = (ALGO == 3) ? kBlock : rounds * kBlock;
-    const long nblk = (c.n + tile - 1) / tile;
+    // The hardware starts blocks in index order; the launch ends when the last ones drain, the chip emptying over one block's life.
+    // The grid therefore ends with one-round tiles, as many as the chip holds blocks at once: 1440x1080 is 3 037 two-round tiles for
+    // 1 280 resident slots — two full waves and a third that holds the chip for a whole life at 37 % occupancy (0.205 ms where the
+    // large-grid rate gives 0.156) — or 2 398 long tiles followed by 1 280 short ones.
+    long nfull = (c.n + tile - 1) / tile, nblk = nfull;
+    if (ALGO != 3 && rounds > 1) {
+        const long tail = std::min<long>(c.n, resident_block_slots(T::kOcc) * (long)kBlock);
+        nfull = (c.n - tail) / tile;
+        nblk = nfull + (c.n - nfull * tile + kBlock - 1) / kBlock;
+    }
+    a.nfull = nfull;
     if (nblk <= 0) return hipSuccess;
     if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true, S, A>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false, S, A>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
