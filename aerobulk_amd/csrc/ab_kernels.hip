@@ -96,7 +96,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
 
     CellOut<R, A> o;
     constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
-    constexpr bool kCsgLds = TILED && SKIN && sizeof(R) == 8;      // flux_kernel filled the cool skin's g(u) table
+    constexpr bool kCsgLds = TILED && sizeof(R) == 8;              // flux_kernel filled COARE's LDS extras (g(u) with the skin schemes, the psi tables without)
     if (ALGO == 1) turb_coare<R, false, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 3) turb_ncar<R, DIAG, A, (sizeof(R) == 8 && kPsiTabDefault)>(hh, in, nb_iter, o);   // flux_kernel's direct path filled the pair of psi tables
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     // (before the barrier of math_tables_init) fp64: COARE reads its psi tables through L1 (ab_gtables.hpp); ECMWF / ANDREAS keep the
     // Kansas psi_m table in LDS; the e_sat table with the skin schemes
     if constexpr (sizeof(R) == 8) {
-        if constexpr (ALGO == 1 || ALGO == 2) { if (SKIN) { esat_table_fill(); csg_table_fill(); } }
+        if constexpr (ALGO == 1 || ALGO == 2) { if (SKIN) { esat_table_fill(); csg_table_fill(); } else psi_coare_lds_fill(); }
         else psi_tables_fill<SKIN>();
     }
     else psi_tables_fill32();                             // (before the barrier below)
