@@ -59,6 +59,28 @@ def test_pointwise_sharding_invariance_full_grid(torch_mod):
         assert torch_mod.equal(full[k][j0 * ni:(j0 + njl) * ni], part[k]), k
 
 
+@pytest.mark.parametrize("algo,skin", [("coare3p6", True), ("coare3p6", False), ("andreas", False), ("ncar", False)])
+def test_launch_geometry_does_not_show_in_the_results(torch_mod, algo, skin):
+    """The grid of a launch is cut into two-round tiles followed by one-round tiles (as many as the chip holds blocks), one-round tiles
+    alone on small grids, a ragged last tile: whatever the cut, a cell's result is the one it has inside any other launch.  The first n
+    cells of a field computed alone, for n around every threshold of the cut (one lane, one wave, one block, the chip's resident
+    blocks +- 1, twice that, a prime), against the same cells of one large launch: bit-identical."""
+    import aerobulk_amd as ab
+    big = 1000003                                       # prime: the last tile is ragged
+    f = ab.synth_fields_device(big, 1)
+    kw = dict(rad_sw=f["rad_sw"], rad_lw=f["rad_lw"]) if skin else {}
+    with ab.Session(algo, big, 1, 1, skin) as s:
+        full = s.compute(1, 2.0, 10.0, *[f[k] for k in IN6], Niter=5, **kw)
+    slots = 256 * 5 * 256                               # cells of one-round tiles the chip holds at five blocks per CU
+    for n in (1, 63, 64, 257, 511, 65537, 256 * 4 * 256 - 1, 256 * 4 * 256 + 1, slots - 1, slots + 1, 2 * slots + 255, 2 * 256 * 4 * 256 + 513, 999983):
+        sub = {k: v[:n].contiguous() for k, v in f.items()}
+        kws = dict(rad_sw=sub["rad_sw"], rad_lw=sub["rad_lw"]) if skin else {}
+        with ab.Session(algo, n, 1, 1, skin) as s:
+            part = s.compute(1, 2.0, 10.0, *[sub[k] for k in IN6], Niter=5, **kws)
+        for k in part:
+            assert torch_mod.equal(full[k][:n], part[k]), (n, k)
+
+
 def test_wind_rotation_symmetry(torch_mod):
     """(U,V) -> (-V,U) rotates the stress vector and leaves every scalar flux unchanged (to rounding: the wind
     module sqrt(u*u+v*v) is FMA-contracted on the GPU, so it is symmetric only to 1 ulp)."""
