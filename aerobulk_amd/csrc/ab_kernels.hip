@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     // (before the barrier of math_tables_init) fp64: COARE reads its psi tables through L1 (ab_gtables.hpp); ECMWF / ANDREAS keep the
     // Kansas psi_m table in LDS; the e_sat table with the skin schemes
     if constexpr (sizeof(R) == 8) {
-        if constexpr (ALGO == 1 || ALGO == 2) { if (SKIN) { esat_table_fill(); csg_table_fill(); } else psi_coare_lds_fill(); }
+        if constexpr (ALGO == 1 || ALGO == 2) { if (SKIN) { esat_table_fill(); csg_table_fill(); psi_coare_lds_fill<false>(); } else psi_coare_lds_fill(); }
         else psi_tables_fill<SKIN>();
     }
     else psi_tables_fill32();                             // (before the barrier below)

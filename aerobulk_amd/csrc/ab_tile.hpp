@@ -82,15 +82,15 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFl
                                 : sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : ((ALGO == 1 && AB_COARE3P0_NOSKIN_OCC) ? AB_COARE3P0_NOSKIN_OCC : AB_NOSKIN_OCC))
                                                : (SKIN ? (ALGO == 4 ? AB_F32_ECMWF_OCC : AB_F32_OCC) : AB_F32_NOSKIN_OCC);
     static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
-    // The kWaves blocks of a CU share its 160 KB of LDS.  Per block, besides the tile (fields + a 2-byte index per cell): the sort's
-    // counters, the queue head and alignment (256 B), the tables of the fp64 log / exp and the constants (fm::s_logtab 1024 B,
-    // s_exptab 512 B, s_ctab 144 B: 1 792 B with alignment), and, in the translation units that define AB_PSI_LDS_TABLES, the
-    // piecewise tables of ab_physics.hpp.  fp64: the e_sat table (1 536 B, kernels with the skin schemes) + either the Kansas psi_m /
-    // psi_h pair (2 x 1 792 B: ECMWF, ANDREAS) or, COARE, the cool skin's g(u) table with the skin schemes (3 584 B; psi through L1,
-    // ab_gtables.hpp) / the blended psi_m, psi_h tables without them (2 x 2 560 B); fp32: the three psi tables (1 536 B; + e_sat: mixed).  The fp64 flux kernels with the skin schemes come
-    // out at exactly two rounds with 280 B to spare: nothing is left in LDS.
-    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3584 : 5120) : 3584) : (MIXED ? 3072 : 1536));
-    static constexpr int kBudget = 160 * 1024 / kWaves - 256 - ((sizeof(R) == 8 || MIXED) ? 1792 : 0) - kPsiTabBytes;
+    // The kWaves blocks of a CU share its 160 KB of LDS (allocated in 512-byte granules: tools/micro/lds_granule.hip).  Per block, besides
+    // the tile (fields + a 2-byte index per cell): the sort's counters and the queue head (136 B; 160 reserved), the tables of the fp64
+    // log / exp and the constants (fm::s_logtab 1024 B, s_exptab 512 B, s_ctab 96 B: 1 632 B), and, in the translation units that define
+    // AB_PSI_LDS_TABLES, the piecewise tables of ab_physics.hpp.  fp64: the e_sat table (1 536 B, kernels with the skin schemes) + either
+    // the Kansas psi_m / psi_h pair (2 x 1 792 B: ECMWF, ANDREAS) or, COARE: with the skin schemes the cool skin's g(u) (1 280 B) and the
+    // blended psi_h (2 560 B; psi_m through L1, ab_gtables.hpp), without them psi_m and psi_h (2 x 2 560 B); fp32: the three psi tables
+    // (1 536 B; + e_sat: mixed).  The fp64 COARE kernels with the skin schemes come out at exactly two rounds with 24 B to spare.
+    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3840 : 5120) : 3584) : (MIXED ? 3072 : 1536));
+    static constexpr int kBudget = 160 * 1024 / kWaves - 160 - ((sizeof(R) == 8 || MIXED) ? 1632 : 0) - kPsiTabBytes;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 2)); // f64: 2 (skin, 4 blocks) / 2 (5 blocks); f32: 2
     static constexpr int kCells = kRounds * kBlock;
     static constexpr int kGroups = kCells / 64;
