@@ -170,3 +170,36 @@ def test_lkb_rows_in_the_log_domain_are_the_references_table():
     for x in (0.11, 0.825, 3.0, 10.0, 30.0, 100., 300., 1000., 1e-9, 0.05):
         assert repr(float(mp.log(mp.mpf(x)))) in body, x
     assert repr(float(mp.log(mp.mpf(0.0025)))) in phys           # ln z0_sea_max in turb_andreas
+
+
+def test_table_positions_stay_inside_their_tables_at_the_last_admissible_argument():
+    """Every piecewise table is indexed by (int)(x * scale) behind a test x < bound.  Scales that are not powers of two are rounded: the
+    position of the LAST admissible argument (the predecessor of the bound) must still truncate to the last interval — the product is
+    monotone in x, so this one value decides for all.  Bounds and scales as the kernels write them (ab_physics.hpp)."""
+    phys = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_physics.hpp")).read()
+    gt = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_gtables.hpp")).read()
+    n_lds = int(re.search(r"kPsiCoareLdsN = (\d+)", gt).group(1))
+    n_csg = int(re.search(r"kCsGTabN = (\d+)", gt).group(1))
+    csg_max = float(re.search(r"kCsGTabMax = ([\d.]+);", gt).group(1))
+    assert "constexpr double kGPsiSMax = 6.6875;" in gt and "kGPsiCoareN = 107" in gt and "kGCsGN = 64" in gt
+    assert "kPsiTabSMax = 6.6875, kPsiTabLMax = 7.4453125, kEsatTabT0 = 265., kEsatTabT1 = 312." in phys
+    assert "if (sl <= R(6.68586094706836))" in phys                      # the Kansas LDS pair's own bound, inside [0, 6.6875)
+
+    def last64(bound, num, den, n, off=0.0):
+        x = np.nextafter(np.float64(bound), np.float64(0))
+        xn = (x - np.float64(off)) * (np.float64(num) / np.float64(den))
+        return int(xn) == n - 1 and xn < n
+
+    def last32(bound, num, den, n):
+        x = np.nextafter(np.float32(bound), np.float32(0))
+        xn = np.float32(x * np.float32(np.float64(num) / np.float64(den)))
+        return int(xn) == n - 1 and xn < n
+
+    assert last64(312., 24., 47., 24, off=265.)          # e_sat
+    assert last64(6.6875, n_lds, 6.6875, n_lds)          # COARE's blended psi in LDS
+    assert last64(6.6875, 107, 6.6875, 107)              # ... and through L1
+    assert last64(np.nextafter(6.68586094706836, 7), 28, 6.6875, 28)   # Kansas pair (<= bound: the bound itself is admissible)
+    assert last64(7.4453125, 28, 7.4453125, 28)          # convective psi (math_test_kernel)
+    assert last64(csg_max, n_csg, csg_max, n_csg)        # cool skin g(u), LDS
+    assert last64(8., 64, 8., 64)                        # ... L1
+    assert last32(6.6875, 32, 6.6875, 32) and last32(7.4453125, 32, 7.4453125, 32)   # fp32 tables
