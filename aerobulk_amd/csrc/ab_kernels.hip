@@ -101,7 +101,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 3) turb_ncar<R, DIAG, A, (sizeof(R) == 8 && kPsiTabDefault)>(hh, in, nb_iter, o);   // flux_kernel's direct path filled the pair of psi tables
     else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG, A>(hh, in, nb_iter, wl, o);
-    else turb_andreas<R, DIAG, A>(hh, in, nb_iter, o);
+    else turb_andreas<R, DIAG, A, (TILED && sizeof(R) == 8)>(hh, in, nb_iter, o);   // flux_kernel filled psi_m's stable-side table
     if (DIAG) {
         const R d[16] = {o.Cd, o.Ch, o.Ce, R(o.t_zu), R(o.q_zu), o.Ubzu, o.CdN, o.ChN, o.CeN, o.z0, o.us, o.L, o.UN10,
                          o.dT_cs, o.dT_wl, o.Hz_wl};
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     // Kansas psi_m table in LDS; the e_sat table with the skin schemes
     if constexpr (sizeof(R) == 8) {
         if constexpr (ALGO == 1 || ALGO == 2) { if (SKIN) { esat_table_fill(); csg_table_fill(); psi_coare_lds_fill<false>(); } else psi_coare_lds_fill(); }
-        else psi_tables_fill<SKIN>();
+        else { psi_tables_fill<SKIN>(); if constexpr (ALGO == 5) andreas_stab_fill(); }
     }
     else psi_tables_fill32();                             // (before the barrier below)
     if constexpr (kMixed) esat_table_fill();              // q_sat of the mixed mode is the fp64 one, through its LDS table

@@ -86,10 +86,10 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFl
     // the tile (fields + a 2-byte index per cell): the sort's counters and the queue head (136 B; 160 reserved), the tables of the fp64
     // log / exp and the constants (fm::s_logtab 1024 B, s_exptab 512 B, s_ctab 96 B: 1 632 B), and, in the translation units that define
     // AB_PSI_LDS_TABLES, the piecewise tables of ab_physics.hpp.  fp64: the e_sat table (1 536 B, kernels with the skin schemes) + either
-    // the Kansas psi_m / psi_h pair (2 x 1 792 B: ECMWF, ANDREAS) or, COARE: with the skin schemes the cool skin's g(u) (1 280 B) and the
+    // the Kansas psi_m / psi_h pair (2 x 1 792 B: ECMWF, ANDREAS; ANDREAS + 800 B: its stable psi_m) or, COARE: with the skin schemes the cool skin's g(u) (1 280 B) and the
     // blended psi_h (2 560 B; psi_m through L1, ab_gtables.hpp), without them psi_m and psi_h (2 x 2 560 B); fp32: the three psi tables
     // (1 536 B; + e_sat: mixed).  The fp64 COARE kernels with the skin schemes come out at exactly two rounds with 24 B to spare.
-    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3840 : 5120) : 3584) : (MIXED ? 3072 : 1536));
+    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3840 : 5120) : (ALGO == 5 ? 4384 : 3584)) : (MIXED ? 3072 : 1536));
     static constexpr int kBudget = 160 * 1024 / kWaves - 160 - ((sizeof(R) == 8 || MIXED) ? 1632 : 0) - kPsiTabBytes;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 2)); // f64: 2 (skin, 4 blocks) / 2 (5 blocks); f32: 2
     static constexpr int kCells = kRounds * kBlock;

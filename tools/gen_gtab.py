@@ -63,6 +63,16 @@ def coare(which):
     return f
 
 
+def psim_andreas_stable(s):
+    """psi_m of ANDREAS on the stable side (Grachev et al. 2007; mod_blk_andreas.f90:321-350) as a function of s = LOG(1 + zeta)"""
+    am, bm = D(5.), D(5.) / D(6.5)
+    B = mp.cbrt((1 - bm) / bm)
+    x = mp.exp(s / 3)
+    return (-3 * am / bm * (x - 1)
+            + am * B / (2 * bm) * (mp.log((x + B) ** 2 / (x * x - x * B + B * B)) - mp.log((1 + B) ** 2 / (1 - B + B * B))
+                                   + 2 * mp.sqrt(3) * (mp.atan((2 * x - B) / (mp.sqrt(3) * B)) - mp.atan((2 - B) / (mp.sqrt(3) * B)))))
+
+
 def g_cs(u):
     if u == 0:
         return mp.mpf(1)
@@ -151,6 +161,18 @@ def main():
         flat = [rows[i][k] for k in range(10) for i in range(32)]
         for j in range(0, len(flat), 4):
             out.append("    " + ", ".join(repr(v) for v in flat[j:j + 4]) + ("," if j + 4 < len(flat) else "};"))
+    # ANDREAS, stable side: psi_m (a cube root, a log, an atan and a division in closed form) is analytic in s = LOG(1 + zeta), its
+    # singularities at Im s = +-pi; zeta <= 15 (the reference's cap): s <= LOG(16) = 2.7726, the table covers [0, 2.8) so that the capped
+    # argument stays inside whatever the last bit of its logarithm
+    out.append("constexpr int kPsiAndStabN = 10;")
+    out.append("constexpr double kPsiAndStabSMax = 2.8;")
+    rows, err = table(psim_andreas_stable, mp.mpf(0), mp.mpf("2.8"), 10)
+    print("kPsiAndStabM", err, file=sys.stderr)
+    out.append(f"// ANDREAS stable psi_m in s = LOG(1 + zeta) for LDS, degree 9, coefficient-major [k * 10 + i], 10 intervals on [0, 2.8): max |table - function| = {err:.2e}")
+    out.append("AB_TAB double kPsiAndStabM[100] = {")
+    flat = [rows[i][k] for k in range(10) for i in range(10)]
+    for j in range(0, len(flat), 4):
+        out.append("    " + ", ".join(repr(v) for v in flat[j:j + 4]) + ("," if j + 4 < len(flat) else "};"))
     DEG = 7
     out.append("}  // namespace ab")
     print("\n".join(out))
