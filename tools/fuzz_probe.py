@@ -43,6 +43,10 @@ CONFIGS = [("coare3p6", 1, 2.0, 10.0, 5), ("coare3p6", 0, 10.0, 10.0, 8), ("coar
 
 def main():
     a = sys.argv[1:]
+    global THRESH
+    if a and a[0] == "--thresh":       # print the values with err > thresh * S(one input, 8 ulp) (default 2)
+        THRESH = float(a[1])
+        a = a[2:]
     if a and a[0] == "--range":        # every configuration of tests/test_gpu_fuzz.py for the seeds first .. last-1
         a = [str(x) for seed in range(int(a[1]), int(a[2])) for c in CONFIGS for x in (seed, *c)]
     for c in range(0, len(a), 6):
