@@ -281,7 +281,7 @@ struct FusedInit {
     // a shard of a sharded session (ab::sharded_model_first_record): the verdict is GLOBAL, so the shard hands its statistics back
     // instead of applying them, and keeps what a redo with another humidity type needs
     bool defer = false;
-    double stats[AB_INIT_NSTATS];
+    double stats[AB_INIT_NSTATS] = {};
     ab::FusedShard *keep = nullptr;
 };
 constexpr int kFusedBlocks = 128;
@@ -886,7 +886,7 @@ namespace ab {
 // staging buffers of the host path, allocated from the calling thread, one shard after the other (sharded_model_first_record: measured —
 // when the shards' worker threads allocate them concurrently inside their first pipelined pass, every record that follows moves
 // over PCIe at 63 GB/s instead of 85, profiles/r3_host_path.txt)
-int leaf_prepare_staging(ab_session *s, int with_rad, int with_ts, const void *host_in0, void *host_out0)
+int leaf_prepare_staging(ab_session *s, int with_rad, int with_ts)
 {
     ab::DeviceGuard dguard_;
     AB_HIP(hipSetDevice(s->device));
@@ -896,15 +896,18 @@ int leaf_prepare_staging(ab_session *s, int with_rad, int with_ts, const void *h
         if ((i < 6 || with_rad) && !s->stage_in[i]) AB_HIP(hipMalloc(&s->stage_in[i], bytes));
     for (int i = 0; i < 6; ++i)
         if ((i < 5 || with_ts) && !s->stage_out[i]) AB_HIP(hipMalloc(&s->stage_out[i], bytes));
-    if (first && host_in0 && host_out0) {
-        // The shard's copy streams carry their FIRST transfer here, alone — one chunk in, one chunk out (the record overwrites both).
-        // Measured on k shards of one device (profiles/r3_host_path.txt): when the shards' very first transfers are the concurrent
-        // chunk pipelines of their workers, EVERY later record moves at 63 GB/s instead of 85 (20.7 -> 27.8 ms per ORCA12 record,
-        // sticky for the life of the process); with each shard's first transfer made alone it does not happen.
+    if (first) {
+        // The shard's copy streams carry their FIRST transfer here, alone — one chunk in, one chunk out, between the staging buffers
+        // and a private host scratch (round 3 used the caller's own arrays: a record that failed afterwards left uninitialised device
+        // memory in the caller's Q_L).  Measured on k shards of one device (profiles/r3_host_path.txt): when the shards' very first
+        // transfers are the concurrent chunk pipelines of their workers, EVERY later record moves at 63 GB/s instead of 85 (20.7 ->
+        // 27.8 ms per ORCA12 record, sticky for the life of the process); with each shard's first transfer made alone it does not happen.
         const size_t cb = bytes < (size_t)kPipeChunk * s->esz ? bytes : (size_t)kPipeChunk * s->esz;
-        AB_HIP(hipMemcpyAsync(s->stage_in[0], host_in0, cb, hipMemcpyHostToDevice, s->s_h2d));
+        std::vector<char> scratch(cb, 0);
+        AB_HIP(hipMemcpyAsync(s->stage_in[0], scratch.data(), cb, hipMemcpyHostToDevice, s->s_h2d));
         AB_HIP(hipStreamSynchronize(s->s_h2d));
-        AB_HIP(hipMemcpyAsync(host_out0, s->stage_out[0], cb, hipMemcpyDeviceToHost, s->s_d2h));
+        AB_HIP(hipMemsetAsync(s->stage_out[0], 0, cb, s->s_d2h));
+        AB_HIP(hipMemcpyAsync(scratch.data(), s->stage_out[0], cb, hipMemcpyDeviceToHost, s->s_d2h));
         AB_HIP(hipStreamSynchronize(s->s_d2h));
     }
     return AB_OK;
@@ -918,6 +921,8 @@ int leaf_fused_first_record(ab_session *leaf, double zt, double zu, int niter, c
     int rc = compute_impl(leaf, 1, zt, zu, niter, in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], out[0], out[1], out[2], out[3],
                           out[4], out[5], AB_MEM_HOST, nullptr, &fi);
     if (rc) { delete fi.keep; return rc; }
+    if (!fi.keep)   // the leaf took the plain path (fewer than kPipeThreshold cells, or diagnostics on): no statistics were taken
+        return fail(AB_ERR_STATE, "fused first record asked of a shard of %ld cells that cannot pipeline it", leaf->n);
     memcpy(stats, fi.stats, sizeof fi.stats);
     *guess = fi.guess;
     *keep = fi.keep;
@@ -1026,10 +1031,14 @@ int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double
         }
         g_sess->last_jt = 0;
         for (ab_session *c : g_sess->shards) c->last_jt = 0;
-        // Large grid on one device: AEROBULK_INIT's statistics ride on the pipelined pass of aerobulk_compute (inputs cross PCIe
-        // once, overlapped with the outputs coming back).  The record is complete when the checks are: an error is still an error.
-        if (!g_sess->sharded() && g_sess->n >= kPipeThreshold && !g_sess->diag_on && (!lsrad || use_skin) &&
-            !getenv("AEROBULK_AMD_NO_FUSED_INIT")) {
+        // The reference's order (mod_aerobulk.f90:246-262) is the default: AEROBULK_INIT decides BEFORE anything is computed, so an
+        // AB_ERR_ALL_MASKED / AB_ERR_HUM_TYPE / AB_ERR_UNITS leaves the caller's output arrays untouched (round 3 did the opposite by
+        // default).  AEROBULK_AMD_FUSED_INIT=1 opts into the one-pass first record: the statistics ride on the pipelined pass of
+        // aerobulk_compute (the inputs cross PCIe once while the outputs already travel back: about 21 ms instead of 31 ms for
+        // record 1 of an ORCA12 grid, once per run) at the price documented in include/aerobulk_amd.h — outputs written before the verdict.
+        const char *fe = getenv("AEROBULK_AMD_FUSED_INIT");
+        const bool fused_ok = fe && fe[0] == '1' && !getenv("AEROBULK_AMD_NO_FUSED_INIT") && (!lsrad || use_skin);
+        if (fused_ok && !g_sess->sharded() && g_sess->n >= kPipeThreshold && !g_sess->diag_on) {
             FusedInit fi;
             fi.have_rad = lsrad ? 1 : 0;
             fi.report = report;
@@ -1037,12 +1046,19 @@ int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double
             return compute_impl(g_sess, jt, zt, zu, g_nb_iter, sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw, ql, qh, tau_x, tau_y,
                                 evap, lsrad ? t_s : nullptr, AB_MEM_HOST, nullptr, &fi);
         }
-        // sharded: the same, every shard on its own device and PCIe link; the verdict is taken on the combined statistics
-        if (g_sess->sharded() && g_sess->shards[0]->n >= kPipeThreshold && !g_sess->shards[0]->diag_on && (!lsrad || use_skin) &&
-            !getenv("AEROBULK_AMD_NO_FUSED_INIT")) {
-            const void *in8[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw};
-            void *out6[6] = {ql, qh, tau_x, tau_y, evap, lsrad ? (void *)t_s : nullptr};
-            return ab::sharded_model_first_record(g_sess, zt, zu, g_nb_iter, in8, out6, lsrad ? 1 : 0, report);
+        if (g_sess->sharded()) {
+            // every shard's copy streams make their first transfer alone (leaf_prepare_staging: the concurrency trap)
+            int rc = ab::sharded_prepare_staging(g_sess, lsrad, lsrad && t_s);
+            if (rc) return rc;
+            // fused, sharded: every shard on its own device and PCIe link, the verdict on the combined statistics.  EVERY shard has
+            // to qualify (the first shards are one row taller: the last may sit just under the threshold; round-3 advisory)
+            bool all = fused_ok;
+            for (ab_session *c : g_sess->shards) all = all && c->n >= kPipeThreshold && !c->diag_on;
+            if (all) {
+                const void *in8[8] = {sst, t_zt, hum_zt, u_zu, v_zu, slp, rad_sw, rad_lw};
+                void *out6[6] = {ql, qh, tau_x, tau_y, evap, lsrad ? (void *)t_s : nullptr};
+                return ab::sharded_model_first_record(g_sess, zt, zu, g_nb_iter, in8, out6, lsrad ? 1 : 0, report);
+            }
         }
         // the reference hands rad_lw to BOTH prsw and prlw (mod_aerobulk.f90:248)
         int rc = ab_session_init(g_sess, sst, t_zt, hum_zt, u_zu, v_zu, slp, lsrad ? rad_lw : nullptr,

@@ -81,6 +81,7 @@ double sharded_last_kernel_ms(ab_session *s);
 int sharded_compute_shards(ab_session *s, int jt, double zt, double zu, int niter, const ab_shard_arrays *sh, void *const *streams);
 int sharded_gather(ab_session *s, int root, const ab_shard_arrays *sh, const ab_flux_arrays *dst, void *const *streams, int synchronize);
 // AEROBULK_MODEL at jt == 1 through a sharded session: AEROBULK_INIT's statistics ride on every shard's pipelined pass
+int sharded_prepare_staging(ab_session *s, int with_rad, int with_ts);
 int sharded_model_first_record(ab_session *s, double zt, double zu, int niter, const void *const in[8], void *const out[6], int have_rad,
                                ab_init_report *report);
 // leaf side of it (ab_runtime.hip): one shard's fused pass (statistics returned, not applied), and its redo with another humidity type
@@ -88,6 +89,6 @@ struct FusedShard;
 int leaf_fused_first_record(ab_session *leaf, double zt, double zu, int niter, const void *const in[8], void *const out[6], int have_rad,
                             double stats[AB_INIT_NSTATS], int *guess, FusedShard **keep);
 int leaf_fused_redo(ab_session *leaf, FusedShard *keep);
-int leaf_prepare_staging(ab_session *leaf, int with_rad, int with_ts, const void *host_in0, void *host_out0);
+int leaf_prepare_staging(ab_session *leaf, int with_rad, int with_ts);
 void leaf_fused_release(FusedShard *keep);
 }  // namespace ab

@@ -317,6 +317,12 @@ double sharded_last_kernel_ms(ab_session *s)
 // type ITS first chunk indicates; the statistics are combined here — the one exchange of the path — the decisions are taken on the
 // whole domain, and a shard whose guess was wrong computes its rows again from the fields resident in its HBM (round 2: a statistics
 // pass of their own and then the compute pass: 30.3 ms against 21.5 ms unsharded).
+// staging buffers and the FIRST transfer of every shard's copy streams, one shard after the other (leaf_prepare_staging: why)
+int sharded_prepare_staging(ab_session *s, int with_rad, int with_ts)
+{
+    return for_shards(s, false, [&](int r) { return leaf_prepare_staging(s->shards[r], with_rad, with_ts); });
+}
+
 int sharded_model_first_record(ab_session *s, double zt, double zu, int niter, const void *const in[8], void *const out[6], int have_rad,
                                ab_init_report *report)
 {
@@ -325,9 +331,7 @@ int sharded_model_first_record(ab_session *s, double zt, double zu, int niter, c
     std::vector<int> guess(n, AB_HUM_SH);
     std::vector<FusedShard *> keep(n, nullptr);
     auto release = [&] { for (auto &k : keep) { leaf_fused_release(k); k = nullptr; } };
-    int rc = for_shards(s, false, [&](int r) {
-        return leaf_prepare_staging(s->shards[r], in[6] && in[7], out[5] != nullptr, off(s, in[0], s->shard_j0[r]), offw(s, out[0], s->shard_j0[r]));
-    });
+    int rc = sharded_prepare_staging(s, in[6] && in[7], out[5] != nullptr);
     if (rc) return rc;
     rc = for_shards(s, true, [&](int r) {
         const long j0 = s->shard_j0[r];

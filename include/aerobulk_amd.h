@@ -293,11 +293,13 @@ int ab_test_math(int op, const double *x, const double *y, double *out, long n);
  * rad_sw/rad_lw/t_s may be NULL (the Fortran OPTIONALs); niter <= 0 keeps the current nb_iter
  * (sticky, default 5: mod_const.f90:33, mod_aerobulk.f90:236).  Host arrays, fp64.
  * Returns an ab_status; `report` (may be NULL) is filled when jt==1.
- * jt == 1 on grids of 4 Mi cells and more (per shard): AEROBULK_INIT's statistics ride on the pipelined pass of the compute (one
- * PCIe crossing of the inputs).  Consequence: when an AEROBULK_INIT error is returned (AB_ERR_ALL_MASKED, AB_ERR_HUM_TYPE,
- * AB_ERR_UNITS) the output arrays already hold fluxes computed with a GUESSED humidity type — the reference aborts before it
- * computes; the arrays mean nothing then.  If the first 2^20 cells misjudge the humidity type of the whole domain, record 1 is
- * computed twice (a one-line notice on stderr).  AEROBULK_AMD_NO_FUSED_INIT=1 restores the reference's order (checks, then compute). */
+ * jt == 1 follows the reference's order (mod_aerobulk.f90:246-262): AEROBULK_INIT's checks first — on an AB_ERR_ALL_MASKED,
+ * AB_ERR_HUM_TYPE or AB_ERR_UNITS the output arrays are untouched — then aerobulk_compute on the fields the checks have just staged
+ * in HBM (one PCIe crossing).  AEROBULK_AMD_FUSED_INIT=1 opts into a one-pass first record on grids of 4 Mi cells and more (per shard,
+ * every shard): the statistics ride on the pipelined pass of the compute, whose kernels start from the humidity type the first 2^20
+ * cells indicate (about 10 ms less, once per run, on an ORCA12 grid).  Consequence of the opt-in: when an AEROBULK_INIT error is
+ * returned the output arrays already hold fluxes computed with a GUESSED humidity type, and if the guess was wrong record 1 is
+ * computed twice (a one-line notice on stderr). */
 int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double zu,
              const double *sst, const double *t_zt, const double *hum_zt,
              const double *u_zu, const double *v_zu, const double *slp,

@@ -8,13 +8,10 @@ Asserted per output field (metric of oracle/parity.py):
   * the largest error of the field relative to its maximum.
 Measured (profiles/r2_fullsize_parity.txt; all eight configurations in the suite since round 3): 58-204 / 0-52 values per field of 15 552 000.
 """
-import os
-from concurrent.futures import ProcessPoolExecutor
-
 import numpy as np
 import pytest
 
-from conftest import ROOT, sensitivity
+from conftest import oracle_full_grid, sensitivity
 
 pytestmark = pytest.mark.gpu
 NI, NJ = 4320, 3600
@@ -22,19 +19,6 @@ IN6 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")
 OUT = (("QL", "ql"), ("QH", "qh"), ("Tau_x", "tau_x"), ("Tau_y", "tau_y"), ("Evap", "evap"), ("T_s", "t_s"))
 N6, N4 = 600, 120            # budgets per field (of 15 552 000 values): about twice what was measured
 MAX_ABS_OVER_SCALE = 2e-12   # largest |got - ref| / max|ref| of any field
-
-
-def _oracle_block(args):
-    algo, skin, niter, j0, njl = args
-    import sys
-    if ROOT not in sys.path:
-        sys.path.insert(0, ROOT)
-    from oracle import pyoracle as po
-    f = po.synth_fields(NI, NJ, j0, njl)
-    o = po.OracleSession(algo, NI * njl, 1, skin).compute(1, 2.0, 10.0, niter, *[f[k] for k in IN6], rad_sw=f["rad_sw"] if skin else None,
-                                                          rad_lw=f["rad_lw"] if skin else None)
-    assert o["rc"] == 0
-    return j0, {k: o[k] for _, k in OUT}
 
 
 # all eight flux configurations of aerobulk_compute: BASELINE config 3 (coare3p6 + skin), config 2's kernel (coare3p6, nb_iter 8),
@@ -45,13 +29,7 @@ def _oracle_block(args):
 def test_every_cell_of_the_benchmark_grid(oracle, algo, skin, niter):
     import aerobulk_amd as ab
     from oracle import parity
-    nproc = max(1, min(os.cpu_count() or 1, 48))
-    per = -(-NJ // (nproc * 4))
-    ref = {k: np.empty(NI * NJ) for _, k in OUT}
-    with ProcessPoolExecutor(nproc) as ex:
-        for j0, o in ex.map(_oracle_block, [(algo, skin, niter, j0, min(per, NJ - j0)) for j0 in range(0, NJ, per)]):
-            for k, v in o.items():
-                ref[k][j0 * NI:j0 * NI + v.size] = v
+    ref = oracle_full_grid(algo, skin, niter, NI, NJ)      # fresh worker interpreters (forkserver), once per session and configuration
     f = oracle.synth_fields(NI, NJ)
     with ab.Session(algo, NI, NJ, 1, skin) as s:
         got = s.compute(1, 2.0, 10.0, *[f[k] for k in IN6], Niter=niter, rad_sw=f["rad_sw"] if skin else None,

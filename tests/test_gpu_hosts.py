@@ -226,15 +226,16 @@ def test_model_first_record_with_fused_init_equals_two_pass(oracle):
     for name, hum in cases.items():
         res = {}
         for mode in ("fused", "two-pass"):
-            if mode == "two-pass":
-                os.environ["AEROBULK_AMD_NO_FUSED_INIT"] = "1"
+            os.environ.pop("AEROBULK_AMD_NO_FUSED_INIT", None)
+            if mode == "fused":
+                os.environ["AEROBULK_AMD_FUSED_INIT"] = "1"      # opt-in since round 4: the default is the reference's order
             else:
-                os.environ.pop("AEROBULK_AMD_NO_FUSED_INIT", None)
+                os.environ.pop("AEROBULK_AMD_FUSED_INIT", None)
             try:
                 r = ab.aerobulk_model(1, 1, "coare3p6", 2.0, 10.0, F["sst"], F["t_zt"], hum, F["u_zu"], F["v_zu"], F["slp"], Niter=4,
                                       l_use_skin=True, rad_sw=F["rad_sw"], rad_lw=F["rad_lw"])
             finally:
-                os.environ.pop("AEROBULK_AMD_NO_FUSED_INIT", None)
+                os.environ.pop("AEROBULK_AMD_FUSED_INIT", None)
             res[mode] = r
         a, b = res["fused"], res["two-pass"]
         assert a["init_report"] == b["init_report"] and a["init_report"]["hum_type"] == ("sh" if name == "sh" else "rh"), a["init_report"]
@@ -243,3 +244,43 @@ def test_model_first_record_with_fused_init_equals_two_pass(oracle):
     with pytest.raises(ab.AerobulkError) as e:            # Celsius SST: the whole domain is masked
         ab.aerobulk_model(1, 1, "coare3p6", 2.0, 10.0, F["sst"] - 273.15, F["t_zt"], F["hum_zt"], F["u_zu"], F["v_zu"], F["slp"], Niter=4)
     assert e.value.status == 5
+
+
+def test_init_errors_at_jt1_leave_the_callers_arrays_untouched(oracle):
+    """The reference's order at jt == 1 (mod_aerobulk.f90:246-262): AEROBULK_INIT aborts BEFORE anything is computed.  On a grid large
+    enough for the chunk pipeline (>= 4 Mi cells), through the C ABI's ab_model with caller-owned output arrays: after
+    AB_ERR_HUM_TYPE and AB_ERR_ALL_MASKED every output array still holds the caller's sentinel; the opt-in one-pass first record
+    (AEROBULK_AMD_FUSED_INIT=1) returns the same codes.  (AB_ERR_UNITS cannot be produced by fields: the mask of
+    mod_aerobulk.f90:108-115 uses the very ranges check_unit_consistency tests, and the humidity's range is that of the detected
+    type; ab_session_init_apply's branch is exercised with doctored statistics in test_abi / test_gpu_sharded.)"""
+    import ctypes as C
+    from aerobulk_amd import _lib
+    L = _lib.load()
+    ni, nj = 2200, 2001                                   # 4.4 M cells
+    f = oracle.synth_fields(ni, nj)
+    n = ni * nj
+    dp = C.POINTER(C.c_double)
+    sentinel = -777.25
+    outs = [np.full(n, sentinel) for _ in range(6)]
+    alg = b"coare3p6"
+
+    def model(fields):
+        p = {k: np.ascontiguousarray(v).ctypes.data_as(dp) for k, v in fields.items()}
+        o = [a.ctypes.data_as(dp) for a in outs]
+        return L.ab_model(1, 1, alg, len(alg), 2.0, 10.0, p["sst"], p["t_zt"], p["hum_zt"], p["u_zu"], p["v_zu"], p["slp"], o[0], o[1], o[2],
+                          o[3], o[4], 4, 1, p["rad_sw"], p["rad_lw"], o[5], ni, nj, None)
+
+    cases = ((6, dict(f, hum_zt=np.full(n, 500.0))),       # AB_ERR_HUM_TYPE: neither kg/kg, K nor %
+             (5, dict(f, sst=f["sst"] - 273.15)))          # AB_ERR_ALL_MASKED: SST in Celsius
+    for want, fields in cases:
+        assert model(fields) == want, L.ab_last_error()
+        for i, o in enumerate(outs):
+            assert np.all(o == sentinel), (want, i)        # nothing was written
+    os.environ["AEROBULK_AMD_FUSED_INIT"] = "1"
+    try:
+        for want, fields in cases:
+            assert model(fields) == want, L.ab_last_error()
+    finally:
+        os.environ.pop("AEROBULK_AMD_FUSED_INIT", None)
+    assert model(f) == 0                                   # and the good fields compute
+    assert not np.any(outs[0] == sentinel)

@@ -12,13 +12,10 @@ AB_F32_MIXED (what `bench.py --config 5` times): fp32 arrays, fp64 anchors (SST,
 hardware transcendentals elsewhere: meets the bar.  AB_F32_STORAGE (fp64 arithmetic on fp32 arrays): one rounding of the result.
 AB_F32 (fp32 arithmetic throughout): does NOT meet it (p99 2e-4, p99.99 1e-3); its error is bounded by quantile for what it is.
 """
-import os
-from concurrent.futures import ProcessPoolExecutor
-
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import oracle_on_cells
 
 pytestmark = pytest.mark.gpu
 IN8 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")
@@ -33,31 +30,10 @@ def restated_error(got, ref, key):
     return d if FLOOR[key] is None else d / np.maximum(np.abs(ref), FLOOR[key])
 
 
-def _oracle_chunk(args):
-    algo, skin, niter, nt, cols = args
-    import sys
-    if ROOT not in sys.path:
-        sys.path.insert(0, ROOT)
-    from oracle import pyoracle as po
-    n = cols[0].size
-    s = po.OracleSession(algo, n, nt, skin)
-    recs = []
-    for jt in range(1, nt + 1):
-        o = s.compute(jt, 2.0, 10.0, niter, *cols[:6], rad_sw=cols[6] if skin else None, rad_lw=cols[7] if skin else None)
-        assert o["rc"] == 0
-        recs.append({k: o[k].copy() for _, k in OUT if k in o})
-    return recs
-
-
 def oracle_parallel(algo, skin, niter, f64, nt=1):
-    """The oracle on the host cores, cells cut into chunks (pointwise path): list over records of dicts of arrays."""
-    n = f64["sst"].size
-    nproc = max(1, min(os.cpu_count() or 1, 48))
-    edges = np.linspace(0, n, max(1, min(nproc * 4, n // 1000 or 1)) + 1).astype(np.int64)
-    jobs = [(algo, skin, niter, nt, [np.ascontiguousarray(f64[k][a:b]) for k in IN8]) for a, b in zip(edges[:-1], edges[1:])]
-    with ProcessPoolExecutor(nproc) as ex:
-        parts = list(ex.map(_oracle_chunk, jobs))
-    return [{k: np.concatenate([p[jt][k] for p in parts]) for k in parts[0][jt]} for jt in range(nt)]
+    """The oracle on the host cores, cells cut into chunks (pointwise path): list over records of dicts of arrays.  Fresh worker
+    interpreters (conftest.oracle_pool: forkserver), never a fork of this process, which holds the HIP runtime."""
+    return oracle_on_cells(algo, skin, niter, f64, nt=nt)
 
 
 def check_restated(got, ref, label, tol=TOL, share=OUTLIER_SHARE, p99=None, tol_ts=None):

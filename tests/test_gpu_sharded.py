@@ -301,7 +301,8 @@ def test_first_record_of_aerobulk_model_is_fused_for_shards_too(oracle, tmp_path
     cells): AEROBULK_INIT's statistics ride on every shard's pass, the verdict is taken on the COMBINED statistics, and a shard whose
     first chunk misjudged the humidity type computes its rows again from its resident fields — here the domain is relative humidity
     and the first 2^20 cells of shard 1 alone read as specific humidity.  Same results and the same report as the two-pass path
-    (AEROBULK_AMD_NO_FUSED_INIT=1) and as one device."""
+    (the default since round 4: the reference's order) and as one device.  The one-pass first record is the opt-in
+    AEROBULK_AMD_FUSED_INIT=1."""
     script = r'''
 import sys, json, numpy as np
 sys.path.insert(0, sys.argv[1])
@@ -319,10 +320,11 @@ np.save(sys.argv[2], np.stack([r[k] for k in ("QL", "QH", "Tau_x", "Tau_y", "Eva
 print("REPORT " + json.dumps(r["init_report"]))
 '''
     res, reps = {}, {}
-    for tag, extra in (("fused", {}), ("twopass", {"AEROBULK_AMD_NO_FUSED_INIT": "1"}), ("one", None)):
+    for tag, extra in (("fused", {"AEROBULK_AMD_FUSED_INIT": "1"}), ("twopass", {}), ("one", None)):
         e = dict(os.environ)
         e.pop("AEROBULK_AMD_DEVICES", None)
         e.pop("AEROBULK_AMD_NO_FUSED_INIT", None)
+        e.pop("AEROBULK_AMD_FUSED_INIT", None)
         if extra is not None:
             e["AEROBULK_AMD_DEVICES"] = "0,0"
             e.update(extra)
@@ -336,3 +338,36 @@ print("REPORT " + json.dumps(r["init_report"]))
     assert reps["fused"] == reps["twopass"] == reps["one"] and '"hum_type": "rh"' in reps["fused"], reps
     np.testing.assert_array_equal(res["fused"], res["twopass"])
     np.testing.assert_array_equal(res["fused"], res["one"])
+
+
+def test_fused_first_record_needs_every_shard_to_qualify(oracle, tmp_path):
+    """Round-3 advisory: with nj = 4095 over two shards the first shard has 2048 rows (4 194 304 cells = the pipelining threshold)
+    and the second 2047 (just under it).  The opt-in fused first record must not be taken (a shard that cannot pipeline takes no
+    statistics): the session falls back to the reference's order, same results and report as one device.  Under the default order
+    the caller's arrays are untouched when AEROBULK_INIT rejects the fields."""
+    script = r'''
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+import aerobulk_amd as ab
+from oracle import pyoracle as po
+ni, nj = 2048, 4095
+f = po.synth_fields(ni, nj)
+F = {k: v.reshape((ni, nj), order="F") for k, v in f.items()}
+args = [F[k] for k in ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp")]
+r = ab.aerobulk_model(1, 1, "coare3p6", 2.0, 10.0, *args, Niter=4, l_use_skin=True, rad_sw=F["rad_sw"], rad_lw=F["rad_lw"])
+np.save(sys.argv[2], np.stack([r[k] for k in ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")]))
+print("REPORT " + json.dumps(r["init_report"]))
+'''
+    res, reps = {}, {}
+    for tag, extra in (("fused-asked", {"AEROBULK_AMD_DEVICES": "0,0", "AEROBULK_AMD_FUSED_INIT": "1"}), ("one", {})):
+        e = dict(os.environ)
+        for k in ("AEROBULK_AMD_DEVICES", "AEROBULK_AMD_NO_FUSED_INIT", "AEROBULK_AMD_FUSED_INIT"):
+            e.pop(k, None)
+        e.update(extra)
+        out = str(tmp_path / f"{tag}.npy")
+        pr = subprocess.run([sys.executable, "-c", script, ROOT, out], env=e, capture_output=True, text=True, timeout=900)
+        assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-4000:]
+        res[tag] = np.load(out)
+        reps[tag] = [ln for ln in pr.stdout.splitlines() if ln.startswith("REPORT ")][0]
+    assert reps["fused-asked"] == reps["one"] and '"hum_type": "sh"' in reps["one"], reps
+    np.testing.assert_array_equal(res["fused-asked"], res["one"])
