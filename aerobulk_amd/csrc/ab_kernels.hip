@@ -134,14 +134,25 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     T_s = o.T_s;
 }
 
+// The kernel's arguments re-read from the kernarg segment through a pointer the compiler cannot see through: the scalar loads stay at the
+// phase that uses them instead of being hoisted to the kernel's entry and kept alive (or spilled to VGPR lanes) across the iteration.
+template <class T> __device__ __forceinline__ const T &kernarg_at(unsigned off)
+{
+    const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const T *)(p + off);
+}
+
 // A: the anchor type (ab_physics.hpp, "ANCHORS").  A = R for the fp64 and fp32 sessions; AB_F32_MIXED is <R = float, S = float,
 // A = double>: fp32 arrays and fp32 hardware transcendentals, with SST, theta, q, T_s, q_s, their differences and q_sat in fp64.
 template <class R, int ALGO, bool SKIN, bool DIAG, class S = R, class A = R>
 // (the DIAG instantiations carry sixteen more live values: four waves per SIMD, on the tiles sized for Tile::kOcc)
-__global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO, SKIN, !std::is_same<R, A>::value>::kOcc)) flux_kernel(const FluxArgs<R, S> a, const DiagArgs<S> dg)
+__global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO, SKIN, !std::is_same<R, A>::value>::kOcc)) flux_kernel(const FluxArgs<R, S> a_in, const DiagArgs<S> dg_in)
 {
     constexpr bool kMixed = !std::is_same<R, A>::value;
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves
+        const FluxArgs<R, S> &a = a_in;
+        const DiagArgs<S> &dg = dg_in;
         const long k = (long)blockIdx.x * kBlock + threadIdx.x;
         const bool live = k < a.n;
         // the cell's loads are in flight while the block fills its math tables
@@ -166,6 +177,14 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
         if (a.t_s) a.t_s[k] = (S)T_s;
         return;
     }
+    // Every phase re-reads the kernel arguments it needs from the kernarg segment (kernarg_at: scalar loads from constant memory, next to
+    // their use).  Loaded once at the kernel's entry — what the compiler does with by-value arguments — the 19 pointers, the heights and
+    // the switches are 80 SGPRs alive across the iteration, where the polynomials' coefficients push them out to VGPR lanes: the headline
+    // kernel carried 107 v_readlane / 21 v_writelane (29 SGPRs spilled), none now; -1.0 % (COARE3p6 + skin) ... -2.9 % (NCAR is not
+    // touched: noise) on 4320x3600, same-box, six order-balanced passes, bit-identical (profiles/r4_notes.md §2).
+    constexpr unsigned kDgOff = (unsigned)((sizeof(FluxArgs<R, S>) + 7) & ~(size_t)7);
+#define AB_ARGS const FluxArgs<R, S> &a = kernarg_at<FluxArgs<R, S>>(0)
+#define AB_DIAGS const DiagArgs<S> &dg = kernarg_at<DiagArgs<S>>(kDgOff)
     using T = Tile<R, ALGO, SKIN, kMixed>;
     // field rows: sst theta q_zt u v slp [qsw rlw]; mixed: one more row at the end, the low part of theta (theta is an fp64 anchor
     // parked as a float pair; sst and q_zt are fp32 numbers anyway, exactly in 'sh' mode and to half an fp32 ulp otherwise)
@@ -175,31 +194,36 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     __shared__ unsigned s_cnt[kSortCounters], s_base[kSortCounters];
     __shared__ int s_next;
     const int tid = threadIdx.x;
-    // <= T::kRounds; fewer on small grids so that every CU gets blocks.  The LAST blocks of the grid own one-round tiles: the chip
-    // drains over the life of a short block instead of a long one (launch_t)
-    int rounds = a.rounds;
-    long tile0 = (long)blockIdx.x * ((long)rounds * kBlock);
-    if ((long)blockIdx.x >= a.nfull) {
-        tile0 = a.nfull * ((long)rounds * kBlock) + ((long)blockIdx.x - a.nfull) * kBlock;
-        rounds = 1;
-    }
-
-    // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126.  The loads of a round are
-    // issued one round ahead: those of round 0 are in flight while the block fills its math tables, those of round r+1 while
-    // round r is pre-processed (a block starts with nothing else to hide that latency behind).
     struct Raw { R sst, t_zt, hum, uu, vv, slp, rsw, rlw; };
-    auto fetch = [&](int r) -> Raw {
+    // tile t of the launch: <= T::kRounds rounds of 256 cells; fewer on small grids so that every CU gets blocks.  The LAST tiles of
+    // the grid are one-round tiles: the chip drains over the life of a short tile instead of a long one (launch_t)
+    auto tile_of = [](const FluxArgs<R, S> &a, long t, long &t0, int &rr) {
+        rr = a.rounds;
+        t0 = t * ((long)rr * kBlock);
+        if (t >= a.nfull) { t0 = a.nfull * ((long)rr * kBlock) + (t - a.nfull) * kBlock; rr = 1; }
+    };
+    // owners load their cells (coalesced); streamed once: non-temporal, so that the fields do not push the piecewise tables
+    // (ab_gtables.hpp) out of the L1
+    auto fetch = [](const FluxArgs<R, S> &a, int tid, long tile0, int rounds, int r) -> Raw {
         Raw w{R(290.), R(290.), R(0.01), R(1.), R(1.), R(101000.), R(0.), R(0.)};
         const long k = tile0 + r * kBlock + tid;
         if (r < rounds && k < a.n) {
-            // streamed once: non-temporal, so that the fields do not push the piecewise tables (ab_gtables.hpp) out of the L1
             w.sst = (R)ldnt(a.sst + k); w.t_zt = (R)ldnt(a.t_zt + k); w.hum = (R)ldnt(a.hum + k); w.uu = (R)ldnt(a.u + k); w.vv = (R)ldnt(a.v + k);
             w.slp = (R)ldnt(a.slp + k);
             if (SKIN) { w.rsw = (R)ldnt(a.rad_sw + k); w.rlw = (R)ldnt(a.rad_lw + k); }
         }
         return w;
     };
-    Raw nxt = fetch(0);
+    long tile0;
+    int rounds;
+    Raw nxt;
+    {
+        AB_ARGS;
+        tile_of(a, (long)blockIdx.x, tile0, rounds);
+        // ---- phase 1 starts here: the loads of a round are issued one round ahead: those of round 0 are in flight while the block fills
+        // its math tables, those of round r+1 while round r is pre-processed (a block starts with nothing else to hide that latency behind)
+        nxt = fetch(a, tid, tile0, rounds, 0);
+    }
     if (tid == 0) s_next = 0;
     tile_sort_reset(s_cnt, tid);
     // (before the barrier of math_tables_init) fp64: COARE reads its psi tables through L1 (ab_gtables.hpp); ECMWF / ANDREAS keep the
@@ -212,91 +236,110 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     if constexpr (kMixed) esat_table_fill();              // q_sat of the mixed mode is the fp64 one, through its LDS table
     math_tables_init<A>();
     if (sizeof(A) != 8) __syncthreads();                  // (fp64: the barrier of math_tables_init) counters zeroed before phase 1
+    {
+        // ---- phase 1: pre-processing mod_aerobulk_compute.f90:99-126
+        {
+            AB_ARGS;
 #pragma unroll 1
-    for (int r = 0; r < rounds; ++r) {
-        const int j = r * kBlock + tid;
-        const long k = tile0 + j;
-        const Raw w = nxt;
-        nxt = fetch(r + 1);
-        int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
-        if (k < a.n) {
-            const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
-            constexpr bool kEsatTab = (SKIN || kMixed) && kPsiTabDefault;
-            A q_zt;
-            if (a.hum_type == 0) q_zt = A(hum);                                     // 'sh'
-            else if (a.hum_type == 1) q_zt = q_air_dp<A, kEsatTab>(A(hum), A(vmax(slp, R(50000.))));   // 'dp' :103
-            else q_zt = q_air_rh<A, kEsatTab>(A(hum), A(t_zt), A(vmax(slp, R(50000.))));              // 'rh' :105
-            const A theta = theta_from_z_p0_t_q<A, kEsatTab>(A(a.h.zt), A(slp), A(t_zt), q_zt);       // :118
-            s_f[0][j] = sst; s_f[1][j] = R(theta); s_f[2][j] = R(q_zt); s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
-            if constexpr (kMixed) s_f[kThLo][j] = R(theta - A(R(theta)));
-            R qsw = R(0.), rlw = R(0.);
-            if (SKIN) {
-                qsw = (R(1.) - K<R>::roce_alb0) * w.rsw;                            // :135,146,161
-                rlw = w.rlw;
-                s_f[SKIN ? 6 : 0][j] = qsw; s_f[SKIN ? 7 : 0][j] = rlw;
-            }
-            if (a.regroup) {
-                const bool wll = SKIN && a.wl_load;
-                bkt = forecast_bucket<ALGO, SKIN>((float)sst, (float)theta, (float)q_zt, (float)uu, (float)vv, (float)slp,
-                                                  (float)qsw, (float)rlw, wll, wll ? (float)a.wl0[k] : 0.f,
-                                                  (wll && ALGO != 4) ? (float)a.wl1[k] : 20.f);
-            } else {
-                bkt = 0;
+            for (int r = 0; r < rounds; ++r) {
+                const int j = r * kBlock + tid;
+                const long k = tile0 + j;
+                const Raw w = nxt;
+                nxt = fetch(a, tid, tile0, rounds, r + 1);
+                int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
+                if (k < a.n) {
+                    const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
+                    constexpr bool kEsatTab = (SKIN || kMixed) && kPsiTabDefault;
+                    A q_zt;
+                    if (a.hum_type == 0) q_zt = A(hum);                                     // 'sh'
+                    else if (a.hum_type == 1) q_zt = q_air_dp<A, kEsatTab>(A(hum), A(vmax(slp, R(50000.))));   // 'dp' :103
+                    else q_zt = q_air_rh<A, kEsatTab>(A(hum), A(t_zt), A(vmax(slp, R(50000.))));              // 'rh' :105
+                    const A theta = theta_from_z_p0_t_q<A, kEsatTab>(A(a.h.zt), A(slp), A(t_zt), q_zt);       // :118
+                    s_f[0][j] = sst; s_f[1][j] = R(theta); s_f[2][j] = R(q_zt); s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
+                    if constexpr (kMixed) s_f[kThLo][j] = R(theta - A(R(theta)));
+                    R qsw = R(0.), rlw = R(0.);
+                    if (SKIN) {
+                        qsw = (R(1.) - K<R>::roce_alb0) * w.rsw;                            // :135,146,161
+                        rlw = w.rlw;
+                        s_f[SKIN ? 6 : 0][j] = qsw; s_f[SKIN ? 7 : 0][j] = rlw;
+                    }
+                    if (a.regroup) {
+                        const bool wll = SKIN && a.wl_load;
+                        bkt = forecast_bucket<ALGO, SKIN>((float)sst, (float)theta, (float)q_zt, (float)uu, (float)vv, (float)slp,
+                                                          (float)qsw, (float)rlw, wll, wll ? (float)a.wl0[k] : 0.f,
+                                                          (wll && ALGO != 4) ? (float)a.wl1[k] : 20.f);
+                    } else {
+                        bkt = 0;
+                    }
+                }
+                if (a.regroup) tile_sort_note(s_cnt, s_inv, j, bkt, tid);
             }
         }
-        if (a.regroup) tile_sort_note(s_cnt, s_inv, j, bkt, tid);
-    }
-    __syncthreads();
-    // ---- phase 2: who computes which cell
-    if (a.regroup) {
-        tile_sort_place<T::kRounds>(s_cnt, s_base, s_inv, tid, rounds);
-    } else {
-        for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
-    }
-    __syncthreads();
+        __syncthreads();
+        // ---- phase 2: who computes which cell
+        {
+            AB_ARGS;
+            if (a.regroup) {
+                tile_sort_place<T::kRounds>(s_cnt, s_base, s_inv, tid, rounds);
+                tile_sort_reset(s_cnt, tid);   // (behind the barrier inside tile_sort_place: the counts have been read) for the block's next tile
+            } else {
+                for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
+            }
+        }
+        __syncthreads();
 
-    // ---- phase 3: groups of 64 sorted cells, fetched from a queue
-    const int lane = tid & 63;
-    const Heights<R> hh = detached(a.h);      // loop invariants out of their scalar-load tuples (ab_tile.hpp)
-    int nb_iter = a.nb_iter;
-    uniform_scalar(nb_iter);
+        // ---- phase 3: groups of 64 sorted cells, fetched from a queue
+        {
+            AB_ARGS;
+            AB_DIAGS;
+            const int lane = tid & 63;
+            const Heights<R> hh = detached(a.h);      // loop invariants out of their scalar-load tuples (ab_tile.hpp)
+            int nb_iter = a.nb_iter;
+            uniform_scalar(nb_iter);
 #pragma unroll 1
-    for (;;) {
-        int g = 0;
-        if (lane == 0) g = atomicAdd(&s_next, 1);
-        g = __builtin_amdgcn_readfirstlane(g);
-        if (g >= rounds * (kBlock / 64)) break;
-        const int j = s_inv[g * 64 + lane];
-        const long k = tile0 + j;
-        if (k >= a.n) continue;
+            for (;;) {
+                int g = 0;
+                if (lane == 0) g = atomicAdd(&s_next, 1);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (g >= rounds * (kBlock / 64)) break;
+                const int j = s_inv[g * 64 + lane];
+                const long k = tile0 + j;
+                if (k >= a.n) continue;
 
-        R QL, QH, tx, ty, zEvap;
-        A T_s;
-        A theta = A(s_f[1][j]);
-        if constexpr (kMixed) theta = theta + A(s_f[kThLo][j]);
-        compute_cell<R, ALGO, SKIN, DIAG, true, S, A>(a, dg, hh, nb_iter, k, A(s_f[0][j]), theta, A(s_f[2][j]), s_f[3][j], s_f[4][j], s_f[5][j],
-                                          SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
-                                          ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
-                                          // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare
-                                          (SKIN && sizeof(R) == 8) ? (lds_vptr<R>)&s_f[0][j] : (lds_vptr<R>)nullptr, T::kCells);
-        // the cell's LDS slot is read by this lane only: reuse it for the results
-        s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = R(T_s);
-    }
-    __syncthreads();
+                R QL, QH, tx, ty, zEvap;
+                A T_s;
+                A theta = A(s_f[1][j]);
+                if constexpr (kMixed) theta = theta + A(s_f[kThLo][j]);
+                compute_cell<R, ALGO, SKIN, DIAG, true, S, A>(a, dg, hh, nb_iter, k, A(s_f[0][j]), theta, A(s_f[2][j]), s_f[3][j], s_f[4][j], s_f[5][j],
+                                                  SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
+                                                  ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
+                                                  // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare
+                                                  (SKIN && sizeof(R) == 8) ? (lds_vptr<R>)&s_f[0][j] : (lds_vptr<R>)nullptr, T::kCells);
+                // the cell's LDS slot is read by this lane only: reuse it for the results
+                s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = R(T_s);
+            }
+        }
+        __syncthreads();
 
-    // ---- phase 4: owners store (coalesced)
+        // ---- phase 4: owners store (coalesced)
+        {
+            AB_ARGS;
 #pragma unroll 1
-    for (int r = 0; r < rounds; ++r) {
-        const int j = r * kBlock + tid;
-        const long k = tile0 + j;
-        if (k >= a.n) break;
-        stnt(a.ql + k, (S)s_f[0][j]);
-        stnt(a.qh + k, (S)s_f[1][j]);
-        stnt(a.tau_x + k, (S)s_f[2][j]);
-        stnt(a.tau_y + k, (S)s_f[3][j]);
-        if (a.evap) stnt(a.evap + k, (S)s_f[4][j]);                                // :208
-        if (a.t_s) stnt(a.t_s + k, (S)s_f[5][j]);                                  // :206
+            for (int r = 0; r < rounds; ++r) {
+                const int j = r * kBlock + tid;
+                const long k = tile0 + j;
+                if (k >= a.n) break;
+                stnt(a.ql + k, (S)s_f[0][j]);
+                stnt(a.qh + k, (S)s_f[1][j]);
+                stnt(a.tau_x + k, (S)s_f[2][j]);
+                stnt(a.tau_y + k, (S)s_f[3][j]);
+                if (a.evap) stnt(a.evap + k, (S)s_f[4][j]);                                // :208
+                if (a.t_s) stnt(a.t_s + k, (S)s_f[5][j]);                                  // :206
+            }
+        }
     }
+#undef AB_ARGS
+#undef AB_DIAGS
 }
 
 template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)

@@ -23,6 +23,7 @@ template <class R> static Heights<R> make_heights(double zt, double zu)
     h.fg_ca = (R)(0.035 * log(10. / 0.0001) / log(zu / 0.0001));  // mod_common_coare.f90:107
     h.inv_zu = (R)(1. / zu);
     h.zt_o_zu = (R)(zt / zu);
+    h.fg_cb = -(R)(0.004 * 600. * 1.2 * 1.2 * 1.2) * h.inv_zu;   // zc_b of FIRST_GUESS_COARE (mod_common_coare.f90:141), one product in R
     h.zt_eq_zu = (fabs(zu - zt) < 0.01) ? 1 : 0;
     return h;
 }

@@ -35,7 +35,7 @@ template <class R> __device__ __forceinline__ Heights<R> detached(const Heights<
 #ifndef AB_ARGS_AS_LOADED
     uniform_scalar(h.zt); uniform_scalar(h.zu); uniform_scalar(h.log_zt); uniform_scalar(h.log_zu); uniform_scalar(h.log_10);
     uniform_scalar(h.log_ztu); uniform_scalar(h.log_zu10); uniform_scalar(h.fg_ca); uniform_scalar(h.inv_zu);
-    uniform_scalar(h.zt_o_zu); uniform_scalar(h.zt_eq_zu);
+    uniform_scalar(h.zt_o_zu); uniform_scalar(h.zt_eq_zu); uniform_scalar(h.fg_cb);
 #endif
     return h;
 }     // 4 stability bins x 4 warm-layer bins

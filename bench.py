@@ -17,8 +17,9 @@ output fields to rank 0 when N > 1; the grid is j-block sharded across ranks: st
    4  all five algorithms back-to-back on 4320x3600 (no skin scheme for any: one consistent setting; --skin adds
       the scheme for the three algorithms that have one); a step = the five passes; value = 5 x cells per step
    5  ECMWF + cool-skin/warm-layer, fp32 path, 12960x10800
-For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
-Rank 0 prints ONE JSON line.
+N > 1: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU; the driver's form), or plain
+`python bench.py --gpus N` = ONE process with one sharded library session over N devices and the library's own in-process RCCL
+gather (main_inprocess; --launcher torchrun starts the former as a child instead).  ONE JSON line is printed.
 """
 import argparse
 import hashlib
@@ -194,6 +195,188 @@ def resolve_config(a):
     return passes, grid, prec, niter
 
 
+def main_inprocess(a):
+    """`python bench.py --gpus N` as typed: ONE process, one sharded library session per pass over N devices.  Every shard's fields
+    are resident on its device; a step = ab_session_compute_shards (kernels enqueued on every device) + ab_session_gather of
+    tau / Q_L / Q_H / E (+ T_s with --gather-ts) to the device of shard 0 by RCCL send / recv inside the process
+    (ncclCommInitAll) — the north_star's layout behind AEROBULK_MODEL's call site (mod_aerobulk.f90:250-262).  Two sets of output /
+    destination buffers: the gather of step t (on communication streams) drains while step t + 1 computes."""
+    import torch
+    import aerobulk_amd as ab
+
+    nsh = a.gpus
+    devs = [int(x) for x in a.devices.split(",")] if a.devices else list(range(nsh))
+    if len(devs) != nsh:
+        raise SystemExit(f"--devices lists {len(devs)} shards, --gpus says {nsh}")
+    nvis = torch.cuda.device_count()
+    if max(devs) >= nvis:
+        raise SystemExit(f"--gpus {nsh}: device {max(devs)} asked for, {nvis} visible (one-GPU box: --devices 0,0,... puts the shards on device 0)")
+    passes, grid, precision, niter = resolve_config(a)
+    ni, nj = (int(x) for x in grid.lower().split("x"))
+    npass = len(passes)
+    any_skin = any(sk for _, sk in passes)
+    zt, zu = 2.0, 10.0
+    esz = 8 if precision == "f64" else 4
+    tdt = torch.float64 if precision == "f64" else torch.float32
+    dtype_label = {"f64": "f64", "f32": "f32", "f32_storage": "f32 arrays / f64 arithmetic",
+                   "f32_mixed": "f32 arrays / f64 anchors + f32 transcendentals (AB_F32_MIXED)"}[precision]
+    gnames = ("QL", "QH", "Tau_x", "Tau_y", "Evap") + (("T_s",) if (a.gather_ts and any_skin) else ())
+    root = 0
+    root_dev = torch.device("cuda", devs[root])
+    torch.cuda.set_device(root_dev)
+    nbuf = 1 if a.no_pipeline_gather else 2
+
+    sessions = [ab.Session(algo, ni, nj, 1, skin, precision=precision, device=devs) for algo, skin in passes]
+    for s_ in sessions:
+        s_.set_humidity("sh")
+    shards = sessions[0].shards()                      # [(j0, njl, device)]: the same cut for every pass
+    fields, cstream, mstream = [], [], []
+    for j0, njl, d in shards:
+        with torch.cuda.device(d):
+            fields.append(ab.synth_fields_device(ni, nj, j0, njl, precision=precision, device=torch.device("cuda", d), with_rad=True))
+            cstream.append(torch.cuda.Stream(device=d))
+            mstream.append(torch.cuda.Stream(device=d))
+    torch.cuda.synchronize()
+    # destinations on the root's device: [buffer set][pass] -> dict of whole-grid tensors; the root shard computes straight into its rows
+    dst = [[{k: torch.zeros(ni * nj, dtype=tdt, device=root_dev) for k in gnames} for _ in range(npass)] for _ in range(nbuf)]
+    outs = []                                          # [buffer set][pass][shard] -> dict of that shard's output tensors
+    for b in range(nbuf):
+        per_pass = []
+        for p, (algo, skin) in enumerate(passes):
+            per_shard = []
+            for r, (j0, njl, d) in enumerate(shards):
+                names = ("QL", "QH", "Tau_x", "Tau_y", "Evap") + (("T_s",) if skin else ())
+                if r == root:
+                    o = {k: (dst[b][p][k][j0 * ni:(j0 + njl) * ni] if k in dst[b][p] else torch.empty(ni * njl, dtype=tdt, device=root_dev)) for k in names}
+                else:
+                    o = {k: torch.empty(ni * njl, dtype=tdt, device=torch.device("cuda", d)) for k in names}
+                per_shard.append(o)
+            per_pass.append(per_shard)
+        outs.append(per_pass)
+    shard_in = [[{k: f[k] for k in (IN6 + (("rad_sw", "rad_lw") if skin else ()))} for f in fields] for _, skin in passes]
+    c_ptr = [st.cuda_stream for st in cstream]
+    m_ptr = [st.cuda_stream for st in mstream]
+    gdone = [[None] * len(shards) for _ in range(nbuf)]      # per buffer set and shard: event "the gathers that read this set are done"
+    nstep = [0]
+
+    def step(with_gather=True, nit=None):
+        b = nstep[0] % nbuf
+        nstep[0] += 1
+        for r, (_, _, d) in enumerate(shards):               # the set is written again only after its gathers of nbuf steps ago
+            if gdone[b][r] is not None:
+                cstream[r].wait_event(gdone[b][r])
+        for p, sess in enumerate(sessions):
+            sess.compute_shards(1, zt, zu, shard_in[p], outs[b][p], Niter=niter if nit is None else nit, streams=c_ptr, check=False)
+            if with_gather:
+                for r in range(len(shards)):                 # communication streams: behind the kernels of this pass
+                    mstream[r].wait_stream(cstream[r])
+                sess.gather([{k: v for k, v in o.items() if k in gnames} for o in outs[b][p]], dst[b][p], root=root, streams=m_ptr, synchronize=False)
+        if with_gather:
+            for r, (_, _, d) in enumerate(shards):
+                ev = torch.cuda.Event()
+                ev.record(mstream[r])
+                gdone[b][r] = ev
+            # the root's compute stream also waits for what was received into this set before writing it again
+            ev = torch.cuda.Event()
+            ev.record(mstream[root])
+            gdone[b][root] = ev
+
+    def sync():
+        for d in sorted(set(devs)):
+            torch.cuda.synchronize(d)
+
+    def timed(nsteps, with_gather):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step(with_gather)
+        sync()
+        return time.perf_counter() - t0
+
+    for _ in range(max(4, 40 // npass) if ni * nj <= 4320 * 3600 else 4):     # clock ramp, as the other path
+        step()
+    sync()
+    for _ in range(a.warmup):
+        step()
+    elapsed = timed(a.steps, True)
+    elapsed_resident = timed(a.steps, False)
+    for s_ in sessions:
+        s_.check()
+
+    # per-device kernel duration: events on every shard's compute stream around the launch of the headline pass
+    kms = [0.0] * len(shards)
+    nrep = min(a.steps, 10)
+    for _ in range(nrep):
+        evs = []
+        for r, (_, _, d) in enumerate(shards):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cstream[r])
+            evs.append((e0, e1))
+        sessions[0].compute_shards(1, zt, zu, shard_in[0], outs[0][0], Niter=niter, streams=c_ptr, check=False)
+        for r in range(len(shards)):
+            evs[r][1].record(cstream[r])
+        sync()
+        for r in range(len(shards)):
+            kms[r] += evs[r][0].elapsed_time(evs[r][1]) / nrep
+
+    verify_msg = None
+    if a.verify:
+        step(True, nit=niter + 1)                              # other fields than every step before: a stale buffer cannot pass
+        sync()
+        b = (nstep[0] - 1) % nbuf
+        ff = ab.synth_fields_device(ni, nj, precision=precision, device=root_dev, with_rad=True)
+        bad = []
+        for p, (algo, skin) in enumerate(passes):
+            with ab.Session(algo, ni, nj, 1, skin, precision=precision, device=devs[root]) as s1:
+                s1.set_humidity("sh")
+                one = s1.compute(1, zt, zu, *[ff[k] for k in IN6], Niter=niter + 1, rad_sw=ff["rad_sw"] if skin else None,
+                                 rad_lw=ff["rad_lw"] if skin else None, want_T_s=skin)
+            bad += [f"{algo}:{k}" for k in gnames if k in one and not torch.equal(dst[b][p][k], one[k])]
+        verify_msg = "gathered == single-GPU (bit-identical)" if not bad else f"MISMATCH in {bad}"
+        if bad:
+            raise SystemExit("verify failed: " + verify_msg)
+
+    cells = ni * nj
+    head_algo, head_skin = passes[0]
+    bpc = algorithmic_bytes_per_cell(head_skin, esz)
+    slow = max(range(len(shards)), key=lambda r: kms[r])
+    n_slow = ni * shards[slow][1]
+    achieved = bpc * n_slow / (kms[slow] * 1e-3) / 1e9 if kms[slow] > 0 else 0.0
+    what = " + ".join(f"{al}{' + cool-skin/warm-layer' if sk else ''}" for al, sk in passes)
+    headline = (a.config == 3 and head_algo == "coare3p6" and head_skin and (ni, nj) == (4320, 3600))
+    ndist = len(set(devs))
+    forced = os.environ.get("AEROBULK_AMD_GATHER") == "rccl"
+    res = {
+        "metric": "Mcell/s COARE3p6+cool-skin on 4320x3600 grid" if headline else f"Mcell/s {what} on {ni}x{nj} grid",
+        "value": round(npass * cells * a.steps / elapsed / 1e6, 2), "unit": "Mcell/s", "n_gpus": nsh, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": dtype_label, "data": "synthetic", "launcher": "inprocess",
+        "config": {"workload": f"BASELINE config {a.config}: {what}, {ni}x{nj} grid, nb_iter={niter}, zt=2 zu=10, one time record (jt=1=Nt)"
+                               f"{' per algorithm, the ' + str(npass) + ' passes back-to-back' if npass > 1 else ''}, fields resident in the HBM of the "
+                               f"device that owns their rows",
+                   "grid": [ni, nj], "algo": head_algo if npass == 1 else list(ALL_ALGOS), "skin": head_skin if npass == 1 else any_skin, "nb_iter": niter,
+                   "sharding": f"one process, one sharded session: {nsh} j-blocks of {shards[0][1]}..{shards[-1][1]} rows on devices {devs} "
+                               f"(ab_session_compute_shards), {', '.join(gnames)} gathered to device {devs[root]} by ab_session_gather "
+                               f"(in-process RCCL send / recv over {ndist if ndist > 1 else (1 if forced else 0)} communicator ranks; device-to-device "
+                               f"copies for shards on the root's device), {nbuf} buffer set{'s' if nbuf > 1 else ''}"},
+        "n_ranks_rccl": ndist if ndist > 1 else (1 if forced else 0),
+        "resident": {"value": round(npass * cells * a.steps / elapsed_resident / 1e6, 2), "unit": "Mcell/s",
+                     "ms_per_step": round(elapsed_resident / a.steps * 1e3, 4),
+                     "note": "the same K steps with the fluxes left on the device that computed them (no gather)"},
+        "per_device_kernel_ms": {f"shard{r}@gpu{shards[r][2]}": round(kms[r], 4) for r in range(len(shards))},
+        "roofline": {"bound": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": None, "kernel": f"flux_kernel<{precision},{head_algo},{'skin' if head_skin else 'noskin'}>",
+                     "kernel_ms": round(kms[slow], 4), "bytes_per_cell": bpc, "cells_per_launch": n_slow,
+                     "note": "the slowest shard's launch of the first pass; per device, not summed over devices"},
+    }
+    if verify_msg:
+        res["verify"] = verify_msg
+    print(json.dumps(res), flush=True)
+    for s_ in sessions:
+        s_.close()
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,7 +412,30 @@ def main():
     ap.add_argument("--no-pipeline-gather", action="store_true", help="N>1: every step waits for its own gathers (round 2's order) instead "
                     "of letting them drain while the next step computes into the other buffer set")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row sub-blocks per rank (gather of one overlaps compute of the next)")
+    ap.add_argument("--launcher", default="auto", choices=["auto", "inprocess", "torchrun"],
+                    help="N>1 started as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment): inprocess (auto) = ONE process, one "
+                         "sharded library session over the devices (ab_session_compute_shards + ab_session_gather: in-process RCCL), what a "
+                         "Fortran host gets at mod_aerobulk.f90:250-262; torchrun = start `python -m torch.distributed.run` as a child (before "
+                         "anything touches the GPU) and run one rank per GPU")
+    ap.add_argument("--devices", default=None, help="inprocess: device ordinals of the shards, e.g. 0,1,2,3 (default 0..N-1); an ordinal may "
+                                                     "repeat (several shards on one GPU: how the path is exercised on a one-GPU box)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if a.launcher == "torchrun":          # a child process, started before this one initialises the GPU; its exit code is ours
+            import subprocess
+            argv, skip = [], False
+            for x in sys.argv[1:]:
+                if skip or x.startswith("--launcher="):
+                    skip = False
+                elif x == "--launcher":
+                    skip = True
+                else:
+                    argv.append(x)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", os.environ.get("MASTER_PORT", "29577"), os.path.abspath(__file__), *argv]
+            raise SystemExit(subprocess.call(cmd))
+        return main_inprocess(a)
 
     import torch
     import aerobulk_amd as ab
@@ -237,9 +443,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     ngpu = torch.cuda.device_count()
     dev_index = local_rank if a.backend == "nccl" else local_rank % max(ngpu, 1)
     torch.cuda.set_device(dev_index)

@@ -141,7 +141,7 @@ def pytest_runtest_protocol(item, nextitem):
 # runs last and only while the session is inside its wall budget (AB_TEST_BUDGET_S, default 600 s; 0 = no budget); tier 1 / 2 never skip.
 BUDGET_S = float(os.environ.get("AB_TEST_BUDGET_S", "600"))
 _FULLSIZE_T1 = ("coare3p6-True-5", "coare3p6-False-8")                    # BASELINE configs 3 and 2 (kernel) on every cell of the ORCA12 grid
-_BENCH_T2 = ("world0-extra0", "world6-extra6", "world8-extra8")            # default, config 4, config 5: the other launches are tier 3
+_BENCH_T2 = ("[2-extra0]", "[2-extra6]", "[2-extra8]")                     # default, config 4, config 5: the other torchrun launches are tier 3
 
 
 def tier_of(nodeid):

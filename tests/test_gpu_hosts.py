@@ -186,6 +186,27 @@ def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
         assert "link_GBps" in res["config"]["sharding_tuning"], res["config"]
 
 
+@pytest.mark.parametrize("extra,env", [([], {}), (["--gather-ts"], {"AEROBULK_AMD_GATHER": "rccl"}), (["--config", "4", "--no-pipeline-gather"], {})],
+                         ids=["d2d", "rccl-one-device-communicator", "config4-unpipelined"])
+def test_bench_as_typed_runs_the_library_sharded_session(extra, env):
+    """`python3 bench.py --gpus 2` exactly as typed (no launcher, no WORLD_SIZE): one process, one sharded library session —
+    ab_session_compute_shards on device-resident rows + ab_session_gather — here with both shards on device 0 (--devices 0,0: the box
+    has one GPU); AEROBULK_AMD_GATHER=rccl makes the second shard's rows travel by ncclSend / ncclRecv on a one-device communicator.
+    --verify: the gathered fields are bit-identical to one unsharded session."""
+    import sys
+    e = dict(os.environ, **env)
+    e.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--grid", "720x333", "--steps", "3", "--warmup", "1",
+           "--verify", *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["launcher"] == "inprocess" and res["verify"].startswith("gathered == single-GPU")
+    assert res["value"] > 0 and res["resident"]["value"] > 0 and len(res["per_device_kernel_ms"]) == 2
+    assert res["n_ranks_rccl"] == (1 if env else 0)
+    assert res["roofline"]["achieved"] > 0
+
+
 def test_sharded_init_statistics_match_global_init(oracle):
     """AEROBULK_INIT on a grid sharded over ranks (SURVEY §8e "the one true exchange"): per-shard ab_session_init_stats,
     SUM/MIN/MAX combination (what an all-reduce does), ab_session_init_apply -> same report as one global init."""

@@ -195,7 +195,7 @@ int main(int argc, char **argv)
     const Heights<double> hd = make_heights<double>(zt, zu);
     Heights<CD> h;
     h.zt = hd.zt; h.zu = hd.zu; h.log_zt = hd.log_zt; h.log_zu = hd.log_zu; h.log_10 = hd.log_10; h.log_ztu = hd.log_ztu;
-    h.log_zu10 = hd.log_zu10; h.fg_ca = hd.fg_ca; h.inv_zu = hd.inv_zu; h.zt_o_zu = hd.zt_o_zu; h.zt_eq_zu = hd.zt_eq_zu;
+    h.log_zu10 = hd.log_zu10; h.fg_ca = hd.fg_ca; h.inv_zu = hd.inv_zu; h.zt_o_zu = hd.zt_o_zu; h.zt_eq_zu = hd.zt_eq_zu; h.fg_cb = hd.fg_cb;
     double sum_ql = 0.;
     const long n = ni * nj;
     for (long j = 1; j <= nj; ++j)

@@ -393,6 +393,7 @@ def cmd_report(a):
     by_class, by_op, by_region, by_leaf, by_path = (collections.Counter() for _ in range(5))
     slots_class, lanes_class = collections.Counter(), collections.Counter()
     region_class = collections.defaultdict(collections.Counter)
+    by_line, line_class, line_fn = collections.Counter(), collections.defaultdict(collections.Counter), {}
     tot_valu = tot_salu = tot_lds = tot_vmem = tot_smem = tot_other = 0
     exec0_valu, exec0_blocks = 0, []
     for b, ins in enumerate(blocks):
@@ -415,6 +416,12 @@ def cmd_report(a):
                 region_class[r][c] += w
                 by_leaf[leaf_of(fr)] += w
                 by_path[second_region(fr)] += w
+                # the source line of the OUTERMOST physics frame below the math leaves: where in ab_physics.hpp the instruction was asked for
+                phys = [(f_, l_, fn) for f_, l_, fn in fr if fn and fn not in LEAF_MATH and fn not in CONTAINERS and l_]
+                key = (phys[0][0], phys[0][1]) if phys else (fr[0][0], fr[0][1])
+                by_line[key] += w
+                line_class[key][c] += w
+                line_fn[key] = phys[0][2] if phys else leaf_of(fr)
                 tot_valu += w
             elif op.startswith("s_") and not op.startswith(("s_load", "s_buffer", "s_waitcnt", "s_nop", "s_barrier", "s_store", "s_atomic", "s_dcache")):
                 tot_salu += w
@@ -475,6 +482,12 @@ def cmd_report(a):
                 rows.append((w, r, c))
     for w, r, c in sorted(rows, reverse=True):
         p(f"   {r:28s} {c:52s} {w * per:8.1f}")
+    p("")
+    p("== by source line of the innermost physics function (instructions per cell; of which not fp64 arithmetic; the classes above 2 per cell)")
+    for key, w in by_line.most_common(70):
+        other = sum(v for c, v in line_class[key].items() if c not in fp64)
+        det = ", ".join(f"{c.split(' (')[0]} {v * per:.0f}" for c, v in line_class[key].most_common() if c not in fp64 and v * per >= 2.0)
+        p(f"   {key[0]}:{key[1]:<5d} {line_fn[key]:22s} {w * per:7.1f}   non-fp64 {other * per:6.1f}   {det}")
     txt = "\n".join(L) + "\n"
     if a.out:
         open(a.out, "w").write(txt)
