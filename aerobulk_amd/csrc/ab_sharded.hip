@@ -540,7 +540,12 @@ int sharded_gather(ab_session *s, int root, const ab_shard_arrays *sh, const ab_
         }
         const int rc2 = R.GroupEnd();
         if (rc == 0) rc = rc2;
-        if (rc != 0) return sfail(AB_ERR_HIP, "ab_session_gather: RCCL: %s", R.GetErrorString ? R.GetErrorString(rc) : "error");
+        if (rc != 0) {
+            // the device-to-device copies of the local shards are already enqueued into dst: drain them, so that the caller does not
+            // reuse or free the destination while they are in flight (round-3 advisory)
+            if (hipSetDevice(root_dev) == hipSuccess) (void)hipStreamSynchronize(root_st);
+            return sfail(AB_ERR_HIP, "ab_session_gather: RCCL: %s (dst holds the rows of the root's own device only)", R.GetErrorString ? R.GetErrorString(rc) : "error");
+        }
     }
     if (synchronize) {
         if (hipSetDevice(root_dev) != hipSuccess || hipStreamSynchronize(root_st) != hipSuccess)

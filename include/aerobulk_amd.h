@@ -158,7 +158,11 @@ int ab_session_check(ab_session *s);
  * ordered behind the work already enqueued on its shard's stream (the compute that produced the fluxes), and the receives are
  * enqueued on the root shard's stream: asynchronous unless `synchronize` != 0.  librccl.so is loaded on first use (dlopen);
  * a session whose shards all live on one device never touches it.
- * Measured on one GPU only (k shards on one device, 1-device communicator): no multi-device run has happened yet. */
+ * STATUS: the multi-device leg (ncclCommInitAll over distinct devices, ncclSend on the shard's stream / ncclRecv on the root's in one
+ * group) is EXPERIMENTAL: this pool has one GPU per box, so it has only ever run as k shards on one device through a one-device
+ * communicator (tests/test_gpu_sharded.py, `python bench.py --gpus N --devices 0,0,...`); no run on two devices has happened
+ * (INTEGRATION.md).  With streams == NULL the transfers use each device's NULL stream.  On an RCCL error the call drains the root's
+ * stream before it returns AB_ERR_HIP: dst then holds the rows of the shards on the root's device only. */
 typedef struct ab_shard_arrays {
     const void *sst, *t_zt, *hum_zt, *u_zu, *v_zu, *slp, *rad_sw, *rad_lw;   /* inputs: the shard's rows, on the shard's device */
     void *ql, *qh, *tau_x, *tau_y, *evap, *t_s;                               /* outputs (evap, t_s may be NULL) */

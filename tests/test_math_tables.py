@@ -203,3 +203,40 @@ def test_table_positions_stay_inside_their_tables_at_the_last_admissible_argumen
     assert last64(csg_max, n_csg, csg_max, n_csg)        # cool skin g(u), LDS
     assert last64(8., 64, 8., 64)                        # ... L1
     assert last32(6.6875, 32, 6.6875, 32) and last32(7.4453125, 32, 7.4453125, 32)   # fp32 tables
+
+
+def test_warm_layer_absorption_table_indexed_by_the_bits_of_the_depth():
+    """kGWlAbs (ab_gtables.hpp): WL_COARE's absorbed fraction of the solar flux (mod_skin_coare.f90:167-168, 205-207) against its closed
+    form in 40-digit arithmetic, with the index and the local variable formed exactly as wl_absorb() forms them from the bits of H:
+    every depth the scheme can produce (H clamped to [0.1, 20]) lands inside the table, on the right interval, within 1e-15."""
+    import struct
+    mp.mp.dps = 40
+    gt = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_gtables.hpp")).read()
+    assert "constexpr int kGWlAbsN = 144, kGWlAbsE0 = -4;" in gt
+    m = re.search(r"AB_TAB double kGWlAbs\[1152\] = \{(.*?)\};", gt, re.S)
+    tab = np.array([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()]).reshape(144, 8)
+
+    def closed(H):
+        H = mp.mpf(H)
+        c = [mp.mpf(0.28 * 0.014), mp.mpf(0.27 * 0.357), mp.mpf(0.45 * 12.82)]
+        a = [mp.mpf(0.014), mp.mpf(0.357), mp.mpf(12.82)]
+        return 1 - sum(ci * (-mp.expm1(-H / ai)) for ci, ai in zip(c, a)) / H
+
+    rng = np.random.default_rng(5)
+    hs = np.concatenate([[0.1, np.nextafter(0.1, 1), 20.0, np.nextafter(20.0, 0), 0.125, 1.0, 16.0, np.nextafter(16.0, 0)],
+                         np.exp(rng.uniform(np.log(0.1), np.log(20.0), 400))])
+    worst = 0.0
+    for H in hs:
+        hi = struct.unpack("<q", struct.pack("<d", H))[0] >> 32
+        lo = struct.unpack("<Q", struct.pack("<d", H))[0] & 0xFFFFFFFF
+        idx = (hi >> 16) - ((1023 - 4) << 4)
+        assert 0 <= idx < 144, (H, idx)
+        v = struct.unpack("<d", struct.pack("<Q", (((hi & 0xFFFF) | 0x3FF00000) << 32) | lo))[0]
+        u = v * 32.0 - 33.0
+        assert -1.0 <= u < 1.0
+        p = 0.0
+        for c in tab[idx][::-1]:
+            p = p * u + c
+        ref = closed(H)
+        worst = max(worst, float(abs(mp.mpf(p) - ref) / abs(ref)))
+    assert worst < 1e-15, worst

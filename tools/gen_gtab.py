@@ -15,6 +15,11 @@ LDS has no room for live in global memory:
                     the convective arguments pi: intervals of 1/16 put the degree-7 interpolation error at the rounding of the
                     coefficients; the LDS of a block has no room for 2 x 6.7 KB, the L1 does.)
   kGPsikM / H       Kansas / Paulson psi_m and psi_h in s = LOG(|1 - 16 zeta|) (ECMWF, NCAR, ANDREAS), 28 intervals on [0, 6.6875)
+  kGWlAbs           WL_COARE's absorbed fraction 1 - sum_i c_i a_i (1 - exp(-H/a_i))/H of the solar flux in a warm layer of depth H
+                    (mod_skin_coare.f90:167-168, 205-207; three exponentials and a division, up to ten times per cell), on 0.0625 <= H < 32
+                    (the scheme clamps H to [0.1, 20]).  Indexed by the BITS of H: interval = exponent and the top four mantissa bits
+                    (16 intervals per binade, 9 binades: 144 intervals), local variable from the remaining mantissa bits — no logarithm,
+                    no floor: a shift, a subtraction, a mask and one FMA.  4.3e-16 relative.
   kGCsG             the cool skin's absorption profile g(u) = (1 - exp(-u))/u, u = delta/8e-4 (mod_phymbl.f90:2030-2044 via
                     CS_COARE / CS_ECMWF: zfr = c0 + 11 delta - 6.6e-5/delta (1 - exp(-delta/8e-4))), 64 intervals of 1/8 on [0, 8)
 
@@ -77,6 +82,14 @@ def g_cs(u):
     if u == 0:
         return mp.mpf(1)
     return -mp.expm1(-u) / u
+
+
+def wl_abs(H):
+    """absorbed fraction of the solar flux in a warm layer of depth H (WL_COARE, mod_skin_coare.f90:167-168, 205-207), the products of
+    the literals taken as the doubles the kernel's closed form uses"""
+    a1, a2, a3 = D(0.014), D(0.357), D(12.82)
+    c1, c2, c3 = D(0.28 * 0.014), D(0.27 * 0.357), D(0.45 * 12.82)
+    return 1 - (c1 * (-mp.expm1(-H / a1)) + c2 * (-mp.expm1(-H / a2)) + c3 * (-mp.expm1(-H / a3))) / H
 
 
 def local_fit(f, a, b):
@@ -174,6 +187,24 @@ def main():
     for j in range(0, len(flat), 4):
         out.append("    " + ", ".join(repr(v) for v in flat[j:j + 4]) + ("," if j + 4 < len(flat) else "};"))
     DEG = 7
+    # WL_COARE's absorbed fraction, indexed by the bits of H (16 intervals per binade over 2^-4 <= H < 2^5)
+    rows, worst = [], mp.mpf(0)
+    for e in range(-4, 5):
+        for k in range(16):
+            a, b = mp.mpf(2) ** e * (1 + mp.mpf(k) / 16), mp.mpf(2) ** e * (1 + mp.mpf(k + 1) / 16)
+            c = local_fit(wl_abs, a, b)
+            rows.append(c)
+            if b > mp.mpf("0.1") and a < 20:
+                for j in range(33):
+                    u = mp.mpf(-1) + mp.mpf(2) * j / 32
+                    pp = mp.mpf(0)
+                    for cc in reversed(c):
+                        pp = pp * u + mp.mpf(cc)
+                    x = (a + b) / 2 + (b - a) / 2 * u
+                    worst = max(worst, abs(pp - wl_abs(x)) / abs(wl_abs(x)))
+    print("kGWlAbs", float(worst), file=sys.stderr)
+    out.append("constexpr int kGWlAbsN = 144, kGWlAbsE0 = -4;    // intervals; exponent of the first binade")
+    emit(out, "kGWlAbs", rows, float(worst), "WL_COARE absorbed fraction of the solar flux vs layer depth H, 16 intervals per binade on [2^-4, 2^5), relative error on [0.1, 20]")
     out.append("}  // namespace ab")
     print("\n".join(out))
 

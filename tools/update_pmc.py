@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turn a tools/prof_quick.sh run (gpurun_out/prof_<tag>/) into the committed artefacts:
-    profiles/<name>_flux_kernel.txt  (rocpd summaries of the 5 passes)   and   profiles/r3_pmc.json (what bench.py quotes,
+    profiles/<name>_flux_kernel.txt  (rocpd summaries of the 5 passes)   and   profiles/r4_pmc.json (what bench.py quotes,
 stamped with the hash of the kernel sources + flags it was taken with: bench.py only quotes it for that very device code).
 
     python tools/update_pmc.py gpurun_out/prof_<tag> <name>
@@ -44,7 +44,7 @@ def main():
         "fp64_insts_per_launch": {k: val(f"SQ_INSTS_VALU_{k.upper()}_F64") for k in ("fma", "mul", "add", "trans")},
         "waves_per_launch": val("SQ_WAVES"),
     }
-    json.dump(pmc, open(os.path.join(ROOT, "profiles", "r3_pmc.json"), "w"), indent=1)
+    json.dump(pmc, open(os.path.join(ROOT, "profiles", "r4_pmc.json"), "w"), indent=1)
     print(out)
     print(json.dumps(pmc, indent=1))
 
