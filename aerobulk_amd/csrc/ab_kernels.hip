@@ -226,10 +226,17 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     }
     if (tid == 0) s_next = 0;
     tile_sort_reset(s_cnt, tid);
-    // (before the barrier of math_tables_init) fp64: COARE reads its psi tables through L1 (ab_gtables.hpp); ECMWF / ANDREAS keep the
-    // Kansas psi_m table in LDS; the e_sat table with the skin schemes
+    // (before the barrier of math_tables_init) fp64: COARE + skin reads its psi tables through L1 (ab_gtables.hpp: indexed by the bits of
+    // their argument, no logarithm); COARE without the skin schemes, ECMWF and ANDREAS keep theirs in LDS; the e_sat table with the skin schemes
     if constexpr (sizeof(R) == 8) {
-        if constexpr (ALGO == 1 || ALGO == 2) { if (SKIN) { esat_table_fill(); csg_table_fill(); psi_coare_lds_fill<false>(); } else psi_coare_lds_fill(); }
+        if constexpr (ALGO == 1 || ALGO == 2) {
+            if (SKIN) {
+                esat_table_fill(); csg_table_fill();
+#ifdef AB_PSI_NOBITS
+                psi_coare_lds_fill<false>();
+#endif
+            } else psi_coare_lds_fill();
+        }
         else { psi_tables_fill<SKIN>(); if constexpr (ALGO == 5) andreas_stab_fill(); }
     }
     else psi_tables_fill32();                             // (before the barrier below)

@@ -89,7 +89,12 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFl
     // the Kansas psi_m / psi_h pair (2 x 1 792 B: ECMWF, ANDREAS; ANDREAS + 800 B: its stable psi_m) or, COARE: with the skin schemes the cool skin's g(u) (1 280 B) and the
     // blended psi_h (2 560 B; psi_m through L1, ab_gtables.hpp), without them psi_m and psi_h (2 x 2 560 B); fp32: the three psi tables
     // (1 536 B; + e_sat: mixed).  The fp64 COARE kernels with the skin schemes come out at exactly two rounds with 24 B to spare.
-    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? 3840 : 5120) : (ALGO == 5 ? 4384 : 3584)) : (MIXED ? 3072 : 1536));
+#ifdef AB_PSI_NOBITS
+#define AB_COARE_SKIN_TAB_BYTES 3840   // g(u) 1 280 B + the blended psi_h 2 560 B (round 3)
+#else
+#define AB_COARE_SKIN_TAB_BYTES 1280   // g(u); psi_m and psi_h through L1, indexed by the bits of their argument (round 4)
+#endif
+    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? AB_COARE_SKIN_TAB_BYTES : 5120) : (ALGO == 5 ? 4384 : 3584)) : (MIXED ? 3072 : 1536));
     static constexpr int kBudget = 160 * 1024 / kWaves - 160 - ((sizeof(R) == 8 || MIXED) ? 1632 : 0) - kPsiTabBytes;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 2)); // f64: 2 (skin, 4 blocks) / 2 (5 blocks); f32: 2
     static constexpr int kCells = kRounds * kBlock;

@@ -240,3 +240,36 @@ def test_warm_layer_absorption_table_indexed_by_the_bits_of_the_depth():
         ref = closed(H)
         worst = max(worst, float(abs(mp.mpf(p) - ref) / abs(ref)))
     assert worst < 1e-15, worst
+
+
+def test_coare_psi_tables_indexed_by_the_bits_of_their_argument():
+    """kGPsiCoareBM / BH (ab_gtables.hpp): COARE's blended unstable psi_m / psi_h as functions of y = |1 - 15 zeta|, the interval taken from
+    the exponent and the top four mantissa bits of y exactly as psi_coare<kPsiBits> takes it: against the reference's formulas
+    (mod_common_coare.f90:235-252, :326-342, tools/gen_gtab.py) in 40-digit arithmetic, every zeta the iteration can produce."""
+    import struct
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_gtab
+    mp.mp.dps = 40
+    gt = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_gtables.hpp")).read()
+    assert "constexpr int kGPsiCoareBN = 160;" in gt
+    rng = np.random.default_rng(11)
+    zetas = -np.concatenate([[0.0, 1e-12, 1e-6, 50.0, 49.999, 1.0 / 15.0, 2.0 / 15.0], 10.0 ** rng.uniform(-8, np.log10(50.0), 300)])
+    for which, name in (("m", "kGPsiCoareBM"), ("h", "kGPsiCoareBH")):
+        m = re.search(rf"AB_TAB double {name}\[1280\] = \{{(.*?)\}};", gt, re.S)
+        tab = np.array([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()]).reshape(160, 8)
+        f = gen_gtab.coare(which)
+        worst = 0.0
+        for z in zetas:
+            y = abs(1.0 - 15.0 * z)
+            bits = struct.unpack("<Q", struct.pack("<d", y))[0]
+            hi, lo = bits >> 32, bits & 0xFFFFFFFF
+            idx = (hi >> 16) - (1023 << 4)
+            assert 0 <= idx < 160, (z, idx)
+            v = struct.unpack("<d", struct.pack("<Q", (((hi & 0xFFFF) | 0x3FF00000) << 32) | lo))[0]
+            u = v * 32.0 - 33.0
+            p = 0.0
+            for c in tab[idx][::-1]:
+                p = p * u + c
+            worst = max(worst, float(abs(mp.mpf(p) - f(mp.log(mp.mpf(y))))))
+        assert worst < 2e-15, (which, worst)      # values up to 6.6

@@ -15,6 +15,10 @@ LDS has no room for live in global memory:
                     the convective arguments pi: intervals of 1/16 put the degree-7 interpolation error at the rounding of the
                     coefficients; the LDS of a block has no room for 2 x 6.7 KB, the L1 does.)
   kGPsikM / H       Kansas / Paulson psi_m and psi_h in s = LOG(|1 - 16 zeta|) (ECMWF, NCAR, ANDREAS), 28 intervals on [0, 6.6875)
+  kGPsiCoareBM / BH the same blended psi_m / psi_h of COARE as functions of y = |1 - 15 zeta| itself, 1 <= y < 1024 (zeta > -68), indexed by the
+                    BITS of y like kGWlAbs below: 16 intervals per binade, 10 binades = 160 intervals, degree 7 — the logarithm that the
+                    tables in s need (one per evaluation, eleven per unstable cell of the headline kernel: ~20 issue slots each) is gone.
+                    For the kernels with the skin schemes (both through L1; their LDS has no room for tables this long).
   kGWlAbs           WL_COARE's absorbed fraction 1 - sum_i c_i a_i (1 - exp(-H/a_i))/H of the solar flux in a warm layer of depth H
                     (mod_skin_coare.f90:167-168, 205-207; three exponentials and a division, up to ten times per cell), on 0.0625 <= H < 32
                     (the scheme clamps H to [0.1, 20]).  Indexed by the BITS of H: interval = exponent and the top four mantissa bits
@@ -187,6 +191,25 @@ def main():
     for j in range(0, len(flat), 4):
         out.append("    " + ", ".join(repr(v) for v in flat[j:j + 4]) + ("," if j + 4 < len(flat) else "};"))
     DEG = 7
+    # COARE's blended psi_m / psi_h indexed by the bits of y = |1 - 15 zeta| (16 intervals per binade over 1 <= y < 2^10)
+    out.append("constexpr int kGPsiCoareBN = 160;    // intervals: exponent and top four mantissa bits of y")
+    for which, name in (("m", "kGPsiCoareBM"), ("h", "kGPsiCoareBH")):
+        fs = coare(which)
+        fy = lambda y, fs=fs: fs(mp.log(y))
+        rows, worst = [], mp.mpf(0)
+        for e in range(0, 10):
+            for k in range(16):
+                a, b = mp.mpf(2) ** e * (1 + mp.mpf(k) / 16), mp.mpf(2) ** e * (1 + mp.mpf(k + 1) / 16)
+                c = local_fit(fy, a, b)
+                rows.append(c)
+                for j in range(17):
+                    u = mp.mpf(-1) + mp.mpf(2) * j / 16
+                    pp = mp.mpf(0)
+                    for cc in reversed(c):
+                        pp = pp * u + mp.mpf(cc)
+                    worst = max(worst, abs(pp - fy((a + b) / 2 + (b - a) / 2 * u)))
+        print(name, float(worst), file=sys.stderr)
+        emit(out, name, rows, float(worst), f"COARE unstable psi_{which} (Kansas / convective blend) vs y = |1 - 15 zeta|, 16 intervals per binade on [1, 1024)")
     # WL_COARE's absorbed fraction, indexed by the bits of H (16 intervals per binade over 2^-4 <= H < 2^5)
     rows, worst = [], mp.mpf(0)
     for e in range(-4, 5):
