@@ -92,7 +92,7 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFl
 #ifdef AB_PSI_NOBITS
 #define AB_COARE_SKIN_TAB_BYTES 3840   // g(u) 1 280 B + the blended psi_h 2 560 B (round 3)
 #else
-#define AB_COARE_SKIN_TAB_BYTES 1280   // g(u); psi_m and psi_h through L1, indexed by the bits of their argument (round 4)
+#define AB_COARE_SKIN_TAB_BYTES 3584   // the cool skin's T(u) table (degree 7 x 56 intervals); psi_m and psi_h through L1, indexed by the bits of their argument (round 4)
 #endif
     static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? AB_COARE_SKIN_TAB_BYTES : 5120) : (ALGO == 5 ? 4384 : 3584)) : (MIXED ? 3072 : 1536));
     static constexpr int kBudget = 160 * 1024 / kWaves - 160 - ((sizeof(R) == 8 || MIXED) ? 1632 : 0) - kPsiTabBytes;

@@ -15,7 +15,7 @@ AB_F32 (fp32 arithmetic throughout): does NOT meet it (p99 2e-4, p99.99 1e-3); i
 import numpy as np
 import pytest
 
-from conftest import oracle_on_cells
+from conftest import _log, oracle_on_cells
 
 pytestmark = pytest.mark.gpu
 IN8 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")
@@ -119,20 +119,32 @@ def test_orca36_fp32_sessions_against_the_oracle_on_a_subsample():
     import torch
     import aerobulk_amd as ab
     from oracle import pyoracle as po
+    import time
+    t0 = time.time()
+
+    def stage(what):      # (this test took 5 s on most leases and 665 s on one: the run log says where)
+        torch.cuda.synchronize()
+        _log(f"[ab-test]   orca36 stage: {what}  t+{time.time() - t0:.1f}s")
+
     ni, nj, stride = 12960, 10800, 31
     names = ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp", "rad_sw", "rad_lw")
     f = ab.synth_fields_device(ni, nj, precision="f32")
+    stage("fields generated on the device")
     sub = {k.lower(): f[k][::stride].cpu().numpy().astype(np.float64) for k in names}
     assert sub["sst"].size >= 4_000_000
+    stage("subsample on the host")
     ref = oracle_parallel("ecmwf", True, 5, sub)[0]
+    stage("oracle on the subsample")
     del po
     full = {}
     for prec in ("f32_mixed", "f32_storage", "f32"):
         with ab.Session("ecmwf", ni, nj, 1, True, precision=prec) as s:
             got = s.compute(1, 2.0, 10.0, *[f[k] for k in names[:6]], Niter=5, rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
+        stage(f"{prec}: computed")
         for k in got:
             assert bool(torch.isfinite(got[k]).all()), (prec, k)
         g = {k: v[::stride].cpu().numpy() for k, v in got.items()}
+        stage(f"{prec}: finite, subsample on the host")
         if prec == "f32_mixed":
             check_restated(g, ref, "ORCA36 subsample f32_mixed", p99=3e-6)
             full = got
@@ -147,9 +159,11 @@ def test_orca36_fp32_sessions_against_the_oracle_on_a_subsample():
         if prec != "f32_mixed":
             del got
     # a j-block computed alone (what one of 8 ranks owns) is bit-identical to the same rows of the full launch
+    stage("three modes checked")
     j0, njl = 4050, 1350
     fs = ab.synth_fields_device(ni, nj, j0, njl, precision="f32")
     with ab.Session("ecmwf", ni, njl, 1, True, precision="f32_mixed") as s:
         part = s.compute(1, 2.0, 10.0, *[fs[k] for k in names[:6]], Niter=5, rad_sw=fs["rad_sw"], rad_lw=fs["rad_lw"])
     for k in full:
         assert torch.equal(full[k][j0 * ni:(j0 + njl) * ni], part[k]), k
+    stage("j-block invariance")

@@ -200,7 +200,7 @@ def test_table_positions_stay_inside_their_tables_at_the_last_admissible_argumen
     assert last64(6.6875, 107, 6.6875, 107)              # ... and through L1
     assert last64(np.nextafter(6.68586094706836, 7), 28, 6.6875, 28)   # Kansas pair (<= bound: the bound itself is admissible)
     assert last64(7.4453125, 28, 7.4453125, 28)          # convective psi (math_test_kernel)
-    assert last64(csg_max, n_csg, csg_max, n_csg)        # cool skin g(u), LDS
+    assert (n_csg, csg_max) == (56, 7.0) and last64(csg_max, n_csg, csg_max, n_csg)        # cool skin T(u) = 8.8e-3 u - 0.0825 g(u), LDS
     assert last64(8., 64, 8., 64)                        # ... L1
     assert last32(6.6875, 32, 6.6875, 32) and last32(7.4453125, 32, 7.4453125, 32)   # fp32 tables
 

@@ -149,21 +149,24 @@ def main():
     rows, err = table(g_cs, mp.mpf(0), mp.mpf(8), 64)
     emit(out, "kGCsG", rows, err, "cool-skin absorption profile g(u) = (1 - exp(-u))/u")
     print("kGCsG", err, file=sys.stderr)
-    # the same function for LDS (tiled COARE + skin kernels: twenty evaluations per cell inside the cool skin's fixed-point chain, where
-    # the L1 round trip of the interval-major table showed): coefficient-major like the other LDS tables.  g is entire: degree 9 on 16
-    # intervals of [0, 8) is at the rounding of the coefficients (7e-17) in 1 280 B, where degree 7 needed 56 intervals (3.5 KB) — the
-    # room psi_h takes in these kernels (below)
+    # For LDS (tiled COARE + skin kernels: twenty evaluations per cell inside the cool skin's fixed-point chain, where the L1 round trip of
+    # the interval-major table showed): not g itself but what the chain wants from it, the part of the absorbed fraction that depends on
+    # the layer alone,  T(u) = 11 * 8e-4 u - (6.6e-5 / 8e-4) g(u),  zfr = MAX(c0 + T(delta / 8e-4), 0.01)  (CS_COARE mod_skin_coare.f90:85,
+    # delta_skin_layer / the absorption profile of Fairall et al. 1996): a product, an FMA and a subtraction less per evaluation than
+    # c0 + 11 delta - 0.0825 g.  Degree 7 on 56 intervals of [0, 7) (3 584 B, coefficient-major; the room the blended psi_h took until
+    # round 4, when COARE's psi tables went to L1 with bit indexing): two FMAs less per evaluation than the degree-9 table on 16 intervals.
+    def t_cs(u):
+        return D(11.) * D(8.E-4) * u - (D(6.6E-5) / D(8.E-4)) * g_cs(u)
+    rows, err = table(t_cs, mp.mpf(0), mp.mpf(7), 56)
+    print("kCsTTab", err, file=sys.stderr)
+    out.append(f"// T(u) = 8.8e-3 u - 0.0825 g(u) for LDS, degree 7, coefficient-major [k * 56 + i], 56 intervals on [0, 7): max |table - function| = {err:.2e}")
+    out.append("constexpr int kCsGTabN = 56, kCsGTabDeg = 7;")
+    out.append("constexpr double kCsGTabMax = 7.;")
+    out.append("AB_TAB double kCsGTab[448] = {")
+    flat = [rows[i][k] for k in range(8) for i in range(56)]
+    for jj in range(0, len(flat), 4):
+        out.append("    " + ", ".join(repr(v) for v in flat[jj:jj + 4]) + ("," if jj + 4 < len(flat) else "};"))
     global DEG
-    DEG = 9
-    rows, err = table(g_cs, mp.mpf(0), mp.mpf(8), 16)
-    DEG = 7
-    out.append(f"// g(u) for LDS, degree 9, coefficient-major [k * 16 + i], 16 intervals on [0, 8): max |table - function| = {err:.2e}")
-    out.append("constexpr int kCsGTabN = 16, kCsGTabDeg = 9;")
-    out.append("constexpr double kCsGTabMax = 8.;")
-    out.append("AB_TAB double kCsGTab[160] = {")
-    flat = [rows[i][k] for k in range(10) for i in range(16)]
-    for j in range(0, len(flat), 4):
-        out.append("    " + ", ".join(repr(v) for v in flat[j:j + 4]) + ("," if j + 4 < len(flat) else "};"))
     # COARE's blended psi_m / psi_h once more, for LDS: the flux kernels WITHOUT the skin schemes have 5.4 KB of LDS left at five blocks
     # per CU, and their iteration is short enough that three table lookups through L1 (twelve 1 KB gathers per wave and iteration) keep the
     # texture addresser 72 % busy and the VALU waiting (77 % busy).  Degree 9 on 32 intervals of [0, 6.6875): 2 x 2 560 B, the error at
