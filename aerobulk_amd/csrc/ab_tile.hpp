@@ -132,6 +132,7 @@ __device__ __forceinline__ int forecast_bucket(float sst, float theta, float q, 
             const F qabs = fabs * qsw + qns;
             wbin = qabs < -40.f ? 0 : (qabs < 0.f ? 1 : (qabs < 40.f ? 2 : 3));
             if (wl_load && M::abs(dTprev) >= 1.e-6f && wbin < 2) wbin = 2;
+#ifndef AB_BUCKET_NOSHIFT
             if (qabs > 0.f) {      // the warming of this record shifts the stability: estimate of mod_skin_coare.f90:199-224
                 const F alpha = alpha_sw<F>(sst);
                 const F tac = vmax(1.44e-3f * Ub * wnd, 0.002f) * 3600.f;
@@ -141,6 +142,7 @@ __device__ __forceinline__ int forecast_bucket(float sst, float theta, float q, 
                 if (hz < 1.f) dT *= M::rcp(hz);
                 dthv -= dT * (1.f + 11.5f * qs);
             }
+#endif
         }
     }
     const int sbin = dthv < -0.3f ? 0 : (dthv < 0.f ? 1 : (dthv < 0.3f ? 2 : 3));
