@@ -29,7 +29,9 @@ template <class R, class S = R> struct FluxArgs {
     int nb_iter, hum_type, wl_load, wl_store, isecday, dawn_uniform;
     int regroup;  // sort the tile's cells into like-behaved waves (see flux_kernel)
     int rounds;   // tile = rounds*256 cells (<= Tile<R,ALGO,SKIN>::kRounds)
-    long nfull;   // blocks [0, nfull) own tiles of `rounds` rounds; the blocks behind them, dispatched last, one round each (launch_t)
+    long nfull;   // tiles [0, nfull) have `rounds` rounds; the ntail tiles behind them, handed out last, one round each (launch_t)
+    long ntail;
+    int *queue;   // flux_kernel_cu: three tile counters in device memory (zero between launches)
 };
 
 // optional per-cell diagnostics of TURB_* (ab_session_set_diagnostics); read only by the DIAG instantiations
@@ -62,7 +64,7 @@ template <class T> __device__ __forceinline__ void stnt(T *p, T v) { *p = v; }
 // One cell from its pre-processed inputs to the six outputs of aerobulk_compute: TURB_<algo> (mod_aerobulk_compute.f90
 // :129-176), BULK_FORMULA and the stress vector (:184-194).  k: global cell index (warm-layer state, diagnostics, longitude).
 // A: anchor type of SST, theta, q (ab_physics.hpp, "ANCHORS"): R, or double with R = float in the mixed mode.
-template <class R, int ALGO, bool SKIN, bool DIAG, bool TILED = false, class S = R, class A = R>
+template <class R, int ALGO, bool SKIN, bool DIAG, bool TILED = false, class S = R, class A = R, int LTABS = 1>
 __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const DiagArgs<S> &dg, const Heights<R> &hh, int nb_iter, long k, A sst,
                                              A theta_zt, A q_zt, R uu, R vv, R slp, R qsw, R rlw, R &QL, R &QH, R &tx, R &ty,
                                              R &zEvap, A &T_s, lds_cvptr<R> pu = nullptr, lds_cvptr<R> pv = nullptr,
@@ -96,7 +98,7 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
 
     CellOut<R, A> o;
     constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
-    constexpr bool kCsgLds = TILED && sizeof(R) == 8;              // flux_kernel filled COARE's LDS extras (g(u) with the skin schemes, the psi tables without)
+    constexpr int kCsgLds = (TILED && sizeof(R) == 8) ? LTABS : 0;   // flux_kernel filled COARE's LDS extras (the cool skin's table with the skin schemes, the psi tables without); 2: flux_kernel_cu's CU-wide psi and WL tables too
     if (ALGO == 1) turb_coare<R, false, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
     else if (ALGO == 3) turb_ncar<R, DIAG, A, (sizeof(R) == 8 && kPsiTabDefault)>(hh, in, nb_iter, o);   // flux_kernel's direct path filled the pair of psi tables
@@ -349,6 +351,209 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
 #undef AB_DIAGS
 }
 
+// ---- one workgroup per CU -----------------------------------------------------------------------------------------------------------
+// flux_kernel above runs four independent 256-thread blocks per CU, each with its own copy of every LDS table: 4 x 6.7 KB of the CU's
+// 160 KB hold the same numbers four times, and the long tables (COARE's psi_m / psi_h, WL_COARE's absorbed fraction: 19 KB) have to be
+// read through the L1 — whose texture addresser became the kernel's limiter once they had replaced the arithmetic (round 4: doubling the
+// table loads costs +33 %, profiles/r4_notes.md).  flux_kernel_cu is ONE workgroup of sixteen waves per CU: the tables exist once (23 KB,
+// the long ones included: nothing goes through the texture addresser but the fields), and the workgroup is four TEAMS of four waves
+// (one per SIMD) that each do what a block of flux_kernel does — own tile, own sort, own group queue — on tiles handed out by a queue in
+// device memory, for the whole launch (persistent).  A team synchronises with a barrier of its own (an LDS counter: s_barrier is
+// workgroup-wide and would put the four teams in step, which costs 20 %, ibid.); the odd teams take a one-round tile first so that the
+// teams of a CU are out of phase from the start.
+constexpr int kCuTeams = 4, kCuBlock = kCuTeams * kBlock;
+struct TeamSync {
+    unsigned *bar;        // LDS counter of the team
+    unsigned *target;     // this wave's count of the arrivals it has to see (registers)
+    __device__ __forceinline__ void operator()() const
+    {
+        *target += kBlock / 64;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's LDS writes are done before its arrival shows
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (;;) {
+            unsigned seen = __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+            if ((int)(seen - *target) >= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+template <class R, int ALGO, bool SKIN, class S = R>
+__global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, S> a_in, const DiagArgs<S> dg_in)
+{
+    static_assert(sizeof(R) == 8 && (ALGO == 1 || ALGO == 2) && SKIN, "the CU-wide kernel serves the fp64 COARE kernels with the skin schemes");
+    using A = R;
+    constexpr unsigned kDgOff = (unsigned)((sizeof(FluxArgs<R, S>) + 7) & ~(size_t)7);
+#define AB_ARGS const FluxArgs<R, S> &a = kernarg_at<FluxArgs<R, S>>(0)
+#define AB_DIAGS const DiagArgs<S> &dg = kernarg_at<DiagArgs<S>>(kDgOff)
+    using T = Tile<R, ALGO, SKIN, false>;
+    constexpr int kCells = 2 * kBlock;                      // two-round tiles, as in flux_kernel
+    __shared__ R s_fa[kCuTeams][T::kFields][kCells];
+    __shared__ unsigned short s_inva[kCuTeams][kCells];
+    __shared__ unsigned s_cnta[kCuTeams][kSortCounters], s_basea[kCuTeams][kSortCounters];
+    __shared__ int s_nexta[kCuTeams];
+    __shared__ long s_tilea[kCuTeams];
+    __shared__ unsigned s_bara[kCuTeams];
+    const int team = (int)threadIdx.x / kBlock;
+    const int tid0 = (int)threadIdx.x % kBlock;
+    R (*s_f)[kCells] = s_fa[team];
+    unsigned short *s_inv = s_inva[team];
+    unsigned *s_cnt = s_cnta[team], *s_base = s_basea[team];
+    int *s_next = &s_nexta[team];
+    long *s_tile = &s_tilea[team];
+    unsigned arrivals = 0;
+    const TeamSync sync{&s_bara[team], &arrivals};
+    struct Raw { R sst, t_zt, hum, uu, vv, slp, rsw, rlw; };
+    auto tile_of = [](const FluxArgs<R, S> &a, long t, long &t0, int &rr) {
+        rr = a.rounds;
+        t0 = t * ((long)rr * kBlock);
+        if (t >= a.nfull) { t0 = a.nfull * ((long)rr * kBlock) + (t - a.nfull) * kBlock; rr = 1; }
+    };
+    auto fetch = [](const FluxArgs<R, S> &a, int tid, long tile0, int rounds, int r) -> Raw {
+        Raw w{R(290.), R(290.), R(0.01), R(1.), R(1.), R(101000.), R(0.), R(0.)};
+        const long k = tile0 + r * kBlock + tid;
+        if (r < rounds && k < a.n) {
+            w.sst = (R)ldnt(a.sst + k); w.t_zt = (R)ldnt(a.t_zt + k); w.hum = (R)ldnt(a.hum + k); w.uu = (R)ldnt(a.u + k); w.vv = (R)ldnt(a.v + k);
+            w.slp = (R)ldnt(a.slp + k);
+            w.rsw = (R)ldnt(a.rad_sw + k); w.rlw = (R)ldnt(a.rad_lw + k);
+        }
+        return w;
+    };
+    // the team's next tile: the two-round tiles first, then the one-round tiles of the launch's tail; -1 when both pools are empty
+    auto grab = [](const FluxArgs<R, S> &a, bool tail_first) -> long {            // thread 0 of the team
+        int *q = a.queue;
+        const long ntiles = a.nfull + a.ntail;
+        if (tail_first) {
+            const long t = a.nfull + (long)atomicAdd(&q[1], 1);
+            if (t < ntiles) return t;
+        }
+        long t = (long)atomicAdd(&q[0], 1);
+        if (t < a.nfull) return t;
+        if (tail_first) return -1;                                                 // (its look at the tail pool came back empty already)
+        t = a.nfull + (long)atomicAdd(&q[1], 1);
+        return t < ntiles ? t : -1;
+    };
+    if (tid0 == 0) {
+        s_bara[team] = 0u;
+        *s_next = 0;
+        *s_tile = grab(kernarg_at<FluxArgs<R, S>>(0), (team & 1) != 0);
+    }
+    tile_sort_reset(s_cnt, tid0);
+    esat_table_fill(); csg_table_fill(); cu_tables_fill();      // every thread of the workgroup: one copy for the CU
+    math_tables_init<A>();                                       // (+ the workgroup's one and only s_barrier)
+#pragma unroll 1
+    for (;;) {
+        // what derives from the thread index (LDS addresses of the thread's cells, the masks of the sort's prefix scan ...) is formed again
+        // for every tile: hoisted out of the tile loop it is fifty registers held, or spilled, around the whole iteration
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        long tile0;
+        int rounds;
+        // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126
+        {
+            AB_ARGS;
+            long t = *s_tile;      // grabbed by thread 0 two team barriers ago (the first one: before the workgroup's barrier)
+            t = ((long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+            if (t < 0) break;
+            tile_of(a, t, tile0, rounds);
+            Raw nxt = fetch(a, tid, tile0, rounds, 0);
+#pragma unroll 1
+            for (int r = 0; r < rounds; ++r) {
+                const int j = r * kBlock + tid;
+                const long k = tile0 + j;
+                const Raw w = nxt;
+                nxt = fetch(a, tid, tile0, rounds, r + 1);
+                int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
+                if (k < a.n) {
+                    const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
+                    A q_zt;
+                    if (a.hum_type == 0) q_zt = A(hum);                                     // 'sh'
+                    else if (a.hum_type == 1) q_zt = q_air_dp<A, kPsiTabDefault>(A(hum), A(vmax(slp, R(50000.))));   // 'dp' :103
+                    else q_zt = q_air_rh<A, kPsiTabDefault>(A(hum), A(t_zt), A(vmax(slp, R(50000.))));              // 'rh' :105
+                    const A theta = theta_from_z_p0_t_q<A, kPsiTabDefault>(A(a.h.zt), A(slp), A(t_zt), q_zt);       // :118
+                    const R qsw = (R(1.) - K<R>::roce_alb0) * w.rsw;                                                  // :135,146,161
+                    s_f[0][j] = sst; s_f[1][j] = R(theta); s_f[2][j] = R(q_zt); s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
+                    s_f[6][j] = qsw; s_f[7][j] = w.rlw;
+                    if (a.regroup) {
+                        const bool wll = a.wl_load;
+                        bkt = forecast_bucket<ALGO, SKIN>((float)sst, (float)theta, (float)q_zt, (float)uu, (float)vv, (float)slp,
+                                                          (float)qsw, (float)w.rlw, wll, wll ? (float)a.wl0[k] : 0.f, wll ? (float)a.wl1[k] : 20.f);
+                    } else {
+                        bkt = 0;
+                    }
+                }
+                if (a.regroup) tile_sort_note(s_cnt, s_inv, j, bkt, tid);
+            }
+        }
+        sync();
+        // ---- phase 2: who computes which cell; thread 0 asks for the team's next tile
+        {
+            AB_ARGS;
+            if (tid == 0) *s_tile = grab(a, false);      // (every thread of the team has read the current one before the barrier above)
+            if (a.regroup) {
+                tile_sort_place<2>(s_cnt, s_base, s_inv, tid, rounds, sync);
+                tile_sort_reset(s_cnt, tid);              // (behind the barrier inside tile_sort_place: the counts have been read) for the next tile
+            } else {
+                for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
+            }
+        }
+        sync();
+        // ---- phase 3: groups of 64 sorted cells, fetched from the team's queue
+        {
+            AB_ARGS;
+            AB_DIAGS;
+            const int lane = tid & 63;
+            const Heights<R> hh = detached(a.h);
+            int nb_iter = a.nb_iter;
+            uniform_scalar(nb_iter);
+#pragma unroll 1
+            for (;;) {
+                int g = 0;
+                if (lane == 0) g = atomicAdd(s_next, 1);
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (g >= rounds * (kBlock / 64)) break;
+                const int j = s_inv[g * 64 + lane];
+                const long k = tile0 + j;
+                if (k >= a.n) continue;
+                R QL, QH, tx, ty, zEvap;
+                A T_s;
+                compute_cell<R, ALGO, SKIN, false, true, S, A, 2>(a, dg, hh, nb_iter, k, A(s_f[0][j]), A(s_f[1][j]), A(s_f[2][j]), s_f[3][j], s_f[4][j], s_f[5][j],
+                                                                  s_f[6][j], s_f[7][j], QL, QH, tx, ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
+                                                                  (lds_vptr<R>)&s_f[0][j], kCells);
+                s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = R(T_s);
+            }
+        }
+        sync();
+        // ---- phase 4: owners store (coalesced).  No barrier behind it: phase 4 reads and the next phase 1 writes a thread's OWN tile slots, and
+        // the group queue is re-armed by thread 0 two team barriers ahead of its next use
+        {
+            AB_ARGS;
+#pragma unroll 1
+            for (int r = 0; r < rounds; ++r) {
+                const int j = r * kBlock + tid;
+                const long k = tile0 + j;
+                if (k >= a.n) break;
+                stnt(a.ql + k, (S)s_f[0][j]);
+                stnt(a.qh + k, (S)s_f[1][j]);
+                stnt(a.tau_x + k, (S)s_f[2][j]);
+                stnt(a.tau_y + k, (S)s_f[3][j]);
+                if (a.evap) stnt(a.evap + k, (S)s_f[4][j]);                                // :208
+                if (a.t_s) stnt(a.t_s + k, (S)s_f[5][j]);                                  // :206
+            }
+            if (tid == 0) *s_next = 0;
+        }
+    }
+    if (tid0 == 0) {   // the last team out re-arms the counters for the next launch
+        AB_ARGS;
+        int *q = a.queue;
+        if (atomicAdd(&q[2], 1) == (int)gridDim.x * kCuTeams - 1) { atomicExch(&q[0], 0); atomicExch(&q[1], 0); atomicExch(&q[2], 0); }
+    }
+#undef AB_ARGS
+#undef AB_DIAGS
+}
+
 template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipError_t launch_t(const FluxCall &c, hipStream_t stream)
 {
     using T = Tile<R, ALGO, SKIN, !std::is_same<R, A>::value>;
@@ -383,7 +588,19 @@ template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipErro
         nblk = nfull + (c.n - nfull * tile + kBlock - 1) / kBlock;
     }
     a.nfull = nfull;
+    a.ntail = nblk - nfull;
+    a.queue = c.flags ? c.flags + 4 : nullptr;
     if (nblk <= 0) return hipSuccess;
+    // fp64 COARE with the skin schemes on a grid that fills the chip several times over: one workgroup per CU (flux_kernel_cu)
+    if constexpr (std::is_same<R, double>::value && std::is_same<A, double>::value && (ALGO == 1 || ALGO == 2) && SKIN) {
+        // AEROBULK_AMD_CU_KERNEL=0: never (A/B); =1: on every grid (tests: the golden vectors are 2 048 cells)
+        static const int mode = []{ const char *e = getenv("AEROBULK_AMD_CU_KERNEL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+        const long cus = resident_block_slots(4) / 4;
+        if (!diag && a.queue && rounds <= 2 && (mode == 1 || (mode < 0 && rounds == 2 && nblk >= 2 * cus * kCuTeams))) {
+            hipLaunchKernelGGL((flux_kernel_cu<R, ALGO, SKIN, S>), dim3((unsigned)cus), dim3(kCuBlock), 0, stream, a, dg);
+            return hipGetLastError();
+        }
+    }
     if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true, S, A>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false, S, A>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     return hipGetLastError();

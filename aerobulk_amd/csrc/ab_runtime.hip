@@ -159,9 +159,9 @@ int ab_session_create(ab_session **out, int algo, long ni, long nj, int nt, int 
     chk(hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking));
     chk(hipEventCreate(&s->ev0));
     chk(hipEventCreate(&s->ev1));
-    chk(hipMalloc((void **)&s->d_flags, sizeof(int)));
+    chk(hipMalloc((void **)&s->d_flags, 8 * sizeof(int)));   // [0] the error flag; [4..6] the tile counters of flux_kernel_cu (zero between launches: the kernel re-arms them)
     chk(hipMalloc((void **)&s->d_partials, sizeof(double) * ab::kStatBlocks * ab::kStatStride));
-    if (e == hipSuccess) chk(hipMemset(s->d_flags, 0, sizeof(int)));
+    if (e == hipSuccess) chk(hipMemset(s->d_flags, 0, 8 * sizeof(int)));
     if (s->use_skin && nt > 1) {  // persistent warm-layer planes; a single record keeps them in registers
         const int np = (algo == AB_ALGO_ECMWF) ? 2 : 4;
         for (int p = 0; p < np; ++p) chk(hipMalloc(&s->wl[p], s->esz * (size_t)s->n));

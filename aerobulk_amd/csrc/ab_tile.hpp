@@ -178,8 +178,12 @@ __device__ __forceinline__ void tile_sort_note(unsigned *s_cnt, unsigned short *
     const unsigned rank = atomicAdd(&s_cnt[bkt * kSortSub + (tid & (kSortSub - 1))], 1u);
     s_inv[j] = (unsigned short)(rank | ((unsigned)bkt << kSortRankBits));
 }
-template <int MAXROUNDS>
-__device__ __forceinline__ void tile_sort_place(const unsigned *s_cnt, unsigned *s_base, unsigned short *s_inv, int tid, int rounds)
+struct BlockSync {
+    __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+// `sync`: the barrier of the threads that share the tile (the block's; a team's in flux_kernel_cu)
+template <int MAXROUNDS, class Sync = BlockSync>
+__device__ __forceinline__ void tile_sort_place(const unsigned *s_cnt, unsigned *s_base, unsigned short *s_inv, int tid, int rounds, Sync sync = Sync())
 {
     static_assert(kSortCounters <= 64, "one wave scans the counters");
     if (tid < 64) {   // exclusive prefix over the counters, bucket-major (wave 0)
@@ -195,7 +199,7 @@ __device__ __forceinline__ void tile_sort_place(const unsigned *s_cnt, unsigned 
     unsigned key[MAXROUNDS];
 #pragma unroll
     for (int r = 0; r < MAXROUNDS; ++r) key[r] = (r < rounds) ? (unsigned)s_inv[r * kBlock + tid] : 0u;
-    __syncthreads();
+    sync();
     const unsigned sub = (unsigned)tid & (kSortSub - 1);
 #pragma unroll
     for (int r = 0; r < MAXROUNDS; ++r)

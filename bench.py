@@ -421,7 +421,7 @@ def main():
                                                      "repeat (several shards on one GPU: how the path is exercised on a one-GPU box)")
     a = ap.parse_args()
 
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (a.gpus > 1 or a.launcher == "inprocess") and "WORLD_SIZE" not in os.environ:   # (--launcher inprocess --gpus 1: the same code path on one shard)
         if a.launcher == "torchrun":          # a child process, started before this one initialises the GPU; its exit code is ours
             import subprocess
             argv, skip = [], False

@@ -37,8 +37,11 @@ def remarks(tmp_path_factory):
             cur = kernels.setdefault(m.group(2), {})
         elif cur is not None:
             cur[m.group(1).split(" ")[0]] = int(m.group(2))
-    flux = {k: v for k, v in kernels.items() if "flux_kernel" in k}
+    flux = {k: v for k, v in kernels.items() if "flux_kernelI" in k}
     assert len(flux) == 64, len(flux)     # 16 (5 algorithms x skin where it exists, x DIAG) x {fp64, fp32, fp32 arrays / fp64 arithmetic, mixed}
+    cu = {k: v for k, v in kernels.items() if "flux_kernel_cuI" in k}
+    assert len(cu) == 4, len(cu)          # one workgroup per CU: COARE 3.0 / 3.6 with the skin schemes, fp64 arithmetic on fp64 / fp32 arrays
+    flux.update(cu)
     return flux
 
 
@@ -56,6 +59,10 @@ def test_no_flux_kernel_uses_scratch(remarks):
 def test_lds_of_the_resident_blocks_fits_the_cu(remarks):
     seen = set()
     for name, v in remarks.items():
+        if "flux_kernel_cuI" in name:
+            # ONE workgroup of sixteen waves per CU: all of its 160 KB, four waves per SIMD (128 VGPRs)
+            assert v["Occupancy"] >= 4 and 150 * 1024 < v["LDS"] <= LDS_PER_CU, (name, v)
+            continue
         r, algo, skin, diag, s, a = _params(name)
         if algo == 3:
             assert v["LDS"] < (6144 if r == "d" else 4096)   # NCAR: direct kernel, math tables (+ fp64: the Kansas psi_m / psi_h pair, 3.5 KB)

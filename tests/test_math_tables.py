@@ -205,16 +205,36 @@ def test_table_positions_stay_inside_their_tables_at_the_last_admissible_argumen
     assert last32(6.6875, 32, 6.6875, 32) and last32(7.4453125, 32, 7.4453125, 32)   # fp32 tables
 
 
+def _bits_table(name, n):
+    gt = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_gtables.hpp")).read()
+    assert "constexpr int kLPsiCoareN = 80, kLWlAbsN = 72;" in gt
+    m = re.search(rf"AB_TAB double {name}\[{10 * n}\] = \{{(.*?)\}};", gt, re.S)
+    return np.array([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()]).reshape(n, 10)
+
+
+def _bits_eval(tab, x, e0):
+    """as bits_pos8<E0>() and lds10_at() of ab_physics.hpp: interval from the exponent and the top three mantissa bits, local variable
+    from the other 49, Horner from the top coefficient"""
+    import struct
+    bits = struct.unpack("<Q", struct.pack("<d", x))[0]
+    hi, lo = bits >> 32, bits & 0xFFFFFFFF
+    idx = (hi >> 17) - ((1023 + e0) << 3)
+    assert 0 <= idx < tab.shape[0], (x, idx)
+    v = struct.unpack("<d", struct.pack("<Q", (((hi & 0x1FFFF) | 0x3FF00000) << 32) | lo))[0]
+    u = v * 16.0 - 17.0
+    assert -1.0 <= u < 1.0
+    p = 0.0
+    for c in tab[idx][::-1]:
+        p = p * u + c
+    return p
+
+
 def test_warm_layer_absorption_table_indexed_by_the_bits_of_the_depth():
-    """kGWlAbs (ab_gtables.hpp): WL_COARE's absorbed fraction of the solar flux (mod_skin_coare.f90:167-168, 205-207) against its closed
+    """kLWlAbs (ab_gtables.hpp): WL_COARE's absorbed fraction of the solar flux (mod_skin_coare.f90:167-168, 205-207) against its closed
     form in 40-digit arithmetic, with the index and the local variable formed exactly as wl_absorb() forms them from the bits of H:
     every depth the scheme can produce (H clamped to [0.1, 20]) lands inside the table, on the right interval, within 1e-15."""
-    import struct
     mp.mp.dps = 40
-    gt = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_gtables.hpp")).read()
-    assert "constexpr int kGWlAbsN = 144, kGWlAbsE0 = -4;" in gt
-    m = re.search(r"AB_TAB double kGWlAbs\[1152\] = \{(.*?)\};", gt, re.S)
-    tab = np.array([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()]).reshape(144, 8)
+    tab = _bits_table("kLWlAbs", 72)
 
     def closed(H):
         H = mp.mpf(H)
@@ -227,49 +247,26 @@ def test_warm_layer_absorption_table_indexed_by_the_bits_of_the_depth():
                          np.exp(rng.uniform(np.log(0.1), np.log(20.0), 400))])
     worst = 0.0
     for H in hs:
-        hi = struct.unpack("<q", struct.pack("<d", H))[0] >> 32
-        lo = struct.unpack("<Q", struct.pack("<d", H))[0] & 0xFFFFFFFF
-        idx = (hi >> 16) - ((1023 - 4) << 4)
-        assert 0 <= idx < 144, (H, idx)
-        v = struct.unpack("<d", struct.pack("<Q", (((hi & 0xFFFF) | 0x3FF00000) << 32) | lo))[0]
-        u = v * 32.0 - 33.0
-        assert -1.0 <= u < 1.0
-        p = 0.0
-        for c in tab[idx][::-1]:
-            p = p * u + c
         ref = closed(H)
-        worst = max(worst, float(abs(mp.mpf(p) - ref) / abs(ref)))
+        worst = max(worst, float(abs(mp.mpf(_bits_eval(tab, H, -4)) - ref) / abs(ref)))
     assert worst < 1e-15, worst
 
 
 def test_coare_psi_tables_indexed_by_the_bits_of_their_argument():
-    """kGPsiCoareBM / BH (ab_gtables.hpp): COARE's blended unstable psi_m / psi_h as functions of y = |1 - 15 zeta|, the interval taken from
-    the exponent and the top four mantissa bits of y exactly as psi_coare<kPsiBits> takes it: against the reference's formulas
+    """kLPsiCoareM / H (ab_gtables.hpp): COARE's blended unstable psi_m / psi_h as functions of y = |1 - 15 zeta|, the interval taken from
+    the exponent and the top three mantissa bits of y exactly as psi_coare<kPsiBits / kPsiBitsLds> takes it: against the reference's formulas
     (mod_common_coare.f90:235-252, :326-342, tools/gen_gtab.py) in 40-digit arithmetic, every zeta the iteration can produce."""
-    import struct
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_gtab
     mp.mp.dps = 40
-    gt = open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_gtables.hpp")).read()
-    assert "constexpr int kGPsiCoareBN = 160;" in gt
     rng = np.random.default_rng(11)
     zetas = -np.concatenate([[0.0, 1e-12, 1e-6, 50.0, 49.999, 1.0 / 15.0, 2.0 / 15.0], 10.0 ** rng.uniform(-8, np.log10(50.0), 300)])
-    for which, name in (("m", "kGPsiCoareBM"), ("h", "kGPsiCoareBH")):
-        m = re.search(rf"AB_TAB double {name}\[1280\] = \{{(.*?)\}};", gt, re.S)
-        tab = np.array([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()]).reshape(160, 8)
+    for which, name in (("m", "kLPsiCoareM"), ("h", "kLPsiCoareH")):
+        tab = _bits_table(name, 80)
         f = gen_gtab.coare(which)
         worst = 0.0
         for z in zetas:
             y = abs(1.0 - 15.0 * z)
-            bits = struct.unpack("<Q", struct.pack("<d", y))[0]
-            hi, lo = bits >> 32, bits & 0xFFFFFFFF
-            idx = (hi >> 16) - (1023 << 4)
-            assert 0 <= idx < 160, (z, idx)
-            v = struct.unpack("<d", struct.pack("<Q", (((hi & 0xFFFF) | 0x3FF00000) << 32) | lo))[0]
-            u = v * 32.0 - 33.0
-            p = 0.0
-            for c in tab[idx][::-1]:
-                p = p * u + c
-            worst = max(worst, float(abs(mp.mpf(p) - f(mp.log(mp.mpf(y))))))
+            worst = max(worst, float(abs(mp.mpf(_bits_eval(tab, y, 0)) - f(mp.log(mp.mpf(y))))))
         assert worst < 2e-15, (which, worst)      # values up to 6.6

@@ -15,15 +15,15 @@ LDS has no room for live in global memory:
                     the convective arguments pi: intervals of 1/16 put the degree-7 interpolation error at the rounding of the
                     coefficients; the LDS of a block has no room for 2 x 6.7 KB, the L1 does.)
   kGPsikM / H       Kansas / Paulson psi_m and psi_h in s = LOG(|1 - 16 zeta|) (ECMWF, NCAR, ANDREAS), 28 intervals on [0, 6.6875)
-  kGPsiCoareBM / BH the same blended psi_m / psi_h of COARE as functions of y = |1 - 15 zeta| itself, 1 <= y < 1024 (zeta > -68), indexed by the
-                    BITS of y like kGWlAbs below: 16 intervals per binade, 10 binades = 160 intervals, degree 7 — the logarithm that the
-                    tables in s need (one per evaluation, eleven per unstable cell of the headline kernel: ~20 issue slots each) is gone.
-                    For the kernels with the skin schemes (both through L1; their LDS has no room for tables this long).
-  kGWlAbs           WL_COARE's absorbed fraction 1 - sum_i c_i a_i (1 - exp(-H/a_i))/H of the solar flux in a warm layer of depth H
+  kLPsiCoareM / H   the same blended psi_m / psi_h of COARE as functions of y = |1 - 15 zeta| itself, 1 <= y < 1024 (zeta > -68), indexed by the
+                    BITS of y: interval = exponent and top three mantissa bits (8 intervals per binade, 10 binades = 80 intervals), local
+                    variable from the remaining mantissa bits — no logarithm, no floor: a shift, a subtraction, a mask and one FMA.  Degree 9,
+                    interval-major rows of ten doubles (80 B).  The logarithm that the tables in s need (one per evaluation, eleven per
+                    unstable cell of the headline kernel: ~20 issue slots each) is gone.  6.4 KB each: in LDS where a whole CU shares one
+                    copy (flux_kernel_cu), else through L1 — the same numbers and the same polynomial either way.
+  kLWlAbs           WL_COARE's absorbed fraction 1 - sum_i c_i a_i (1 - exp(-H/a_i))/H of the solar flux in a warm layer of depth H
                     (mod_skin_coare.f90:167-168, 205-207; three exponentials and a division, up to ten times per cell), on 0.0625 <= H < 32
-                    (the scheme clamps H to [0.1, 20]).  Indexed by the BITS of H: interval = exponent and the top four mantissa bits
-                    (16 intervals per binade, 9 binades: 144 intervals), local variable from the remaining mantissa bits — no logarithm,
-                    no floor: a shift, a subtraction, a mask and one FMA.  4.3e-16 relative.
+                    (the scheme clamps H to [0.1, 20]), indexed by the bits of H the same way: 72 intervals, degree 9, 1.0e-16 relative.
   kGCsG             the cool skin's absorption profile g(u) = (1 - exp(-u))/u, u = delta/8e-4 (mod_phymbl.f90:2030-2044 via
                     CS_COARE / CS_ECMWF: zfr = c0 + 11 delta - 6.6e-5/delta (1 - exp(-delta/8e-4))), 64 intervals of 1/8 on [0, 8)
 
@@ -194,43 +194,44 @@ def main():
     for j in range(0, len(flat), 4):
         out.append("    " + ", ".join(repr(v) for v in flat[j:j + 4]) + ("," if j + 4 < len(flat) else "};"))
     DEG = 7
-    # COARE's blended psi_m / psi_h indexed by the bits of y = |1 - 15 zeta| (16 intervals per binade over 1 <= y < 2^10)
-    out.append("constexpr int kGPsiCoareBN = 160;    // intervals: exponent and top four mantissa bits of y")
-    for which, name in (("m", "kGPsiCoareBM"), ("h", "kGPsiCoareBH")):
-        fs = coare(which)
-        fy = lambda y, fs=fs: fs(mp.log(y))
+    # ---- tables indexed by the bits of their argument: degree 9 on 8 intervals per binade, interval-major rows of ten doubles (80 B: five
+    # 16-byte reads on one address; from LDS in flux_kernel_cu, where a whole CU shares one copy, through L1 elsewhere)
+    DEG = 9
+
+    def bits_table(f, e0, e1, nsub, lo=None, hi=None, rel=False):
         rows, worst = [], mp.mpf(0)
-        for e in range(0, 10):
-            for k in range(16):
-                a, b = mp.mpf(2) ** e * (1 + mp.mpf(k) / 16), mp.mpf(2) ** e * (1 + mp.mpf(k + 1) / 16)
-                c = local_fit(fy, a, b)
+        for e in range(e0, e1):
+            for k in range(nsub):
+                a, b = mp.mpf(2) ** e * (1 + mp.mpf(k) / nsub), mp.mpf(2) ** e * (1 + mp.mpf(k + 1) / nsub)
+                c = local_fit(f, a, b)
                 rows.append(c)
-                for j in range(17):
-                    u = mp.mpf(-1) + mp.mpf(2) * j / 16
-                    pp = mp.mpf(0)
-                    for cc in reversed(c):
-                        pp = pp * u + mp.mpf(cc)
-                    worst = max(worst, abs(pp - fy((a + b) / 2 + (b - a) / 2 * u)))
-        print(name, float(worst), file=sys.stderr)
-        emit(out, name, rows, float(worst), f"COARE unstable psi_{which} (Kansas / convective blend) vs y = |1 - 15 zeta|, 16 intervals per binade on [1, 1024)")
-    # WL_COARE's absorbed fraction, indexed by the bits of H (16 intervals per binade over 2^-4 <= H < 2^5)
-    rows, worst = [], mp.mpf(0)
-    for e in range(-4, 5):
-        for k in range(16):
-            a, b = mp.mpf(2) ** e * (1 + mp.mpf(k) / 16), mp.mpf(2) ** e * (1 + mp.mpf(k + 1) / 16)
-            c = local_fit(wl_abs, a, b)
-            rows.append(c)
-            if b > mp.mpf("0.1") and a < 20:
-                for j in range(33):
-                    u = mp.mpf(-1) + mp.mpf(2) * j / 32
-                    pp = mp.mpf(0)
-                    for cc in reversed(c):
-                        pp = pp * u + mp.mpf(cc)
-                    x = (a + b) / 2 + (b - a) / 2 * u
-                    worst = max(worst, abs(pp - wl_abs(x)) / abs(wl_abs(x)))
-    print("kGWlAbs", float(worst), file=sys.stderr)
-    out.append("constexpr int kGWlAbsN = 144, kGWlAbsE0 = -4;    // intervals; exponent of the first binade")
-    emit(out, "kGWlAbs", rows, float(worst), "WL_COARE absorbed fraction of the solar flux vs layer depth H, 16 intervals per binade on [2^-4, 2^5), relative error on [0.1, 20]")
+                if (lo is None or b > lo) and (hi is None or a < hi):
+                    for j in range(17):
+                        u = mp.mpf(-1) + mp.mpf(2) * j / 16
+                        pp = mp.mpf(0)
+                        for cc in reversed(c):
+                            pp = pp * u + mp.mpf(cc)
+                        x = (a + b) / 2 + (b - a) / 2 * u
+                        worst = max(worst, abs(pp - f(x)) / (abs(f(x)) if rel else 1))
+        return rows, float(worst)
+
+    def emit10(name, rows, err, what):
+        out.append(f"// {what}: {len(rows)} intervals x 10 coefficients (degree 9, interval-major), max error {err:.2e}")
+        out.append(f"AB_TAB double {name}[{10 * len(rows)}] = {{")
+        flat = [c for r in rows for c in r]
+        for jj in range(0, len(flat), 4):
+            out.append("    " + ", ".join(repr(v) for v in flat[jj:jj + 4]) + ("," if jj + 4 < len(flat) else "};"))
+
+    out.append("constexpr int kLPsiCoareN = 80, kLWlAbsN = 72;    // LDS copies: 8 intervals per binade; y in [1, 1024), H in [2^-4, 2^5)")
+    for which, name in (("m", "kLPsiCoareM"), ("h", "kLPsiCoareH")):
+        fs = coare(which)
+        rows, err = bits_table(lambda y, fs=fs: fs(mp.log(y)), 0, 10, 8)
+        print(name, err, file=sys.stderr)
+        emit10(name, rows, err, f"COARE unstable psi_{which} vs y = |1 - 15 zeta| for LDS")
+    rows, err = bits_table(wl_abs, -4, 5, 8, lo=mp.mpf("0.1"), hi=mp.mpf(20), rel=True)
+    print("kLWlAbs", err, file=sys.stderr)
+    emit10("kLWlAbs", rows, err, "WL_COARE absorbed fraction vs depth H for LDS (relative error on [0.1, 20])")
+    DEG = 7
     out.append("}  // namespace ab")
     print("\n".join(out))
 
