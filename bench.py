@@ -40,6 +40,18 @@ ALL_ALGOS = ("coare3p0", "coare3p6", "ncar", "ecmwf", "andreas")
 PMC_JSON = os.path.join(ROOT, "profiles", "r4_pmc.json")
 
 
+def kernel_label(precision, algo, skin, n_cells, ab):
+    """Name of the kernel a launch of n_cells runs (launch_t, ab_kernels.hip): fp64 COARE with the skin schemes on grids of three tiles per
+    team and more takes flux_kernel_cu (one workgroup of sixteen waves per CU, every table in LDS); everything else the 256-thread flux_kernel."""
+    cu = (precision in ("f64", "f32_storage") and algo in ("coare3p0", "coare3p6") and skin and os.environ.get("AEROBULK_AMD_CU_KERNEL", "")[:1] != "0")
+    if cu:
+        import torch
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        tiles = (n_cells - min(n_cells, cus * 4 * 256)) // 512 + -(-min(n_cells, cus * 4 * 256) // 256)
+        cu = tiles >= 3 * cus * 4
+    return f"{'flux_kernel_cu' if cu else 'flux_kernel'}<{precision},{algo},{'skin' if skin else 'noskin'}>"
+
+
 def algorithmic_bytes_per_cell(skin, esz):
     """no skin 6 in + 5 out; skin (single record) 8 in + 6 out."""
     return (8 + 6) * esz if skin else (6 + 5) * esz
@@ -365,7 +377,7 @@ def main_inprocess(a):
                      "note": "the same K steps with the fluxes left on the device that computed them (no gather)"},
         "per_device_kernel_ms": {f"shard{r}@gpu{shards[r][2]}": round(kms[r], 4) for r in range(len(shards))},
         "roofline": {"bound": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": None, "kernel": f"flux_kernel<{precision},{head_algo},{'skin' if head_skin else 'noskin'}>",
+                     "traffic": None, "kernel": kernel_label(precision, head_algo, head_skin, n_slow, ab),
                      "kernel_ms": round(kms[slow], 4), "bytes_per_cell": bpc, "cells_per_launch": n_slow,
                      "note": "the slowest shard's launch of the first pass; per device, not summed over devices"},
     }
@@ -749,7 +761,7 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": prof["hbm_traffic_bytes"] if prof else None,
-                         "kernel": f"flux_kernel<{precision},{head_algo},{'skin' if head_skin else 'noskin'}>",
+                         "kernel": kernel_label(precision, head_algo, head_skin, n_local, ab),
                          "kernel_ms": round(k_ms, 4), "bytes_per_cell": bpc, "cells_per_launch": n_local,
                          "fp64_frac": prof["fp64_frac"] if prof else None,
                          "valu_issue_frac": prof["valu_issue_frac"] if prof else None,
