@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run bench.py for every BASELINE.json configuration that fits one GPU and collect the JSON lines (SURVEY §8d "configs ->
-concrete runs"): writes gpurun_out/configs.jsonl (copy to profiles/r3_configs.jsonl)."""
+concrete runs"): writes gpurun_out/configs.jsonl (copy to profiles/r4_configs.jsonl)."""
 import json
 import os
 import subprocess
