@@ -376,7 +376,7 @@ def main_inprocess(a):
                      "ms_per_step": round(elapsed_resident / a.steps * 1e3, 4),
                      "note": "the same K steps with the fluxes left on the device that computed them (no gather)"},
         "per_device_kernel_ms": {f"shard{r}@gpu{shards[r][2]}": round(kms[r], 4) for r in range(len(shards))},
-        "roofline": {"bound": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "roofline": {"bound": "hbm", "limiter": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": None, "kernel": kernel_label(precision, head_algo, head_skin, n_slow, ab),
                      "kernel_ms": round(kms[slow], 4), "bytes_per_cell": bpc, "cells_per_launch": n_slow,
                      "note": "the slowest shard's launch of the first pass; per device, not summed over devices"},
@@ -758,7 +758,7 @@ def main():
             # contraction on this path).  achieved/peak/frac are the HBM figures BASELINE.json asks for (algorithmic bytes over the
             # live kernel duration); `profile` holds the hardware-counter view of the binding resource, quoted only when the
             # committed profile was taken with this very device code.
-            "roofline": {"bound": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limiter": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": prof["hbm_traffic_bytes"] if prof else None,
                          "kernel": kernel_label(precision, head_algo, head_skin, n_local, ab),
