@@ -145,6 +145,134 @@ template <class T> __device__ __forceinline__ const T &kernarg_at(unsigned off)
     return *(const T *)(p + off);
 }
 
+// ---- the four phases of a tile, shared by flux_kernel (a 256-thread block owns the tile) and flux_kernel_cu (a team of a CU-wide workgroup
+// does).  s_f: the tile's field rows [kFields][CELLS] in LDS; tid: the thread's index among the 256 that own the tile.
+template <class R> struct RawCell { R sst, t_zt, hum, uu, vv, slp, rsw, rlw; };
+// tile t of the launch: `rounds` rounds of 256 cells; the LAST tiles of the grid are one-round tiles: the chip drains over the life of a
+// short tile instead of a long one (launch_t)
+template <class R, class S> __device__ __forceinline__ void tile_of(const FluxArgs<R, S> &a, long t, long &t0, int &rr)
+{
+    rr = a.rounds;
+    t0 = t * ((long)rr * kBlock);
+    if (t >= a.nfull) { t0 = a.nfull * ((long)rr * kBlock) + (t - a.nfull) * kBlock; rr = 1; }
+}
+// owners load their cells (coalesced); streamed once: non-temporal, so that the fields do not push the piecewise tables out of the L1
+template <class R, class S, bool SKIN> __device__ __forceinline__ RawCell<R> tile_fetch(const FluxArgs<R, S> &a, int tid, long tile0, int rounds, int r)
+{
+    RawCell<R> w{R(290.), R(290.), R(0.01), R(1.), R(1.), R(101000.), R(0.), R(0.)};
+    const long k = tile0 + r * kBlock + tid;
+    if (r < rounds && k < a.n) {
+        w.sst = (R)ldnt(a.sst + k); w.t_zt = (R)ldnt(a.t_zt + k); w.hum = (R)ldnt(a.hum + k); w.uu = (R)ldnt(a.u + k); w.vv = (R)ldnt(a.v + k);
+        w.slp = (R)ldnt(a.slp + k);
+        if (SKIN) { w.rsw = (R)ldnt(a.rad_sw + k); w.rlw = (R)ldnt(a.rad_lw + k); }
+    }
+    return w;
+}
+// phase 1: pre-processing mod_aerobulk_compute.f90:99-126 of the owners' cells, parked in LDS; the forecast of each cell's bucket.  The
+// loads of round r + 1 are in flight while round r is pre-processed (`nxt`: those of round 0, issued by the caller)
+template <class R, int ALGO, bool SKIN, class S, class A, int CELLS>
+__device__ __forceinline__ void tile_phase1(const FluxArgs<R, S> &a, int tid, long tile0, int rounds, RawCell<R> nxt, R (*s_f)[CELLS], unsigned *s_cnt,
+                                            unsigned short *s_inv)
+{
+    constexpr bool kMixed = !std::is_same<R, A>::value;
+    constexpr int kThLo = (SKIN ? 8 : 6);      // mixed: one more row at the end, the low part of theta
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const int j = r * kBlock + tid;
+        const long k = tile0 + j;
+        const RawCell<R> w = nxt;
+        nxt = tile_fetch<R, S, SKIN>(a, tid, tile0, rounds, r + 1);
+        int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
+        if (k < a.n) {
+            const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
+            constexpr bool kEsatTab = (SKIN || kMixed) && kPsiTabDefault;
+            A q_zt;
+            if (a.hum_type == 0) q_zt = A(hum);                                     // 'sh'
+            else if (a.hum_type == 1) q_zt = q_air_dp<A, kEsatTab>(A(hum), A(vmax(slp, R(50000.))));   // 'dp' :103
+            else q_zt = q_air_rh<A, kEsatTab>(A(hum), A(t_zt), A(vmax(slp, R(50000.))));              // 'rh' :105
+            const A theta = theta_from_z_p0_t_q<A, kEsatTab>(A(a.h.zt), A(slp), A(t_zt), q_zt);       // :118
+            s_f[0][j] = sst; s_f[1][j] = R(theta); s_f[2][j] = R(q_zt); s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
+            if constexpr (kMixed) s_f[kThLo][j] = R(theta - A(R(theta)));
+            R qsw = R(0.), rlw = R(0.);
+            if (SKIN) {
+                qsw = (R(1.) - K<R>::roce_alb0) * w.rsw;                            // :135,146,161
+                rlw = w.rlw;
+                s_f[SKIN ? 6 : 0][j] = qsw; s_f[SKIN ? 7 : 0][j] = rlw;
+            }
+            if (a.regroup) {
+                const bool wll = SKIN && a.wl_load;
+                bkt = forecast_bucket<ALGO, SKIN>((float)sst, (float)theta, (float)q_zt, (float)uu, (float)vv, (float)slp,
+                                                  (float)qsw, (float)rlw, wll, wll ? (float)a.wl0[k] : 0.f,
+                                                  (wll && ALGO != 4) ? (float)a.wl1[k] : 20.f);
+            } else {
+                bkt = 0;
+            }
+        }
+        if (a.regroup) tile_sort_note(s_cnt, s_inv, j, bkt, tid);
+    }
+}
+// phase 2: who computes which cell (the counting sort's placement; the counters are zeroed again for the owners' next tile)
+template <int MAXROUNDS, class R, class S, class Sync>
+__device__ __forceinline__ void tile_phase2(const FluxArgs<R, S> &a, int tid, int rounds, unsigned *s_cnt, unsigned *s_base, unsigned short *s_inv, Sync sync)
+{
+    if (a.regroup) {
+        tile_sort_place<MAXROUNDS>(s_cnt, s_base, s_inv, tid, rounds, sync);
+        tile_sort_reset(s_cnt, tid);   // (behind the barrier inside tile_sort_place: the counts have been read)
+    } else {
+        for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
+    }
+}
+// phase 3: groups of 64 sorted cells, fetched from the tile's queue; the results go back to the cell's LDS slot
+template <class R, int ALGO, bool SKIN, bool DIAG, class S, class A, int LTABS, int CELLS>
+__device__ __forceinline__ void tile_phase3(const FluxArgs<R, S> &a, const DiagArgs<S> &dg, int tid, long tile0, int rounds, R (*s_f)[CELLS],
+                                            const unsigned short *s_inv, int *s_next)
+{
+    constexpr bool kMixed = !std::is_same<R, A>::value;
+    constexpr int kThLo = (SKIN ? 8 : 6);
+    const int lane = tid & 63;
+    const Heights<R> hh = detached(a.h);      // loop invariants out of their scalar-load tuples (ab_tile.hpp)
+    int nb_iter = a.nb_iter;
+    uniform_scalar(nb_iter);
+#pragma unroll 1
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(s_next, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= rounds * (kBlock / 64)) break;
+        const int j = s_inv[g * 64 + lane];
+        const long k = tile0 + j;
+        if (k >= a.n) continue;
+
+        R QL, QH, tx, ty, zEvap;
+        A T_s;
+        A theta = A(s_f[1][j]);
+        if constexpr (kMixed) theta = theta + A(s_f[kThLo][j]);
+        compute_cell<R, ALGO, SKIN, DIAG, true, S, A, LTABS>(a, dg, hh, nb_iter, k, A(s_f[0][j]), theta, A(s_f[2][j]), s_f[3][j], s_f[4][j], s_f[5][j],
+                                          SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
+                                          ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
+                                          // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare
+                                          (SKIN && sizeof(R) == 8) ? (lds_vptr<R>)&s_f[0][j] : (lds_vptr<R>)nullptr, CELLS);
+        // the cell's LDS slot is read by this lane only: reuse it for the results
+        s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = R(T_s);
+    }
+}
+// phase 4: owners store (coalesced)
+template <class R, class S, int CELLS> __device__ __forceinline__ void tile_phase4(const FluxArgs<R, S> &a, int tid, long tile0, int rounds, R (*s_f)[CELLS])
+{
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const int j = r * kBlock + tid;
+        const long k = tile0 + j;
+        if (k >= a.n) break;
+        stnt(a.ql + k, (S)s_f[0][j]);
+        stnt(a.qh + k, (S)s_f[1][j]);
+        stnt(a.tau_x + k, (S)s_f[2][j]);
+        stnt(a.tau_y + k, (S)s_f[3][j]);
+        if (a.evap) stnt(a.evap + k, (S)s_f[4][j]);                                // :208
+        if (a.t_s) stnt(a.t_s + k, (S)s_f[5][j]);                                  // :206
+    }
+}
+
 // A: the anchor type (ab_physics.hpp, "ANCHORS").  A = R for the fp64 and fp32 sessions; AB_F32_MIXED is <R = float, S = float,
 // A = double>: fp32 arrays and fp32 hardware transcendentals, with SST, theta, q, T_s, q_s, their differences and q_sat in fp64.
 template <class R, int ALGO, bool SKIN, bool DIAG, class S = R, class A = R>
@@ -190,41 +318,19 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     using T = Tile<R, ALGO, SKIN, kMixed>;
     // field rows: sst theta q_zt u v slp [qsw rlw]; mixed: one more row at the end, the low part of theta (theta is an fp64 anchor
     // parked as a float pair; sst and q_zt are fp32 numbers anyway, exactly in 'sh' mode and to half an fp32 ulp otherwise)
-    constexpr int kThLo = T::kFields - 1;
     __shared__ R s_f[T::kFields][T::kCells];
     __shared__ unsigned short s_inv[T::kCells];
     __shared__ unsigned s_cnt[kSortCounters], s_base[kSortCounters];
     __shared__ int s_next;
     const int tid = threadIdx.x;
-    struct Raw { R sst, t_zt, hum, uu, vv, slp, rsw, rlw; };
-    // tile t of the launch: <= T::kRounds rounds of 256 cells; fewer on small grids so that every CU gets blocks.  The LAST tiles of
-    // the grid are one-round tiles: the chip drains over the life of a short tile instead of a long one (launch_t)
-    auto tile_of = [](const FluxArgs<R, S> &a, long t, long &t0, int &rr) {
-        rr = a.rounds;
-        t0 = t * ((long)rr * kBlock);
-        if (t >= a.nfull) { t0 = a.nfull * ((long)rr * kBlock) + (t - a.nfull) * kBlock; rr = 1; }
-    };
-    // owners load their cells (coalesced); streamed once: non-temporal, so that the fields do not push the piecewise tables
-    // (ab_gtables.hpp) out of the L1
-    auto fetch = [](const FluxArgs<R, S> &a, int tid, long tile0, int rounds, int r) -> Raw {
-        Raw w{R(290.), R(290.), R(0.01), R(1.), R(1.), R(101000.), R(0.), R(0.)};
-        const long k = tile0 + r * kBlock + tid;
-        if (r < rounds && k < a.n) {
-            w.sst = (R)ldnt(a.sst + k); w.t_zt = (R)ldnt(a.t_zt + k); w.hum = (R)ldnt(a.hum + k); w.uu = (R)ldnt(a.u + k); w.vv = (R)ldnt(a.v + k);
-            w.slp = (R)ldnt(a.slp + k);
-            if (SKIN) { w.rsw = (R)ldnt(a.rad_sw + k); w.rlw = (R)ldnt(a.rad_lw + k); }
-        }
-        return w;
-    };
     long tile0;
     int rounds;
-    Raw nxt;
+    RawCell<R> nxt;
     {
         AB_ARGS;
-        tile_of(a, (long)blockIdx.x, tile0, rounds);
-        // ---- phase 1 starts here: the loads of a round are issued one round ahead: those of round 0 are in flight while the block fills
-        // its math tables, those of round r+1 while round r is pre-processed (a block starts with nothing else to hide that latency behind)
-        nxt = fetch(a, tid, tile0, rounds, 0);
+        tile_of(a, (long)blockIdx.x, tile0, rounds);     // <= T::kRounds; fewer on small grids so that every CU gets blocks
+        // the loads of round 0 are in flight while the block fills its math tables (a block starts with nothing else to hide that latency behind)
+        nxt = tile_fetch<R, S, SKIN>(a, tid, tile0, rounds, 0);
     }
     if (tid == 0) s_next = 0;
     tile_sort_reset(s_cnt, tid);
@@ -245,108 +351,13 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
     if constexpr (kMixed) esat_table_fill();              // q_sat of the mixed mode is the fp64 one, through its LDS table
     math_tables_init<A>();
     if (sizeof(A) != 8) __syncthreads();                  // (fp64: the barrier of math_tables_init) counters zeroed before phase 1
-    {
-        // ---- phase 1: pre-processing mod_aerobulk_compute.f90:99-126
-        {
-            AB_ARGS;
-#pragma unroll 1
-            for (int r = 0; r < rounds; ++r) {
-                const int j = r * kBlock + tid;
-                const long k = tile0 + j;
-                const Raw w = nxt;
-                nxt = fetch(a, tid, tile0, rounds, r + 1);
-                int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
-                if (k < a.n) {
-                    const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
-                    constexpr bool kEsatTab = (SKIN || kMixed) && kPsiTabDefault;
-                    A q_zt;
-                    if (a.hum_type == 0) q_zt = A(hum);                                     // 'sh'
-                    else if (a.hum_type == 1) q_zt = q_air_dp<A, kEsatTab>(A(hum), A(vmax(slp, R(50000.))));   // 'dp' :103
-                    else q_zt = q_air_rh<A, kEsatTab>(A(hum), A(t_zt), A(vmax(slp, R(50000.))));              // 'rh' :105
-                    const A theta = theta_from_z_p0_t_q<A, kEsatTab>(A(a.h.zt), A(slp), A(t_zt), q_zt);       // :118
-                    s_f[0][j] = sst; s_f[1][j] = R(theta); s_f[2][j] = R(q_zt); s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
-                    if constexpr (kMixed) s_f[kThLo][j] = R(theta - A(R(theta)));
-                    R qsw = R(0.), rlw = R(0.);
-                    if (SKIN) {
-                        qsw = (R(1.) - K<R>::roce_alb0) * w.rsw;                            // :135,146,161
-                        rlw = w.rlw;
-                        s_f[SKIN ? 6 : 0][j] = qsw; s_f[SKIN ? 7 : 0][j] = rlw;
-                    }
-                    if (a.regroup) {
-                        const bool wll = SKIN && a.wl_load;
-                        bkt = forecast_bucket<ALGO, SKIN>((float)sst, (float)theta, (float)q_zt, (float)uu, (float)vv, (float)slp,
-                                                          (float)qsw, (float)rlw, wll, wll ? (float)a.wl0[k] : 0.f,
-                                                          (wll && ALGO != 4) ? (float)a.wl1[k] : 20.f);
-                    } else {
-                        bkt = 0;
-                    }
-                }
-                if (a.regroup) tile_sort_note(s_cnt, s_inv, j, bkt, tid);
-            }
-        }
-        __syncthreads();
-        // ---- phase 2: who computes which cell
-        {
-            AB_ARGS;
-            if (a.regroup) {
-                tile_sort_place<T::kRounds>(s_cnt, s_base, s_inv, tid, rounds);
-                tile_sort_reset(s_cnt, tid);   // (behind the barrier inside tile_sort_place: the counts have been read) for the block's next tile
-            } else {
-                for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 3: groups of 64 sorted cells, fetched from a queue
-        {
-            AB_ARGS;
-            AB_DIAGS;
-            const int lane = tid & 63;
-            const Heights<R> hh = detached(a.h);      // loop invariants out of their scalar-load tuples (ab_tile.hpp)
-            int nb_iter = a.nb_iter;
-            uniform_scalar(nb_iter);
-#pragma unroll 1
-            for (;;) {
-                int g = 0;
-                if (lane == 0) g = atomicAdd(&s_next, 1);
-                g = __builtin_amdgcn_readfirstlane(g);
-                if (g >= rounds * (kBlock / 64)) break;
-                const int j = s_inv[g * 64 + lane];
-                const long k = tile0 + j;
-                if (k >= a.n) continue;
-
-                R QL, QH, tx, ty, zEvap;
-                A T_s;
-                A theta = A(s_f[1][j]);
-                if constexpr (kMixed) theta = theta + A(s_f[kThLo][j]);
-                compute_cell<R, ALGO, SKIN, DIAG, true, S, A>(a, dg, hh, nb_iter, k, A(s_f[0][j]), theta, A(s_f[2][j]), s_f[3][j], s_f[4][j], s_f[5][j],
-                                                  SKIN ? s_f[SKIN ? 6 : 0][j] : R(0.), SKIN ? s_f[SKIN ? 7 : 0][j] : R(0.), QL, QH, tx,
-                                                  ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
-                                                  // rows 0-2, 5, 6 (sst theta q slp qsw) are in registers by now: scratch words for turb_coare
-                                                  (SKIN && sizeof(R) == 8) ? (lds_vptr<R>)&s_f[0][j] : (lds_vptr<R>)nullptr, T::kCells);
-                // the cell's LDS slot is read by this lane only: reuse it for the results
-                s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = R(T_s);
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 4: owners store (coalesced)
-        {
-            AB_ARGS;
-#pragma unroll 1
-            for (int r = 0; r < rounds; ++r) {
-                const int j = r * kBlock + tid;
-                const long k = tile0 + j;
-                if (k >= a.n) break;
-                stnt(a.ql + k, (S)s_f[0][j]);
-                stnt(a.qh + k, (S)s_f[1][j]);
-                stnt(a.tau_x + k, (S)s_f[2][j]);
-                stnt(a.tau_y + k, (S)s_f[3][j]);
-                if (a.evap) stnt(a.evap + k, (S)s_f[4][j]);                                // :208
-                if (a.t_s) stnt(a.t_s + k, (S)s_f[5][j]);                                  // :206
-            }
-        }
-    }
+    { AB_ARGS; tile_phase1<R, ALGO, SKIN, S, A>(a, tid, tile0, rounds, nxt, s_f, s_cnt, s_inv); }
+    __syncthreads();
+    { AB_ARGS; tile_phase2<T::kRounds>(a, tid, rounds, s_cnt, s_base, s_inv, BlockSync()); }
+    __syncthreads();
+    { AB_ARGS; AB_DIAGS; tile_phase3<R, ALGO, SKIN, DIAG, S, A, 1>(a, dg, tid, tile0, rounds, s_f, s_inv, &s_next); }
+    __syncthreads();
+    { AB_ARGS; tile_phase4<R, S>(a, tid, tile0, rounds, s_f); }
 #undef AB_ARGS
 #undef AB_DIAGS
 }
@@ -405,22 +416,6 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
     long *s_tile = &s_tilea[team];
     unsigned arrivals = 0;
     const TeamSync sync{&s_bara[team], &arrivals};
-    struct Raw { R sst, t_zt, hum, uu, vv, slp, rsw, rlw; };
-    auto tile_of = [](const FluxArgs<R, S> &a, long t, long &t0, int &rr) {
-        rr = a.rounds;
-        t0 = t * ((long)rr * kBlock);
-        if (t >= a.nfull) { t0 = a.nfull * ((long)rr * kBlock) + (t - a.nfull) * kBlock; rr = 1; }
-    };
-    auto fetch = [](const FluxArgs<R, S> &a, int tid, long tile0, int rounds, int r) -> Raw {
-        Raw w{R(290.), R(290.), R(0.01), R(1.), R(1.), R(101000.), R(0.), R(0.)};
-        const long k = tile0 + r * kBlock + tid;
-        if (r < rounds && k < a.n) {
-            w.sst = (R)ldnt(a.sst + k); w.t_zt = (R)ldnt(a.t_zt + k); w.hum = (R)ldnt(a.hum + k); w.uu = (R)ldnt(a.u + k); w.vv = (R)ldnt(a.v + k);
-            w.slp = (R)ldnt(a.slp + k);
-            w.rsw = (R)ldnt(a.rad_sw + k); w.rlw = (R)ldnt(a.rad_lw + k);
-        }
-        return w;
-    };
     // the team's next tile: the two-round tiles first, then the one-round tiles of the launch's tail; -1 when both pools are empty
     auto grab = [](const FluxArgs<R, S> &a, bool tail_first) -> long {            // thread 0 of the team
         int *q = a.queue;
@@ -458,90 +453,24 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
             t = ((long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t);
             if (t < 0) break;
             tile_of(a, t, tile0, rounds);
-            Raw nxt = fetch(a, tid, tile0, rounds, 0);
-#pragma unroll 1
-            for (int r = 0; r < rounds; ++r) {
-                const int j = r * kBlock + tid;
-                const long k = tile0 + j;
-                const Raw w = nxt;
-                nxt = fetch(a, tid, tile0, rounds, r + 1);
-                int bkt = kBuckets - 1;                                  // cells beyond n: last bucket, skipped in phase 3
-                if (k < a.n) {
-                    const R sst = w.sst, t_zt = w.t_zt, hum = w.hum, uu = w.uu, vv = w.vv, slp = w.slp;
-                    A q_zt;
-                    if (a.hum_type == 0) q_zt = A(hum);                                     // 'sh'
-                    else if (a.hum_type == 1) q_zt = q_air_dp<A, kPsiTabDefault>(A(hum), A(vmax(slp, R(50000.))));   // 'dp' :103
-                    else q_zt = q_air_rh<A, kPsiTabDefault>(A(hum), A(t_zt), A(vmax(slp, R(50000.))));              // 'rh' :105
-                    const A theta = theta_from_z_p0_t_q<A, kPsiTabDefault>(A(a.h.zt), A(slp), A(t_zt), q_zt);       // :118
-                    const R qsw = (R(1.) - K<R>::roce_alb0) * w.rsw;                                                  // :135,146,161
-                    s_f[0][j] = sst; s_f[1][j] = R(theta); s_f[2][j] = R(q_zt); s_f[3][j] = uu; s_f[4][j] = vv; s_f[5][j] = slp;
-                    s_f[6][j] = qsw; s_f[7][j] = w.rlw;
-                    if (a.regroup) {
-                        const bool wll = a.wl_load;
-                        bkt = forecast_bucket<ALGO, SKIN>((float)sst, (float)theta, (float)q_zt, (float)uu, (float)vv, (float)slp,
-                                                          (float)qsw, (float)w.rlw, wll, wll ? (float)a.wl0[k] : 0.f, wll ? (float)a.wl1[k] : 20.f);
-                    } else {
-                        bkt = 0;
-                    }
-                }
-                if (a.regroup) tile_sort_note(s_cnt, s_inv, j, bkt, tid);
-            }
+            tile_phase1<R, ALGO, SKIN, S, A>(a, tid, tile0, rounds, tile_fetch<R, S, SKIN>(a, tid, tile0, rounds, 0), s_f, s_cnt, s_inv);
         }
         sync();
         // ---- phase 2: who computes which cell; thread 0 asks for the team's next tile
         {
             AB_ARGS;
             if (tid == 0) *s_tile = grab(a, false);      // (every thread of the team has read the current one before the barrier above)
-            if (a.regroup) {
-                tile_sort_place<2>(s_cnt, s_base, s_inv, tid, rounds, sync);
-                tile_sort_reset(s_cnt, tid);              // (behind the barrier inside tile_sort_place: the counts have been read) for the next tile
-            } else {
-                for (int r = 0; r < rounds; ++r) s_inv[r * kBlock + tid] = (unsigned short)(r * kBlock + tid);
-            }
+            tile_phase2<2>(a, tid, rounds, s_cnt, s_base, s_inv, sync);
         }
         sync();
         // ---- phase 3: groups of 64 sorted cells, fetched from the team's queue
-        {
-            AB_ARGS;
-            AB_DIAGS;
-            const int lane = tid & 63;
-            const Heights<R> hh = detached(a.h);
-            int nb_iter = a.nb_iter;
-            uniform_scalar(nb_iter);
-#pragma unroll 1
-            for (;;) {
-                int g = 0;
-                if (lane == 0) g = atomicAdd(s_next, 1);
-                g = __builtin_amdgcn_readfirstlane(g);
-                if (g >= rounds * (kBlock / 64)) break;
-                const int j = s_inv[g * 64 + lane];
-                const long k = tile0 + j;
-                if (k >= a.n) continue;
-                R QL, QH, tx, ty, zEvap;
-                A T_s;
-                compute_cell<R, ALGO, SKIN, false, true, S, A, 2>(a, dg, hh, nb_iter, k, A(s_f[0][j]), A(s_f[1][j]), A(s_f[2][j]), s_f[3][j], s_f[4][j], s_f[5][j],
-                                                                  s_f[6][j], s_f[7][j], QL, QH, tx, ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
-                                                                  (lds_vptr<R>)&s_f[0][j], kCells);
-                s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = R(T_s);
-            }
-        }
+        { AB_ARGS; AB_DIAGS; tile_phase3<R, ALGO, SKIN, false, S, A, 2>(a, dg, tid, tile0, rounds, s_f, s_inv, s_next); }
         sync();
         // ---- phase 4: owners store (coalesced).  No barrier behind it: phase 4 reads and the next phase 1 writes a thread's OWN tile slots, and
         // the group queue is re-armed by thread 0 two team barriers ahead of its next use
         {
             AB_ARGS;
-#pragma unroll 1
-            for (int r = 0; r < rounds; ++r) {
-                const int j = r * kBlock + tid;
-                const long k = tile0 + j;
-                if (k >= a.n) break;
-                stnt(a.ql + k, (S)s_f[0][j]);
-                stnt(a.qh + k, (S)s_f[1][j]);
-                stnt(a.tau_x + k, (S)s_f[2][j]);
-                stnt(a.tau_y + k, (S)s_f[3][j]);
-                if (a.evap) stnt(a.evap + k, (S)s_f[4][j]);                                // :208
-                if (a.t_s) stnt(a.t_s + k, (S)s_f[5][j]);                                  // :206
-            }
+            tile_phase4<R, S>(a, tid, tile0, rounds, s_f);
             if (tid == 0) *s_next = 0;
         }
     }
