@@ -129,7 +129,9 @@ int ab_session_set_humidity(ab_session *s, int hum_type);
  * WL state initialises at jt==1 and persists until jt==nt (mod_blk_coare3p6.f90:250,411).
  * AB_MEM_HOST: synchronous; returns AB_ERR_TAU if any cell exceeded 10 N/m^2.
  * AB_MEM_DEVICE: enqueued on `stream` (hipStream_t, NULL = default stream); call
- * ab_session_check() to synchronise and fetch the AB_ERR_TAU flag. */
+ * ab_session_check() to synchronise and fetch the AB_ERR_TAU flag.  The calls of ONE session must be ordered among themselves (one
+ * stream, or the caller's own dependencies between streams): they share the warm-layer state, the error flag and the tile counters
+ * of the persistent kernel.  Independent streams take independent sessions. */
 int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter,
                        const void *sst, const void *t_zt, const void *hum_zt,
                        const void *u_zu, const void *v_zu, const void *slp,
