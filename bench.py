@@ -690,6 +690,39 @@ def main():
     # ingress exposed one after the other), and with the fluxes left where they were computed
     elapsed_exposed = timed(a.steps, True, False) if (gathered and not a.no_pipeline_gather) else None
     elapsed_resident = timed(a.steps, False) if gathered else None
+    # ... and the same without the row chunks either: a model that leaves its fluxes distributed launches ONE kernel per rank and
+    # algorithm over the rank's whole block (the chunks exist to overlap the gather; on their own they only make the launches smaller)
+    elapsed_resident_whole = None
+    if gathered and chunks > 1 and njl > 0:
+        whole = []
+        obuf = torch.zeros((npass, nout, n_local), dtype=tdt, device=dev)
+        for p, (algo, skin) in enumerate(passes):
+            sess = ab.Session(algo, ni, njl, 1, skin, precision=precision, device=dev_index)
+            sess.set_humidity("sh")
+            whole.append((sess, [f[k][:n_local] for k in IN6], (f["rad_sw"][:n_local], f["rad_lw"][:n_local]) if skin else (None, None),
+                          {k: obuf[p, i] for i, k in enumerate(names) if (k != "T_s" or skin)}, skin))
+
+        def step_whole():
+            for sess, ins, rad, out, skin in whole:
+                sess.compute(1, zt, zu, *ins, Niter=niter, rad_sw=rad[0], rad_lw=rad[1], out=out, want_T_s=skin, check=False)
+        for _ in range(3):
+            step_whole()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step_whole()
+        sync()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_resident_whole = float(t.item())
+        for w_ in whole:
+            w_[0].close()
+    elif gathered and chunks > 1:      # (a rank without rows still joins the reduction)
+        sync()
+        t = torch.zeros(1, dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_resident_whole = float(t.item())
 
     # per-launch kernel duration: HIP events recorded by the library around each launch, on the launch stream.
     # Reading an event pair synchronises, so this is a separate pass over the same inputs (not in `elapsed`).
@@ -784,6 +817,12 @@ def main():
             res["resident"] = {"value": round(npass * cells * a.steps / elapsed_resident / 1e6, 2), "unit": "Mcell/s",
                                "ms_per_step": round(elapsed_resident / a.steps * 1e3, 4),
                                "note": "the same K steps with the fluxes left on the GPU that computed them (no gather)"}
+            if elapsed_resident_whole:
+                res["resident"]["chunked"] = dict(res["resident"])
+                res["resident"].update(value=round(npass * cells * a.steps / elapsed_resident_whole / 1e6, 2),
+                                       ms_per_step=round(elapsed_resident_whole / a.steps * 1e3, 4),
+                                       note="K steps of ONE launch per rank and algorithm over the rank's whole block, fluxes left on the GPU that computed "
+                                            "them: what a model with distributed fields gets (`chunked`: the same with the row chunks of the gathered run)")
         if verify_msg:
             res["verify"] = verify_msg
         res["precision_mode"] = {"f64": "AB_F64", "f32": "AB_F32", "f32_storage": "AB_F32_STORAGE", "f32_mixed": "AB_F32_MIXED"}[precision]
