@@ -343,7 +343,13 @@ __global__ void __launch_bounds__(kBlock, (DIAG ? AB_WAVES_PER_EU : Tile<R, ALGO
 #ifdef AB_PSI_NOBITS
                 psi_coare_lds_fill<false>();
 #endif
-            } else psi_coare_lds_fill();
+            } else {
+#ifdef AB_NOSKIN_PSI_LOGTAB
+                psi_coare_lds_fill();
+#else
+                psi_bits_lds_fill();
+#endif
+            }
         }
         else { psi_tables_fill<SKIN>(); if constexpr (ALGO == 5) andreas_stab_fill(); }
     }

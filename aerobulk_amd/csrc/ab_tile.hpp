@@ -57,6 +57,15 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFl
 #ifndef AB_COARE3P0_NOSKIN_OCC   // COARE 3.0 without the skin schemes: 96 VGPRs + 36 B of scratch at five waves once its psi comes from the L1 tables; four waves, no scratch: -12 % against -8 %
 #define AB_COARE3P0_NOSKIN_OCC 4
 #endif
+// COARE 3.6 without the skin schemes (round 4): its psi tables indexed by the bits of their argument (no logarithm: 16 % of its short
+// iteration) are 2 x 6 400 B: two-round tiles fit beside them at FOUR blocks per CU, not at five
+#ifndef AB_COARE3P6_NOSKIN_OCC
+#ifdef AB_NOSKIN_PSI_LOGTAB
+#define AB_COARE3P6_NOSKIN_OCC AB_NOSKIN_OCC
+#else
+#define AB_COARE3P6_NOSKIN_OCC 4
+#endif
+#endif
 #ifndef AB_F32_OCC
 #define AB_F32_OCC 7
 #endif
@@ -79,7 +88,7 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFl
 #endif
     static constexpr int kOcc = POLICY == kTileFour ? 4
                                 : MIXED ? (SKIN ? (ALGO == 4 ? AB_MIXED_OCC : AB_MIXED_COARE_OCC) : AB_MIXED_NOSKIN_OCC)
-                                : sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : ((ALGO == 1 && AB_COARE3P0_NOSKIN_OCC) ? AB_COARE3P0_NOSKIN_OCC : AB_NOSKIN_OCC))
+                                : sizeof(R) == 8 ? (SKIN ? AB_WAVES_PER_EU : ((ALGO == 1 && AB_COARE3P0_NOSKIN_OCC) ? AB_COARE3P0_NOSKIN_OCC : (ALGO == 2 ? AB_COARE3P6_NOSKIN_OCC : AB_NOSKIN_OCC)))
                                                : (SKIN ? (ALGO == 4 ? AB_F32_ECMWF_OCC : AB_F32_OCC) : AB_F32_NOSKIN_OCC);
     static constexpr int kWaves = kOcc * 256 / kBlock;      // resident blocks per CU
     // The kWaves blocks of a CU share its 160 KB of LDS (allocated in 512-byte granules: tools/micro/lds_granule.hip).  Per block, besides
@@ -89,12 +98,17 @@ template <class R, int ALGO, bool SKIN, bool MIXED = false, int POLICY = kTileFl
     // the Kansas psi_m / psi_h pair (2 x 1 792 B: ECMWF, ANDREAS; ANDREAS + 800 B: its stable psi_m) or, COARE: with the skin schemes the cool skin's g(u) (1 280 B) and the
     // blended psi_h (2 560 B; psi_m through L1, ab_gtables.hpp), without them psi_m and psi_h (2 x 2 560 B); fp32: the three psi tables
     // (1 536 B; + e_sat: mixed).  The fp64 COARE kernels with the skin schemes come out at exactly two rounds with 24 B to spare.
+#ifdef AB_NOSKIN_PSI_LOGTAB
+#define AB_COARE_NOSKIN_TAB_BYTES 5120    // the blended psi_m / psi_h in s = LOG(y), degree 9 x 32 intervals (round 3)
+#else
+#define AB_COARE_NOSKIN_TAB_BYTES 12800   // ... indexed by the bits of y, degree 9 x 8 intervals per binade (round 4)
+#endif
 #ifdef AB_PSI_NOBITS
 #define AB_COARE_SKIN_TAB_BYTES 3840   // g(u) 1 280 B + the blended psi_h 2 560 B (round 3)
 #else
 #define AB_COARE_SKIN_TAB_BYTES 3584   // the cool skin's T(u) table (degree 7 x 56 intervals); psi_m and psi_h through L1, indexed by the bits of their argument (round 4)
 #endif
-    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? AB_COARE_SKIN_TAB_BYTES : 5120) : (ALGO == 5 ? 4384 : 3584)) : (MIXED ? 3072 : 1536));
+    static constexpr int kPsiTabBytes = POLICY == kTileFour ? 0 : (sizeof(R) == 8 ? (SKIN ? 1536 : 0) + ((ALGO == 1 || ALGO == 2) ? (SKIN ? AB_COARE_SKIN_TAB_BYTES : AB_COARE_NOSKIN_TAB_BYTES) : (ALGO == 5 ? 4384 : 3584)) : (MIXED ? 3072 : 1536));
     static constexpr int kBudget = 160 * 1024 / kWaves - 160 - ((sizeof(R) == 8 || MIXED) ? 1632 : 0) - kPsiTabBytes;
     static constexpr int kRounds = kBudget / (kBlock * (kFields * (int)sizeof(R) + 2)); // f64: 2 (skin, 4 blocks) / 2 (5 blocks); f32: 2
     static constexpr int kCells = kRounds * kBlock;

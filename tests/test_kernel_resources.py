@@ -68,7 +68,7 @@ def test_lds_of_the_resident_blocks_fits_the_cu(remarks):
             assert v["LDS"] < (6144 if r == "d" else 4096)   # NCAR: direct kernel, math tables (+ fp64: the Kansas psi_m / psi_h pair, 3.5 KB)
             continue
         if r == "d":
-            occ = 4 if (skin or diag or algo == 1) else 5  # Tile::kOcc; the DIAG instantiations are launched for four waves, COARE 3.0 without skin too
+            occ = 4 if (skin or diag or algo in (1, 2)) else 5  # Tile::kOcc; the DIAG instantiations are launched for four waves, COARE without skin too (its bit-indexed psi tables: 12.8 KB)
         elif a == "d":                        # mixed: fp32 work, fp64 anchors
             occ = 4 if diag else ((6 if algo == 4 else 5) if skin else 7)
         else:
