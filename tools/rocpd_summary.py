@@ -23,6 +23,14 @@ def summarise(db):
              f"sum(d.end-d.start)/1e6 from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 6 desc")
     for r in rows:
         print(f"{r[0][:90]:90s} {r[1]:6d} {r[2]:12.3f} {r[3]:12.3f} {r[4]:12.3f} {r[5]:10.3f}")
+    # bench.py launches its pre-roll (clock ramp: the first launches of a process run 5-30 % slow) and warm-up before the K timed steps and the
+    # K launches of the event pass: the average of the LAST 2K dispatches is the figure to hold against the bench line's ms_per_step
+    for name, n in q(f"select s.kernel_name, count(*) from {kd} d join {ks} s on d.kernel_id=s.id where s.kernel_name like '%flux_kernel%' "
+                     f"group by s.kernel_name having count(*) >= 30"):
+        durs = [r[0] for r in q(f"select (d.end-d.start)/1e3 from {kd} d join {ks} s on d.kernel_id=s.id where s.kernel_name='{name}' order by d.start")]
+        tail = durs[-20:]
+        print(f"{name[:90]:90s} last {len(tail)} dispatches (timed steps + event pass): avg_us {sum(tail) / len(tail):.3f}  "
+              f"first {len(durs) - len(tail)} (pre-roll, warm-up): avg_us {sum(durs[:-20]) / max(len(durs) - 20, 1):.3f}")
     rows = q(f"select s.kernel_name, p.name, sum(e.value), count(distinct d.id) from {pe} e join {pi} p on e.pmc_id=p.id "
              f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id group by s.kernel_name, p.name")
     if rows:

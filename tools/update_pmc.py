@@ -39,6 +39,7 @@ def main():
         "valu_insts_per_cell": val("SQ_INSTS_VALU") * 64 / cells,   # wave instructions x 64 lanes / cells
         "valu_busy": val("SQ_ACTIVE_INST_VALU") * 4 / (1024 * val("GRBM_GUI_ACTIVE") / 8),
         "kernel_us_rocprof_avg": avg_us,
+        "kernel_us_timed_region": float(re.search(r"last \d+ dispatches[^:]*: avg_us ([0-9.]+)", txt).group(1)),   # without the pre-roll / warm-up launches
         "kernel_us_pmc_pass": durs[2] if len(durs) > 2 else avg_us,   # duration in the pass that counted the fp64 instructions
         "source_hash": bench.kernel_source_hash(),
         "fp64_insts_per_launch": {k: val(f"SQ_INSTS_VALU_{k.upper()}_F64") for k in ("fma", "mul", "add", "trans")},
