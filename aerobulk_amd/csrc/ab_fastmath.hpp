@@ -289,9 +289,12 @@ AB_TAB double kLogTab[2 * kLogN] = {
     0.7190232141607429, 0.32986163504969085, 0.7110349232870385, 0.34103373183800156};
 #define AB_LOGQ -0.500000000000001, 0.3333333333333342, -0.2499999997172448, 0.19999999974866162, -0.16667855714108057, 0.14286771218144256   /* Q, degree 5 */
 #if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
-static __shared__ __attribute__((aligned(16))) double s_logtab[2 * kLogN];
-static __shared__ double s_exptab[kExpN];
-static __shared__ double s_ctab[kC_N];
+// LDS tables carry a larger alignment than the kernels' tile arrays: the layout sorts by alignment, so the tables take the LOWEST addresses and
+// every lookup's base fits the 16-bit offset field of ds_read (flux_kernel_cu's tiles fill 128 KB: above them each base cost a v_mov_b32)
+#define AB_LDS_TABLE static __shared__ __attribute__((aligned(64)))
+AB_LDS_TABLE double s_logtab[2 * kLogN];
+AB_LDS_TABLE double s_exptab[kExpN];
+AB_LDS_TABLE double s_ctab[kC_N];
 // every kernel that may evaluate a log calls this first (all threads of a block of at least 2 kLogN = 128), then __syncthreads().
 // The three loads of a thread are issued together and waited for once (three copy loops meant three round trips to the constant
 // cache at the start of every block: visible in the kernels with short-lived blocks, NCAR above all).

@@ -31,6 +31,7 @@ template <class R, class S = R> struct FluxArgs {
     int rounds;   // tile = rounds*256 cells (<= Tile<R,ALGO,SKIN>::kRounds)
     long nfull;   // tiles [0, nfull) have `rounds` rounds; the ntail tiles behind them, handed out last, one round each (launch_t)
     long ntail;
+    unsigned long long wl_live;   // bit jit-1 set where MOD(nb_iter, jit) == 0: the iterations whose WL_COARE call is live (0: nb_iter > 64, the kernel divides)
     int *queue;   // flux_kernel_cu: three tile counters in device memory (zero between launches)
 };
 
@@ -99,8 +100,8 @@ __device__ __forceinline__ void compute_cell(const FluxArgs<R, S> &a, const Diag
     CellOut<R, A> o;
     constexpr int kSkin = SKIN ? kSkinBoth : 0;   // aerobulk_compute: cool skin and warm layer together
     constexpr int kCsgLds = (TILED && sizeof(R) == 8) ? LTABS : 0;   // flux_kernel filled COARE's LDS extras (the cool skin's table with the skin schemes, the psi tables without); 2: flux_kernel_cu's CU-wide psi and WL tables too
-    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
-    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride);
+    if (ALGO == 1) turb_coare<R, false, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride, a.wl_live);
+    else if (ALGO == 2) turb_coare<R, true, kSkin, DIAG, A, kCsgLds>(hh, in, nb_iter, wl, dawn, o, park, pstride, a.wl_live);
     else if (ALGO == 3) turb_ncar<R, DIAG, A, (sizeof(R) == 8 && kPsiTabDefault)>(hh, in, nb_iter, o);   // flux_kernel's direct path filled the pair of psi tables
     else if (ALGO == 4) turb_ecmwf<R, kSkin, DIAG, A>(hh, in, nb_iter, wl, o);
     else turb_andreas<R, DIAG, A, (TILED && sizeof(R) == 8)>(hh, in, nb_iter, o);   // flux_kernel filled psi_m's stable-side table
@@ -506,6 +507,10 @@ template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipErro
     a.n = c.n;
     a.h = make_heights<R>(c.zt, c.zu);
     a.nb_iter = c.nb_iter; a.hum_type = c.hum_type; a.wl_load = c.wl_load; a.wl_store = c.wl_store;
+    a.wl_live = 0;
+    if (c.nb_iter <= 64)
+        for (int jit = 1; jit <= c.nb_iter; ++jit)
+            if (c.nb_iter % jit == 0) a.wl_live |= 1ull << (jit - 1);
     a.isecday = c.isecday;
     a.dawn_uniform = dawn_at_lon0(c.isecday);
     a.regroup = c.regroup ? 1 : 0;

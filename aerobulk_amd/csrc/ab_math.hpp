@@ -16,6 +16,14 @@
 
 #include "ab_fastmath.hpp"
 
+// First statement of a rarely taken block that must stay a BRANCH: an empty volatile asm cannot be speculated, so the block is not
+// if-converted into selects executed by every wave (host builds: nothing)
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+#define AB_KEEP_BRANCH() asm volatile("")
+#else
+#define AB_KEEP_BRANCH() ((void)0)
+#endif
+
 namespace ab {
 
 // Block prologue of every kernel whose fp64 math may take a log: fill the LDS table of fm::qlog, then a barrier.  The fp32
@@ -137,6 +145,15 @@ template <class R> __device__ __forceinline__ R rounded(R x)
         asm("" : "+r"(x));
 #endif
     }
+    return x;
+}
+// An operand of a rarely taken block whose arithmetic must stay INSIDE the block: loop-invariant code motion would otherwise hoist it in
+// front of the loop, where every wave pays for it (the volatile asm is neither hoisted nor speculated)
+template <class R> __device__ __forceinline__ R pinned(R x)
+{
+#if defined(__HIPCC__) && !defined(AB_FASTMATH_HOST)
+    if constexpr (std::is_floating_point<R>::value) asm volatile("" : "+v"(x));
+#endif
     return x;
 }
 // `0.5 + SIGN(0.5,x)` == 1  <=>  sign bit of x clear (SIGN(0.5,-0.) = -0.5 on IEEE processors)
