@@ -277,9 +277,9 @@ template <class R, class S, int CELLS> __device__ __forceinline__ void tile_phas
 // A: the anchor type (ab_physics.hpp, "ANCHORS").  A = R for the fp64 and fp32 sessions; AB_F32_MIXED is <R = float, S = float,
 // A = double>: fp32 arrays and fp32 hardware transcendentals, with SST, theta, q, T_s, q_s, their differences and q_sat in fp64.
 template <class R, int ALGO, bool SKIN, bool DIAG, class S = R, class A = R>
-// (the DIAG instantiations carry sixteen more live values: four waves per SIMD, on the tiles sized for Tile::kOcc — three for fp64 COARE with the
-// skin schemes, whose lean kernel fills its 128 registers)
-__global__ void __launch_bounds__(kBlock, (DIAG ? ((sizeof(R) == 8 && SKIN && ALGO <= 2) ? 3 : AB_WAVES_PER_EU) : Tile<R, ALGO, SKIN, !std::is_same<R, A>::value>::kOcc)) flux_kernel(const FluxArgs<R, S> a_in, const DiagArgs<S> dg_in)
+// (the DIAG instantiations carry sixteen more live values: four waves per SIMD, on the tiles sized for Tile::kOcc — three for fp64 with the
+// skin schemes, whose lean kernels fill their 128 registers)
+__global__ void __launch_bounds__(kBlock, (DIAG ? ((sizeof(R) == 8 && SKIN) ? 3 : AB_WAVES_PER_EU) : Tile<R, ALGO, SKIN, !std::is_same<R, A>::value>::kOcc)) flux_kernel(const FluxArgs<R, S> a_in, const DiagArgs<S> dg_in)
 {
     constexpr bool kMixed = !std::is_same<R, A>::value;
     if (ALGO == 3) {   // NCAR: the cheapest iteration, little divergence: the tile machinery costs more than it saves

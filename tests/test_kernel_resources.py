@@ -69,8 +69,8 @@ def test_lds_of_the_resident_blocks_fits_the_cu(remarks):
             continue
         if r == "d":
             occ = 4 if (skin or diag or algo in (1, 2)) else 5  # Tile::kOcc; the DIAG instantiations are launched for four waves, COARE without skin too (its bit-indexed psi tables: 12.8 KB)
-            if diag and skin and algo in (1, 2):
-                occ = 3                       # the diagnostics of COARE + skin on top of a lean kernel that fills its 128 registers
+            if diag and skin:
+                occ = 3                       # the diagnostics of the kernels with the skin schemes on top of lean kernels that fill their 128 registers
         elif a == "d":                        # mixed: fp32 work, fp64 anchors
             occ = 4 if diag else ((6 if algo == 4 else 5) if skin else 7)
         else:
