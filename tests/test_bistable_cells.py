@@ -23,13 +23,20 @@ ALGO, ZT, ZU, NITER, NT = "ecmwf", 10.0, 10.0, 10, 3
 MATCH = 1e-12                 # "equals a build of the reference": relative, on every flux of the cell
 
 
-def _load():
-    d = np.load(os.path.join(GOLDEN, "bistable_cells.npz"))
+# fixture file, record of the rejected value, the reference's own two answers in Q_L (relative gap between its default and its FMA build)
+# Second fixture: round-4 soak, seed 9443 (profiles/r4_fuzz.txt item 10) — a near-calm stable night cell of the same configuration, record 2,
+# rejected at 1.318 of the one-input ceiling; the kernels from before the round's last change give the same numbers.
+FIXTURES = (("bistable_cells.npz", 3, (2e-10, 3e-10)), ("bistable_cells_9443.npz", 2, (6e-10, 7.5e-10)))
+
+
+def _load(name="bistable_cells.npz"):
+    d = np.load(os.path.join(GOLDEN, name))
     return {k: d["in_" + k] for k in IN8}, {v: d["ref_" + v] for v in VARIANTS}, int(d["cell"])
 
 
-def test_the_oracle_is_the_default_build_and_the_cell_has_two_reference_answers(oracle):
-    f, ref, c = _load()
+@pytest.mark.parametrize("name,record,gap", FIXTURES)
+def test_the_oracle_is_the_default_build_and_the_cell_has_two_reference_answers(oracle, name, record, gap):
+    f, ref, c = _load(name)
     s = oracle.OracleSession(ALGO, f["sst"].size, NT, True)
     for jt in range(1, NT + 1):
         o = s.compute(jt, ZT, ZU, NITER, *[f[k] for k in IN8[:6]], rad_sw=f["rad_sw"], rad_lw=f["rad_lw"])
@@ -37,8 +44,8 @@ def test_the_oracle_is_the_default_build_and_the_cell_has_two_reference_answers(
             np.testing.assert_array_equal(o[k], ref["O2"][jt - 1, i], err_msg=f"jt={jt} {k}")     # restatement == reference, bit for bit
     np.testing.assert_array_equal(ref["O0"], ref["O2"])
     np.testing.assert_array_equal(ref["O3"], ref["O2"])
-    ql2, qlf = ref["O2"][2, 0, c], ref["O3fma"][2, 0, c]
-    assert 2e-10 < abs(qlf - ql2) / abs(ql2) < 3e-10                 # the reference's own two answers: 2.56e-10 apart in Q_L
+    ql2, qlf = ref["O2"][record - 1, 0, c], ref["O3fma"][record - 1, 0, c]
+    assert gap[0] < abs(qlf - ql2) / abs(ql2) < gap[1]               # the reference's own two answers: 2.56e-10 (6.8e-10) apart in Q_L
     others = np.delete(np.abs(ref["O3fma"] - ref["O2"]) / np.maximum(np.abs(ref["O2"]), 1e-30), c, axis=2)
     assert others.max() < 1e-12                                      # ... on this cell only: its neighbours agree to the last digits
 
@@ -52,9 +59,10 @@ def matches_a_reference_build(got, refs, tol=MATCH):
 
 
 @pytest.mark.gpu
-def test_hip_gives_one_of_the_references_own_answers():
+@pytest.mark.parametrize("name", [x[0] for x in FIXTURES])
+def test_hip_gives_one_of_the_references_own_answers(name):
     import aerobulk_amd as ab
-    f, ref, c = _load()
+    f, ref, c = _load(name)
     n = f["sst"].size
     with ab.Session(ALGO, n, 1, NT, True) as s:
         for jt in range(1, NT + 1):

@@ -70,6 +70,16 @@ def test_parity_warm_layer_carry_over(oracle, algo):
     assert np.max(np.abs(res[0][0]["t_s"] - res[2][0]["t_s"])) > 1e-6
 
 
+@pytest.mark.parametrize("niter", [6, 64, 65])
+def test_parity_warm_layer_live_iterations(oracle, niter):
+    """WL_COARE commits its state in the iterations jit with MOD(nb_iter, jit) == 0 (mod_blk_coare3p6.f90:370, mod_skin_coare.f90:239-248).
+    The kernel takes them from a 64-bit mask made on the host (FluxArgs::wl_live) and divides only beyond 64 iterations: 6 has four
+    divisors (a mask with several bits), 64 is the mask's last bit, 65 the fallback.  Two records, so that the committed state is read back."""
+    res = _run_both(oracle, "coare3p6", True, niter, 2., ni=96, nj=64, nt=2)
+    for jt, (got, ref) in enumerate(res, 1):
+        assert_hot_parity(got, ref, OUT + ("t_s",), sens=_run_both.sens, jt=jt, label=f"coare3p6 nb_iter={niter} jt={jt}")
+
+
 @pytest.mark.parametrize("hum", ["rh", "dp"])
 def test_parity_humidity_types(oracle, hum):
     f = oracle.synth_fields(200, 100)

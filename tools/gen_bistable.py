@@ -25,13 +25,24 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import pyoracle as po  # noqa: E402
 from test_gpu_fuzz import _fields  # noqa: E402
 
-SEED, ALGO, SKIN, ZT, ZU, NITER, NT, CELL = 5119, "ecmwf", True, 10.0, 10.0, 10, 3, 1805
+ALGO, SKIN, ZT, ZU, NITER, NT = "ecmwf", True, 10.0, 10.0, 10, 3
+# (seed, cell of the filtered fuzz field, record whose Q_L the metric rejected, fixture file).  Second case: round-4 soak, seed 9443 (profiles/r4_fuzz.txt
+# item 10): the same configuration, a near-calm (0.2 m/s) stable night cell, record 2: 6.8e-10 off the default build in Q_L, Q_H, Evap, 6.1e-10 in tau —
+# and the reference's FMA build to 1e-15 in every one of them; the kernels from before the round's last change give the same numbers.
+CASES = ((5119, 1805, 3, "bistable_cells.npz"), (9443, 13104, 2, "bistable_cells_9443.npz"))
 VARIANTS = ("O2", "O0", "O3", "O3fma", "fast")
 IN8 = ("sst", "t_zt", "hum_zt", "u_zu", "v_zu", "slp", "rad_sw", "rad_lw")
 OUT6 = ("ql", "qh", "tau_x", "tau_y", "evap", "t_s")
 
 
 def main():
+    which = [int(a) for a in sys.argv[1:]] or [c[0] for c in CASES]
+    for case in CASES:
+        if case[0] in which:
+            generate(*case)
+
+
+def generate(SEED, CELL, RECORD, FILE):
     n = 60000 + 13 * SEED
     f = _fields(SEED, n)
     keep = np.hypot(f["u_zu"], f["v_zu"]) < 30.0          # odd seed: as tests/test_gpu_fuzz.py::_fuzz_case
@@ -52,17 +63,18 @@ def main():
             o = s.compute(jt, ZT, ZU, NITER, *[blk[k] for k in IN8[:6]], rad_sw=blk["rad_sw"], rad_lw=blk["rad_lw"])
             rows.append(np.stack([o[k] for k in OUT6]))
         out["ref_" + tag] = np.stack(rows)
-    out["meta"] = np.array(f"seed {SEED} {ALGO} skin zt={ZT} zu={ZU} nb_iter={NITER} nt={NT}; cells {lo}..{hi - 1} of the filtered fuzz field, "
+    out["meta"] = np.array(f"seed {SEED} {ALGO} skin zt={ZT} zu={ZU} nb_iter={NITER} nt={NT} record {RECORD}; cells {lo}..{hi - 1} of the filtered fuzz field, "
                            f"the soak's cell is index {CELL - lo}; variants {','.join(VARIANTS)}; planes {','.join(OUT6)}")
     out["cell"] = np.array(CELL - lo)
-    path = os.path.join(ROOT, "tests", "golden", "bistable_cells.npz")
+    out["record"] = np.array(RECORD)
+    path = os.path.join(ROOT, "tests", "golden", FILE)
     np.savez_compressed(path, **out)
     c = CELL - lo
     base = out["ref_O2"]
     print("wrote", path)
     for v in VARIANTS[1:] + ("oracle", "oracle_fma"):
         d = out["ref_" + v] - base
-        print(f"{v:10s}: cell {CELL} record 3  dQL {d[2, 0, c]:+.4e}  dQH {d[2, 1, c]:+.4e}   other cells: max |d|/|ref| "
+        print(f"{v:10s}: cell {CELL} record {RECORD}  dQL {d[RECORD - 1, 0, c]:+.4e}  dQH {d[RECORD - 1, 1, c]:+.4e}   other cells: max |d|/|ref| "
               f"{np.max(np.abs(np.delete(d, c, axis=2)) / np.maximum(np.abs(np.delete(base, c, axis=2)), 1e-30)):.2e}")
 
 
