@@ -87,6 +87,7 @@ SYMBOLS = {
     "ab_session_last_kernel_ms": (C.c_double, [vp]),
     "ab_synth_fields_device": (C.c_int, [vp] * 8 + [C.c_long, C.c_long, C.c_long, C.c_int, vp]),
     "ab_test_math": (C.c_int, [C.c_int, dp, dp, dp, C.c_long]),
+    "ab_phymbl": (C.c_int, [C.c_int, C.c_long, C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_int, dp, C.c_int, C.c_int, vp, dp]),
     "ab_model": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_double] + [dp] * 6 + [dp] * 5
                  + [C.c_int, C.c_int, dp, dp, dp, C.c_long, C.c_long, C.POINTER(InitReport)]),
     "aerobulk_cxx_skin": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, dp, dp] + [dp] * 6 + [dp] * 5

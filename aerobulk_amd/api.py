@@ -488,3 +488,39 @@ def turb_neutral_10m(calgo, U_N10, nb_iter=5, precision="f64"):
         import torch
         torch.cuda.synchronize()
     return out
+
+
+def phymbl(fn, inputs, par0=0.0, flag=0, n_out=1, want=None):
+    """One public function of the reference's mod_phymbl (mod_phymbl.f90:33-139) on arrays: `ab_phymbl` of the C ABI.
+
+    fn: enum ab_phymbl_fn (include/aerobulk_amd.h); inputs: the function's array arguments in the reference's order, None for an
+    OPTIONAL one that is not passed (numpy: host arrays, staged; torch CUDA tensors: used in place); par0 / flag: its scalar REAL /
+    LOGICAL-or-INTEGER argument.  Returns (list of n_out arrays — None where `want` says not wanted —, info) with info =
+    (first cell beyond 10 N/m^2 or -1, its stress) for BULK_FORMULA.  Raises AerobulkError except for AB_ERR_TAU, which is reported
+    through info like BULK_FORMULA_VCTR's STOP message."""
+    lib = _lib.load()
+    first = next(x for x in inputs if x is not None)
+    dev = _is_torch(first)
+    n = int(first.numel() if dev else np.asarray(first).size)
+    pin = (C.c_void_p * len(inputs))()
+    keep = []
+    for i, x in enumerate(inputs):
+        a, k = _ptr(x, np.float64, n)
+        pin[i] = a
+        keep.append(k)
+    want = [True] * n_out if want is None else list(want)
+    if dev:
+        import torch
+        outs = [torch.empty(n, dtype=torch.float64, device=first.device) if w else None for w in want]
+        stream = torch.cuda.current_stream(first.device).cuda_stream
+    else:
+        outs = [np.empty(n, dtype=np.float64) if w else None for w in want]
+        stream = 0
+    pout = (C.c_void_p * n_out)(*[_ptr(o, np.float64, n)[0] for o in outs])
+    par = (C.c_double * 2)(float(par0), 0.0)
+    info = (C.c_double * 2)(-1.0, 0.0)
+    rc = lib.ab_phymbl(int(fn), n, pin, len(inputs), pout, n_out, par, int(flag), AB_MEM_DEVICE if dev else AB_MEM_HOST,
+                       C.c_void_p(stream or 0), info)
+    if rc and rc != AB_ERR_TAU:
+        _raise(rc)
+    return outs, (int(info[0]), float(info[1]))

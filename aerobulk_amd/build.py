@@ -40,7 +40,7 @@ def _run(cmd, **kw):
 
 
 def build_engine(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_ice_kernels.hip", "ab_runtime.hip", "ab_sharded.hip", "ab_cxx.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_ice_kernels.hip", "ab_phymbl.hip", "ab_runtime.hip", "ab_sharded.hip", "ab_cxx.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [
         os.path.join(ROOT, "include", "aerobulk_amd.h"), os.path.join(ROOT, "include", "aerobulk.hpp"), os.path.abspath(__file__)]
     if not force and not _newer(LIB, deps):
@@ -56,44 +56,77 @@ def build_engine(force=False):
     return LIB
 
 
+FC = shutil.which("amdflang") or "/opt/rocm/bin/amdflang"
+FFLAGS = ["-O2", "-fdefault-real-8"]     # default reals promoted like every build macro of the reference (arch/make.macro_GnuLinux:17)
+FDIR = os.path.join(PKG, "fortran")
+FLIB = os.path.join(FDIR, "libaerobulk_amd_fortran.a")
+# module sources in dependency order: what the reference ships as lib/libaerobulk.a + mod/*.mod (its Makefile:22-42,66-71)
+FMODS = ["mod_const", "mod_phymbl", "mod_aerobulk", "mod_blk_turb", "mod_blk_ice"]
+# the repo's own drivers (test harnesses of tests/test_turb_series.py, test_neutral10.py, test_sea_ice.py, test_gpu_hosts.py,
+# test_phymbl.py)
+FDRIVERS = ["example_call_aerobulk", "turb_series_driver", "neutral10_driver", "turb_ice_driver", "phymbl_driver"]
+REF = os.environ.get("AEROBULK_REFERENCE", "/root/reference")
+# Callers of the reference compiled UNCHANGED, where they lie, against the modules above (the drop-in check of SURVEY §8b): binaries
+# go to oracle/_ref/dropin/ (git-ignored, travels to the GPU box like the other reference builds).  Build container only.
+REF_CALLERS = ["src/tests/example_call_aerobulk.f90", "src/tests/test_cx_vs_wind.f90", "src/tests/test_coef_n10.f90",
+               "src/tests/aerobulk_toy.F90", "src/tests/test_phymbl.f90", "src/ice/test_ice.f90", "src/ice/test_aerobulk_ice.f90"]
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "dropin")
+
+
+def _link_flags(exe_dir):
+    rel = os.path.relpath(PKG, exe_dir)
+    return ["-L", PKG, "-laerobulk_amd", f"-Wl,-rpath,$ORIGIN/{rel}"]
+
+
 def build_fortran_host(force=False):
-    """From-scratch Fortran host module (mod_aerobulk) + example driver; needs amdflang."""
-    fc = shutil.which("amdflang") or "/opt/rocm/bin/amdflang"
-    if not os.path.exists(fc):
+    """From-scratch Fortran host: mod_const, mod_phymbl, mod_aerobulk, mod_blk_* (TURB_*), the sea-ice modules, as
+    libaerobulk_amd_fortran.a + *.mod, and the repo's drivers; needs amdflang."""
+    if not os.path.exists(FC):
         print("amdflang absent: Fortran host not built")
         return None
-    fdir = os.path.join(PKG, "fortran")
-    src = os.path.join(fdir, "mod_aerobulk.f90")
-    drv = os.path.join(fdir, "example_call_aerobulk.f90")
-    exe = os.path.join(fdir, "example_call_aerobulk.x")
-    if not os.path.exists(src):
-        return None
-    if force or _newer(exe, [src, drv, LIB]):
-        _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-c", src, "-o", os.path.join(fdir, "mod_aerobulk.o")])
-        _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, drv, os.path.join(fdir, "mod_aerobulk.o"),
-              "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", exe])
-    # TURB_* modules (mod_blk_coare3p6 ...) + the station time-series driver
-    tsrc = os.path.join(fdir, "mod_blk_turb.f90")
-    tdrv = os.path.join(fdir, "turb_series_driver.f90")
-    texe = os.path.join(fdir, "turb_series_driver.x")
-    if force or _newer(texe, [src, tsrc, tdrv, LIB]):
-        _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-I", fdir, "-c", tsrc, "-o", os.path.join(fdir, "mod_blk_turb.o")])
-        _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, tdrv, os.path.join(fdir, "mod_blk_turb.o"),
-              os.path.join(fdir, "mod_aerobulk.o"), "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", texe])
-    ndrv = os.path.join(fdir, "neutral10_driver.f90")
-    nexe = os.path.join(fdir, "neutral10_driver.x")
-    if force or _newer(nexe, [src, tsrc, ndrv, LIB]):
-        _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, ndrv, os.path.join(fdir, "mod_blk_turb.o"),
-              os.path.join(fdir, "mod_aerobulk.o"), "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", nexe])
-    # sea-ice modules (mod_blk_ice_nemo ...) + their driver
-    isrc = os.path.join(fdir, "mod_blk_ice.f90")
-    idrv = os.path.join(fdir, "turb_ice_driver.f90")
-    iexe = os.path.join(fdir, "turb_ice_driver.x")
-    if force or _newer(iexe, [src, isrc, idrv, LIB]):
-        _run([fc, "-O2", "-fdefault-real-8", "-module-dir", fdir, "-I", fdir, "-c", isrc, "-o", os.path.join(fdir, "mod_blk_ice.o")])
-        _run([fc, "-O2", "-fdefault-real-8", "-I", fdir, idrv, os.path.join(fdir, "mod_blk_ice.o"),
-              os.path.join(fdir, "mod_aerobulk.o"), "-L", PKG, "-laerobulk_amd", "-Wl,-rpath,$ORIGIN/..", "-o", iexe])
-    return exe
+    srcs = [os.path.join(FDIR, m + ".f90") for m in FMODS]
+    objs = [os.path.join(FDIR, m + ".o") for m in FMODS]
+    if force or _newer(FLIB, srcs + [os.path.abspath(__file__)]):
+        for src, obj in zip(srcs, objs):      # serial: each module needs the .mod files of the previous ones
+            _run([FC, *FFLAGS, "-fPIC", "-module-dir", FDIR, "-I", FDIR, "-c", src, "-o", obj])
+        if os.path.exists(FLIB):
+            os.remove(FLIB)
+        _run(["/opt/rocm/lib/llvm/bin/llvm-ar", "rcs", FLIB, *objs])
+    for d in FDRIVERS:
+        src, exe = os.path.join(FDIR, d + ".f90"), os.path.join(FDIR, d + ".x")
+        if force or _newer(exe, [src, FLIB, LIB]):
+            _run([FC, *FFLAGS, "-I", FDIR, src, FLIB, *_link_flags(FDIR), "-o", exe])
+    return FLIB
+
+
+def build_reference_callers(force=False):
+    """The reference's own drivers, unmodified, compiled from /root/reference against THIS repo's modules and library."""
+    if not os.path.exists(FC) or not os.path.isdir(os.path.join(REF, "src")):
+        print("reference tree or amdflang absent: reference callers not built (prebuilt oracle/_ref/dropin/*.x are used if present)")
+        return []
+    os.makedirs(DROPIN, exist_ok=True)
+    built = []
+    for rel in REF_CALLERS:
+        src = os.path.join(REF, rel)
+        exe = os.path.join(DROPIN, os.path.splitext(os.path.basename(rel))[0].replace("+", "_") + ".x")
+        if force or _newer(exe, [src, FLIB, LIB]):
+            try:
+                _run([FC, *FFLAGS, "-I", FDIR, "-module-dir", DROPIN, src, FLIB, *_link_flags(DROPIN), "-o", exe])
+            except subprocess.CalledProcessError:
+                # drivers written in a dialect amdflang rejects whatever they are linked against (iargc() undeclared ...): reported,
+                # not fatal; the API example must build
+                if rel == REF_CALLERS[0]:
+                    raise
+                print(f"reference caller {rel}: does not compile with {os.path.basename(FC)} (see message above)", flush=True)
+                continue
+        built.append(exe)
+    # the C++ example against include/aerobulk.hpp
+    src = os.path.join(REF, "src", "tests", "example_call_aerobulk.cpp")
+    exe = os.path.join(DROPIN, "example_call_aerobulk_cxx.x")
+    if force or _newer(exe, [src, LIB, os.path.join(ROOT, "include", "aerobulk.hpp")]):
+        _run(["g++", "-std=c++11", "-O2", "-I", os.path.join(ROOT, "include"), src, *_link_flags(DROPIN), "-o", exe])
+    built.append(exe)
+    return built
 
 
 def build_cxx_example(force=False):
@@ -114,6 +147,7 @@ def build_all(force=False):
     build_engine(force)
     build_fortran_host(force)
     build_cxx_example(force)
+    build_reference_callers(force)
     build_oracle()
 
 

@@ -11,28 +11,13 @@
 ! (-fdefault-real-8, arch/make.macro_GnuLinux:17):
 !    amdflang -O2 -fdefault-real-8 -c mod_aerobulk.f90
 !
-! A minimal `mod_const` (kinds + the constants callers of the reference commonly import: wp, rt0, ...)
-! is provided in this file for source compatibility of such callers (reference: src/mod_const.f90:10-12,60).
-
-MODULE mod_const
-   IMPLICIT NONE
-   PUBLIC
-   INTEGER, PARAMETER :: sp = SELECTED_REAL_KIND( 6, 37)
-   INTEGER, PARAMETER :: dp = SELECTED_REAL_KIND(12,307)
-   INTEGER, PARAMETER :: wp = dp
-   REAL(wp), PARAMETER :: rt0  = 273.15_wp   ! freezing point of fresh water [K]
-   REAL(wp), PARAMETER :: grav = 9.8_wp
-   REAL(wp), PARAMETER :: Patm = 101000._wp
-   INTEGER,  PARAMETER :: nit000 = 1          ! first time step                                  (mod_const.f90:21)
-   INTEGER,  SAVE      :: nitend = 1          ! last time step; AEROBULK_INIT sets it to Nt      (mod_const.f90:22)
-   INTEGER,  SAVE      :: nb_iter = 5         ! iterations of the bulk algorithms, set by `Niter` (mod_const.f90:33)
-END MODULE mod_const
-
+! `mod_const` (kinds, constants, nb_iter / nitend ...) and `mod_phymbl` (the helper functions) are modules of their own next to this
+! file (mod_const.f90, mod_phymbl.f90), like in the reference.
 
 MODULE mod_aerobulk
 
    USE, INTRINSIC :: ISO_C_BINDING
-   USE mod_const, ONLY: wp, nb_iter, nitend
+   USE mod_const, ONLY: wp, nb_iter, nitend, l_use_skin_schemes, ctype_humidity
 
    IMPLICIT NONE
    PRIVATE
@@ -256,6 +241,18 @@ CONTAINS
             &              C_LOC(o1), C_LOC(o2), C_LOC(o3), C_LOC(o4), C_LOC(o5),                                               &
             &              INT(nb_iter,C_INT), MERGE(1_C_INT, 0_C_INT, lskin), cr1, cr2, co6,                               &
             &              INT(Ni,C_LONG), INT(Nj,C_LONG), rep )
+         !! the module variables AEROBULK_INIT sets in the reference (mod_aerobulk.f90:74,127), for callers that read mod_const
+         IF( (jt==1) .AND. ((istat==0).OR.(istat==8)) ) THEN
+            IF( lskin ) l_use_skin_schemes = .TRUE.        ! (never cleared there either)
+            SELECT CASE( rep%hum_type )
+            CASE(0)
+               ctype_humidity = 'sh'
+            CASE(1)
+               ctype_humidity = 'dp'
+            CASE(2)
+               ctype_humidity = 'rh'
+            END SELECT
+         END IF
          !! banner first (the reference prints it before computing), then a possible STOP
          IF( (jt==1) .AND. ((istat==0).OR.(istat==8)) ) CALL print_init_banner( calgo, Ni, Nj, Nt, lskin, rep )
          IF( istat /= 0 ) CALL stop_with_library_message()

@@ -273,6 +273,67 @@ int ab_ice_algo_from_string(const char *calgo);
 int ab_turb_ice_easy(double zt, double zu, int nb_iter, double CdN, double ChN, double CeN, const ab_ice_fields *f, long n,
                      int precision, int mem, void *stream);
 
+/* ---- the public helper functions of mod_phymbl -------------------------------------------------------------------------------
+ * What callers of the reference import with `USE mod_phymbl` next to aerobulk_model (generics mod_phymbl.f90:33-139; e.g.
+ * src/tests/example_call_aerobulk.f90:7,59 Theta_from_z_P0_T_q, aerobulk_toy.F90, test_cx_vs_wind.f90, the sea-ice drivers), as ONE
+ * elementwise entry: function `fn` on n cells.  The Fortran module aerobulk_amd/fortran/mod_phymbl.f90 binds every `_sclr` / `_vctr`
+ * specific of the reference to it; a scalar call is n = 1 (the library has no host arithmetic).
+ *   in[0..n_in)   the function's ARRAY arguments in the order of the reference's dummy arguments with the scalars taken out;
+ *                 an OPTIONAL array that is not passed is NULL (or beyond n_in)
+ *   out[0..n_out) the results; NULL members are not written (at least one must be given)
+ *   par[0]        the function's scalar REAL argument if it has one: pz / pzu, or pPref when in[2] is NULL (pot_temp, abs_temp);
+ *                 par[1] reserved (pass 0)
+ *   flag          its LOGICAL / INTEGER argument: l_ice (0 / 1), iflag of z0tq_LKB (1 temperature, 2 humidity)
+ *   mem           AB_MEM_HOST: arrays staged through HBM; AB_MEM_DEVICE: device arrays, enqueued on `stream` (hipStream_t).  Both
+ *                 return when the results are complete.
+ *   info          may be NULL; AB_PH_BULK_FORMULA: info[0] = index of the first cell whose wind stress exceeds 10 N/m^2 (-1: none),
+ *                 info[1] = that stress; the call then returns AB_ERR_TAU with every output written (BULK_FORMULA_VCTR's STOP,
+ *                 mod_phymbl.f90:1250-1253)
+ * fn (arrays in ; scalar ; arrays out), reference lines in mod_phymbl.f90: */
+enum ab_phymbl_fn {
+    AB_PH_POT_TEMP = 1,             /* pTa, pPz, [pPref] ; pPref ; theta                     :163-200 */
+    AB_PH_ABS_TEMP = 2,             /* pThta, pPz, [pPref] ; pPref ; T                       :205-242 */
+    AB_PH_VIRT_TEMP = 3,            /* pTa, pqa ; - ; T_v                                    :247-276 */
+    AB_PH_PZ_FROM_P0_TZ_QZ = 4,     /* pslp, pTa, pqa ; pz, l_ice ; P(z)                     :283-337 */
+    AB_PH_THETA_FROM_Z_P0_T_Q = 5,  /* pslp, pTa, pqa ; pz, l_ice ; theta                    :343-375 */
+    AB_PH_T_FROM_Z_P0_THETA_Q = 6,  /* pslp, pThta, pqa ; pz, l_ice ; T                      :380-421 */
+    AB_PH_RHO_AIR = 7,              /* pTa, pqa, pslp ; - ; rho                              :522-546 */
+    AB_PH_VISC_AIR = 8,             /* pTa ; - ; nu                                          :549-574 */
+    AB_PH_L_VAP = 9,                /* psst ; - ; L_v                                        :579-598 */
+    AB_PH_CP_AIR = 10,              /* pqa ; - ; Cp                                          :603-622 */
+    AB_PH_GAMMA_MOIST = 11,         /* pTa, pqa ; - ; moist lapse rate                       :627-661 */
+    AB_PH_ONE_ON_L = 12,            /* pThta, pqa, pus, pts, pqs ; - ; 1/L                   :666-708 */
+    AB_PH_RI_BULK = 13,             /* psst, pThta, pssq, pqa, pub, [pTa_layer, pqa_layer] ; pz ; Ri_b   :712-772 */
+    AB_PH_E_SAT = 14,               /* pTa ; - ; e_s over water [Pa]                         :777-811 */
+    AB_PH_E_SAT_ICE = 15,           /* pTa ; - ; e_s over ice                                :815-843 */
+    AB_PH_DE_SAT_DT_ICE = 16,       /* pTa ; - ; d e_s,ice / dT                              :845-875 */
+    AB_PH_Q_SAT = 17,               /* pTa, pslp ; l_ice ; q_s                               :881-921 */
+    AB_PH_DQ_SAT_DT_ICE = 18,       /* pTa, pslp ; - ; d q_s,ice / dT                        :926-958 */
+    AB_PH_Q_AIR_RH = 19,            /* prha [%], pTa, pslp ; - ; q                           :963-985 */
+    AB_PH_Q_AIR_DP = 20,            /* da, slp ; - ; q                                       :990-1000 */
+    AB_PH_RHO_AIR_ADV = 21,         /* pTa, pqa, pslp ; - ; rho (true virtual temperature)   :1008-1024 */
+    AB_PH_Q_SAT_CRUDE = 22,         /* pts, prhoa ; - ; q_s                                  :1029-1038 */
+    AB_PH_DRY_STATIC_ENERGY = 23,   /* pTa, pqa ; pz ; s                                     :1043-1054 */
+    AB_PH_UPDATE_QNSOL_TAU = 24,    /* pts, pqs, pThta, pqa, pust, ptst, pqst, pwnd, pUb, pslp, prlw ; pzu ; pQns, pTau, Qlat   :1059-1144 */
+    AB_PH_BULK_FORMULA = 25,        /* pts, pqs, pThta, pqa, pCd, pCh, pCe, pwnd, pUb, pslp ; pzu, l_ice ; pTau, pQsen, pQlat, pEvap, prhoa   :1149-1261 */
+    AB_PH_ALPHA_SW = 26,            /* psst ; - ; alpha                                      :1267-1286 */
+    AB_PH_QLW_NET = 27,             /* pdwlw, pts ; l_ice ; net long-wave                    :1291-1330 */
+    AB_PH_Z0_FROM_CD = 28,          /* pCd, [ppsi] ; pzu ; z0                                :1335-1366 */
+    AB_PH_Z0_FROM_USTAR = 29,       /* pus, puzu ; pzu ; z0                                  :1371-1391 */
+    AB_PH_CD_FROM_Z0 = 30,          /* pz0, [ppsi] ; pzu ; Cd                                :1396-1414 */
+    AB_PH_F_M_LOUIS = 31,           /* pRib, pCdn, pz0 ; pzu ; f_m                           :1419-1453 */
+    AB_PH_F_H_LOUIS = 32,           /* pRib, pChn, pz0 ; pzu ; f_h                           :1458-1492 */
+    AB_PH_UN10_FROM_USTAR = 33,     /* pUzu, pus, ppsi ; pzu ; UN10                          :1498-1510 */
+    AB_PH_UN10_FROM_CDN = 34,       /* pUb, pCdn, ppsi ; pzu ; UN10                          :1515-1527 */
+    AB_PH_UN10_FROM_CD = 35,        /* pUb, pCd, ppsi ; pzu ; UN10                           :1532-1558 */
+    AB_PH_Z0TQ_LKB = 36,            /* pRer, pz0 ; iflag ; z0t | z0q                         :1635-1701 */
+    AB_PH_E_AIR = 37,               /* pqa, pslp ; - ; e  (fixed point on the WHOLE array: SUM |change| <= 1e-6)   :1706-1736 */
+    AB_PH_RH_AIR = 38,              /* pqa, pTa, pslp ; - ; RH [%]                           :1741-1753 */
+    AB_PH_DELTA_SKIN_LAYER = 39     /* palpha, pQd, pustar_a, [Qlat] ; - ; delta             :2010-2046 */
+};
+int ab_phymbl(int fn, long n, const double *const *in, int n_in, double *const *out, int n_out, const double *par, int flag,
+              int mem, void *stream, double *info);
+
 /* Copy the persistent warm-layer state (planes dT_wl, Hz_wl, Qnt_ac, Tau_ac; ECMWF uses the
  * first two) to host doubles — diagnostics pdT_wl/pHz_wl of TURB_COARE3P6, mod_blk_coare3p6.f90:406-407. */
 int ab_session_get_wl_state(ab_session *s, double *state4n);

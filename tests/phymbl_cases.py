@@ -1,0 +1,153 @@
+"""Inputs and call table of the mod_phymbl helper tests (tests/test_phymbl.py, tools/gen_phymbl_golden.py).
+
+COLUMNS: the 29 columns aerobulk_amd/fortran/phymbl_driver.f90 reads, in its order.  CALLS: for every array record that driver
+writes, the `ab_phymbl` call (include/aerobulk_amd.h) that must reproduce it: (fn, par0, flag, input columns | None, index of the
+output).  The same table drives the C ABI on the GPU and the host instantiation of the product header (tests/phymbl_host.cpp)."""
+import numpy as np
+
+COLUMNS = ["Ta", "Ts", "P", "qa", "qs", "Th", "Pz", "us", "tst", "qst", "W", "Ub", "Cd", "Ch", "Ce", "psi", "z0", "Rib", "rlw", "rh",
+           "dp", "rho", "Rer", "alp", "Qd", "Qlt", "Tly", "qly", "Ti"]
+Z_T, Z_U = 2.0, 10.0       # the driver's pz and pzu
+PATM = 101000.0
+
+
+def _qsat_approx(t, p):
+    e = 611.2 * np.exp(17.67 * (t - 273.15) / (t - 29.65))
+    return 0.622 * e / (p - 0.378 * e)
+
+
+def make_columns(n=512, seed=20251003):
+    """Physically plausible, independent draws; the first cells also feed the scalar specifics."""
+    g = np.random.default_rng(seed)
+    u = lambda lo, hi: g.uniform(lo, hi, n)
+    c = {}
+    c["Ta"] = u(250., 310.)
+    c["Ts"] = u(271., 305.)
+    c["P"] = u(96000., 104000.)
+    c["qa"] = u(0.3, 0.95) * _qsat_approx(c["Ta"], c["P"])
+    c["qs"] = 0.98 * _qsat_approx(c["Ts"], c["P"])
+    c["Th"] = c["Ta"] + u(0.0, 0.15)
+    c["Pz"] = c["P"] * (1. - u(1e-4, 1.5e-3))
+    c["us"] = u(0.01, 1.0)
+    c["tst"] = u(-0.5, 0.5)
+    c["qst"] = u(-5e-4, 5e-4)
+    c["W"] = u(0.5, 30.)
+    c["Ub"] = np.sqrt(c["W"] ** 2 + u(0., 1.) ** 2)
+    c["Cd"] = u(0.5e-3, 3e-3)
+    c["Ch"] = u(0.5e-3, 2e-3)
+    c["Ce"] = u(0.5e-3, 2e-3)
+    c["psi"] = u(-2., 2.)
+    c["z0"] = 10. ** u(-5., -2.)
+    c["Rib"] = u(-2., 2.)
+    c["rlw"] = u(200., 450.)
+    c["rh"] = u(20., 100.)
+    c["dp"] = u(240., 300.)
+    c["rho"] = u(1.0, 1.4)
+    c["Rer"] = 10. ** u(-3., 4.)          # beyond 1000: z0tq_LKB's out-of-range branch
+    c["alp"] = u(5e-5, 3.5e-4)
+    c["Qd"] = u(-400., 50.)               # > 0: the warming branch of delta_skin_layer
+    c["Qlt"] = u(-300., 20.)
+    c["Tly"] = c["Ta"] + u(-1., 1.)
+    c["qly"] = c["qa"] * u(0.9, 1.1)
+    c["Ti"] = u(230., 272.)
+    return np.stack([c[k] for k in COLUMNS], axis=0)     # (29, n)
+
+
+# enum ab_phymbl_fn
+(POT_TEMP, ABS_TEMP, VIRT_TEMP, PZ, THETA, TABS, RHO_AIR, VISC_AIR, L_VAP, CP_AIR, GAMMA_MOIST, ONE_ON_L, RI_BULK, E_SAT, E_SAT_ICE,
+ DE_SAT_DT_ICE, Q_SAT, DQ_SAT_DT_ICE, Q_AIR_RH, Q_AIR_DP, RHO_AIR_ADV, Q_SAT_CRUDE, DRY_STATIC_ENERGY, UPDATE_QNSOL_TAU, BULK_FORMULA,
+ ALPHA_SW, QLW_NET, Z0_FROM_CD, Z0_FROM_USTAR, CD_FROM_Z0, F_M_LOUIS, F_H_LOUIS, UN10_FROM_USTAR, UN10_FROM_CDN, UN10_FROM_CD, Z0TQ_LKB,
+ E_AIR, RH_AIR, DELTA_SKIN) = range(1, 40)
+
+_UQT = ["Ts", "qs", "Th", "qa", "us", "tst", "qst", "W", "Ub", "P", "rlw"]
+_BF = ["Ts", "qs", "Th", "qa", "Cd", "Ch", "Ce", "W", "Ub", "P"]
+_BFI = ["Ti"] + _BF[1:]
+
+# record of phymbl_driver.f90 -> (fn, par0, flag, inputs, output index)
+CALLS = {
+    "pot_temp": (POT_TEMP, PATM, 0, ["Ta", "Pz"], 0),
+    "pot_temp_pref": (POT_TEMP, PATM, 0, ["Ta", "Pz", "P"], 0),
+    "abs_temp": (ABS_TEMP, PATM, 0, ["Th", "Pz"], 0),
+    "abs_temp_pref": (ABS_TEMP, PATM, 0, ["Th", "Pz", "P"], 0),
+    "virt_temp": (VIRT_TEMP, 0., 0, ["Ta", "qa"], 0),
+    "pz_from_p0": (PZ, Z_T, 0, ["P", "Ta", "qa"], 0),
+    "theta_from_z": (THETA, Z_T, 0, ["P", "Ta", "qa"], 0),
+    "t_from_z": (TABS, Z_T, 0, ["P", "Th", "qa"], 0),
+    "pz_from_p0_ice": (PZ, Z_T, 1, ["P", "Ti", "qa"], 0),
+    "theta_from_z_after_ice": (THETA, Z_T, 1, ["P", "Ti", "qa"], 0),
+    "pz_from_p0_again": (PZ, Z_T, 0, ["P", "Ta", "qa"], 0),
+    "rho_air": (RHO_AIR, 0., 0, ["Ta", "qa", "P"], 0),
+    "visc_air": (VISC_AIR, 0., 0, ["Ta"], 0),
+    "l_vap": (L_VAP, 0., 0, ["Ts"], 0),
+    "cp_air": (CP_AIR, 0., 0, ["qa"], 0),
+    "gamma_moist": (GAMMA_MOIST, 0., 0, ["Ta", "qa"], 0),
+    "rho_air_adv": (RHO_AIR_ADV, 0., 0, ["Ta", "qa", "P"], 0),
+    "dry_static_energy": (DRY_STATIC_ENERGY, Z_T, 0, ["Ta", "qa"], 0),
+    "one_on_l": (ONE_ON_L, 0., 0, ["Th", "qa", "us", "tst", "qst"], 0),
+    "ri_bulk": (RI_BULK, Z_U, 0, ["Ts", "Th", "qs", "qa", "Ub"], 0),
+    "ri_bulk_layer": (RI_BULK, Z_U, 0, ["Ts", "Th", "qs", "qa", "Ub", "Tly", "qly"], 0),
+    "e_sat": (E_SAT, 0., 0, ["Ta"], 0),
+    "e_sat_ice": (E_SAT_ICE, 0., 0, ["Ti"], 0),
+    "de_sat_dt_ice": (DE_SAT_DT_ICE, 0., 0, ["Ti"], 0),
+    "q_sat": (Q_SAT, 0., 0, ["Ta", "P"], 0),
+    "q_sat_ice": (Q_SAT, 0., 1, ["Ti", "P"], 0),
+    "dq_sat_dt_ice": (DQ_SAT_DT_ICE, 0., 0, ["Ti", "P"], 0),
+    "q_air_rh": (Q_AIR_RH, 0., 0, ["rh", "Ta", "P"], 0),
+    "q_air_dp": (Q_AIR_DP, 0., 0, ["dp", "P"], 0),
+    "q_sat_crude": (Q_SAT_CRUDE, 0., 0, ["Ts", "rho"], 0),
+    "e_air": (E_AIR, 0., 0, ["qa", "P"], 0),
+    "rh_air": (RH_AIR, 0., 0, ["qa", "Ta", "P"], 0),
+    "uqt_qns": (UPDATE_QNSOL_TAU, Z_U, 0, _UQT, 0),
+    "uqt_tau": (UPDATE_QNSOL_TAU, Z_U, 0, _UQT, 1),
+    "uqt_qlat": (UPDATE_QNSOL_TAU, Z_U, 0, _UQT, 2),
+    "bf_tau": (BULK_FORMULA, Z_U, 0, _BF, 0),
+    "bf_qsen": (BULK_FORMULA, Z_U, 0, _BF, 1),
+    "bf_qlat": (BULK_FORMULA, Z_U, 0, _BF, 2),
+    "bf_evap": (BULK_FORMULA, Z_U, 0, _BF, 3),
+    "bf_rhoa": (BULK_FORMULA, Z_U, 0, _BF, 4),
+    "bf_ice_qlat": (BULK_FORMULA, Z_U, 1, _BFI, 2),
+    "bf_ice_evap": (BULK_FORMULA, Z_U, 1, _BFI, 3),
+    "alpha_sw": (ALPHA_SW, 0., 0, ["Ts"], 0),
+    "qlw_net": (QLW_NET, 0., 0, ["rlw", "Ts"], 0),
+    "qlw_net_ice": (QLW_NET, 0., 1, ["rlw", "Ti"], 0),
+    "z0_from_cd": (Z0_FROM_CD, Z_U, 0, ["Cd"], 0),
+    "z0_from_cd_psi": (Z0_FROM_CD, Z_U, 0, ["Cd", "psi"], 0),
+    "z0_from_ustar": (Z0_FROM_USTAR, Z_U, 0, ["us", "Ub"], 0),
+    "cd_from_z0": (CD_FROM_Z0, Z_U, 0, ["z0"], 0),
+    "cd_from_z0_psi": (CD_FROM_Z0, Z_U, 0, ["z0", "psi"], 0),
+    "f_m_louis": (F_M_LOUIS, Z_U, 0, ["Rib", "Cd", "z0"], 0),
+    "f_h_louis": (F_H_LOUIS, Z_U, 0, ["Rib", "Ch", "z0"], 0),
+    "un10_from_ustar": (UN10_FROM_USTAR, Z_U, 0, ["Ub", "us", "psi"], 0),
+    "un10_from_cdn": (UN10_FROM_CDN, Z_U, 0, ["Ub", "Cd", "psi"], 0),
+    "un10_from_cd": (UN10_FROM_CD, Z_U, 0, ["Ub", "Cd", "psi"], 0),
+    "z0t_lkb": (Z0TQ_LKB, 0., 1, ["Rer", "z0"], 0),
+    "z0q_lkb": (Z0TQ_LKB, 0., 2, ["Rer", "z0"], 0),
+    # scalar-only in the reference: checked on the first cells
+    "delta_skin_s": (DELTA_SKIN, 0., 0, ["alp", "Qd", "us"], 0),
+    "delta_skin_qlat_s": (DELTA_SKIN, 0., 0, ["alp", "Qd", "us", "Qlt"], 0),
+}
+# outputs each function has (to size the `out` table)
+N_OUT = {UPDATE_QNSOL_TAU: 3, BULK_FORMULA: 5}
+# records of the driver that are NOT array results of one call: the `_s` twins (scalar specifics = same numbers on the first cells),
+# the SAVE quirks and the host-side bookkeeping
+EXTRA = ["pref_sticky_s", "variance_vmean", "type_of_humidity", "mod_const"]
+
+
+def read_records(path):
+    """The record stream phymbl_driver.f90 writes: { char[24] name, int32 m, m doubles }."""
+    out = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    o = 0
+    while o < len(data):
+        name = data[o:o + 24].decode().strip()
+        m = int(np.frombuffer(data, np.int32, 1, o + 24)[0])
+        out[name] = np.frombuffer(data, np.float64, m, o + 28).copy()
+        o += 28 + 8 * m
+    return out
+
+
+def write_input(path, cols):
+    with open(path, "wb") as f:
+        np.int32(cols.shape[1]).tofile(f)
+        np.ascontiguousarray(cols, dtype=np.float64).tofile(f)
