@@ -62,6 +62,8 @@ SYMBOLS = {
     "ab_session_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ab_session_destroy": (C.c_int, [vp]),
     "ab_session_create_sharded": (C.c_int, [C.POINTER(vp), C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "ab_session_create_sharded_rows": (C.c_int, [C.POINTER(vp), C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
+                                                 C.POINTER(C.c_long)]),
     "ab_session_shard_count": (C.c_int, [vp]),
     "ab_session_shard_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_int)]),
     "ab_session_init": (C.c_int, [vp] + [vp] * 8 + [C.c_int, vp, C.POINTER(InitReport)]),

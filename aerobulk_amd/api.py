@@ -78,9 +78,10 @@ class Session:
     """One aerobulk_model() time loop (jt = 1..Nt) on one MI355X, or sharded by row blocks over several.
 
     Replaces the reference's module-global state by an explicit handle.  `device`: a HIP ordinal (-1 = current),
-    "all" (one j-block per visible GPU) or a list of ordinals (one j-block each; an ordinal may repeat)."""
+    "all" (one j-block per visible GPU) or a list of ordinals (one j-block each; an ordinal may repeat).  `rows`: with a list of
+    ordinals, the number of rows of each j-block (default: equal blocks)."""
 
-    def __init__(self, calgo, Ni, Nj=1, Nt=1, l_use_skin=False, precision="f64", device=-1):
+    def __init__(self, calgo, Ni, Nj=1, Nt=1, l_use_skin=False, precision="f64", device=-1, rows=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         algo = self._lib.ab_algo_from_string(calgo.encode(), -1)
@@ -93,8 +94,15 @@ class Session:
         prec = PRECISIONS[precision]
         if isinstance(device, (list, tuple)):
             devs = (C.c_int * len(device))(*[int(d) for d in device])
-            rc = self._lib.ab_session_create_sharded(C.byref(self._h), algo, self.Ni, self.Nj, self.Nt, int(self.l_use_skin),
-                                                     prec, devs, len(device))
+            if rows is not None:
+                if len(rows) != len(device):
+                    raise ValueError("rows: one count per shard")
+                nrows = (C.c_long * len(device))(*[int(r) for r in rows])
+                rc = self._lib.ab_session_create_sharded_rows(C.byref(self._h), algo, self.Ni, self.Nj, self.Nt, int(self.l_use_skin),
+                                                              prec, devs, len(device), nrows)
+            else:
+                rc = self._lib.ab_session_create_sharded(C.byref(self._h), algo, self.Ni, self.Nj, self.Nt, int(self.l_use_skin),
+                                                         prec, devs, len(device))
         else:
             rc = self._lib.ab_session_create(C.byref(self._h), algo, self.Ni, self.Nj, self.Nt, int(self.l_use_skin), prec,
                                              -2 if device == "all" else int(device))

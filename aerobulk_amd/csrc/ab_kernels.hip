@@ -538,6 +538,10 @@ template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipErro
         static const int mode = []{ const char *e = getenv("AEROBULK_AMD_CU_KERNEL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
         const long cus = resident_block_slots(4) / 4;
         if (!diag && a.queue && rounds <= 2 && (mode == 1 || (mode < 0 && rounds == 2 && nblk >= 3 * cus * kCuTeams))) {   // from ~1.6 M cells (tools/cu_threshold_probe.py: 4320x450, what one rank of eight owns: 0.98 of the block kernel's time; 4320x225: 1.07)
+            // the tile queue (three counters behind the error flag) is re-armed by the last team of every launch; zeroing it in front of
+            // the launch as well makes a launch independent of how the previous one on this session ended (a fault, an abort, a
+            // caller that broke the one-stream rule): 12 bytes on the launch stream, capturable in a hipGraph
+            if (hipError_t e = hipMemsetAsync(a.queue, 0, 3 * sizeof(int), stream); e != hipSuccess) return e;
             hipLaunchKernelGGL((flux_kernel_cu<R, ALGO, SKIN, S>), dim3((unsigned)cus), dim3(kCuBlock), 0, stream, a, dg);
             return hipGetLastError();
         }

@@ -184,6 +184,21 @@ int ab_session_create_sharded(ab_session **out, int algo, long ni, long nj, int 
     return ab::sharded_create(out, algo, ni, nj, nt, use_skin, precision, devices, nshards);
 }
 
+int ab_session_create_sharded_rows(ab_session **out, int algo, long ni, long nj, int nt, int use_skin, int precision,
+                                   const int *devices, int nshards, const long *nj_per_shard)
+{
+    if (!out) return fail(AB_ERR_ARG, "ab_session_create_sharded_rows: out == NULL");
+    *out = nullptr;
+    if (nshards < 1 || !devices || !nj_per_shard) return fail(AB_ERR_ARG, "ab_session_create_sharded_rows: no device list / no row counts");
+    long sum = 0;
+    for (int r = 0; r < nshards; ++r) {
+        if (nj_per_shard[r] < 1) return fail(AB_ERR_ARG, "ab_session_create_sharded_rows: shard %d has %ld rows", r, nj_per_shard[r]);
+        sum += nj_per_shard[r];
+    }
+    if (sum != nj) return fail(AB_ERR_ARG, "ab_session_create_sharded_rows: the shards hold %ld rows, the grid has %ld", sum, nj);
+    return ab::sharded_create(out, algo, ni, nj, nt, use_skin, precision, devices, nshards, nj_per_shard);
+}
+
 int ab_session_shard_count(const ab_session *s) { return s ? (s->sharded() ? (int)s->shards.size() : 1) : 0; }
 
 int ab_session_shard_info(const ab_session *s, int shard, long *j0, long *nj_local, int *device)

@@ -66,7 +66,8 @@ namespace ab {
 void set_last_error(const std::string &msg);
 // Row-block sharding layer (ab_sharded.hip); each function mirrors the public entry point of the same name and is what that
 // entry point calls for a session with shards.
-int sharded_create(ab_session **out, int algo, long ni, long nj, int nt, int use_skin, int precision, const int *devices, int nshards);
+int sharded_create(ab_session **out, int algo, long ni, long nj, int nt, int use_skin, int precision, const int *devices, int nshards,
+                   const long *nj_per_shard = nullptr);
 int sharded_destroy(ab_session *s);
 int sharded_init_stats(ab_session *s, const void *const in[8], int mem, void *stream, double stats[AB_INIT_NSTATS]);
 int sharded_compute(ab_session *s, int jt, double zt, double zu, int niter, const void *const in[8], void *const out[6], int mem,

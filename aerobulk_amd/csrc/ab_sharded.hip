@@ -13,6 +13,7 @@
 #include "ab_session.hpp"
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>   // types, enumerators, prototypes only: librccl.so is dlopen()ed on first use, never linked
 
 #include <condition_variable>
 #include <cstdarg>
@@ -145,16 +146,17 @@ namespace ab {
 
 void gather_release(ab_session *s);
 
-int sharded_create(ab_session **out, int algo, long ni, long nj, int nt, int use_skin, int precision, const int *devices, int nshards)
+int sharded_create(ab_session **out, int algo, long ni, long nj, int nt, int use_skin, int precision, const int *devices, int nshards,
+                   const long *nj_per_shard)
 {
     ab::DeviceGuard dguard_;
     ab_session *p = new ab_session;
     p->algo = algo; p->ni = ni; p->nj = nj; p->n = ni * nj; p->nt = nt; p->use_skin = use_skin ? 1 : 0;
     p->f32 = (precision != AB_F64); p->compute64 = (precision == AB_F32_STORAGE) ? 1 : (precision == AB_F32_MIXED ? 2 : 0); p->esz = p->f32 ? 4 : 8; p->device = devices ? devices[0] : 0;
-    // contiguous j-blocks, the first (nj mod nshards) one row taller
+    // contiguous j-blocks: the caller's row counts, else equal blocks with the first (nj mod nshards) one row taller
     long j0 = 0;
     for (int r = 0; r < nshards; ++r) {
-        const long njl = nj / nshards + (r < nj % nshards ? 1 : 0);
+        const long njl = nj_per_shard ? nj_per_shard[r] : nj / nshards + (r < nj % nshards ? 1 : 0);
         ab_session *c = nullptr;
         int rc = ab_session_create(&c, algo, ni, njl, nt, use_skin, precision, devices ? devices[r] : r);
         if (rc) {
@@ -380,17 +382,20 @@ int sharded_compute_shards(ab_session *s, int jt, double zt, double zu, int nite
 
 // ------------------------------------------------------------------------------------------------
 // The gather of the fluxes (include/aerobulk_amd.h: ab_session_gather).  RCCL inside the process, loaded on first use.
+// Types, enumerators and prototypes come from RCCL's own header (so that ncclFloat64, ncclComm_t ... are what the library means by them);
+// the library itself is not linked: a session on one device never needs it, and it is loaded when the first multi-device gather asks.
 namespace {
-typedef void *ncclComm_t;
 struct Rccl {
     void *lib = nullptr;
-    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    int version = 0;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
     bool ok() const { return lib != nullptr; }
 };
 Rccl &rccl()
@@ -405,18 +410,22 @@ Rccl &rccl()
         }
         if (!h) return;
         auto sym = [&](const char *n) { return dlsym(h, n); };
-        r.CommInitAll = (int (*)(ncclComm_t *, int, const int *))sym("ncclCommInitAll");
-        r.CommDestroy = (int (*)(ncclComm_t))sym("ncclCommDestroy");
-        r.GroupStart = (int (*)())sym("ncclGroupStart");
-        r.GroupEnd = (int (*)())sym("ncclGroupEnd");
-        r.Send = (int (*)(const void *, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclSend");
-        r.Recv = (int (*)(void *, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclRecv");
-        r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
-        if (r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv) r.lib = h;
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
+        if (!(r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetVersion)) return;
+        // the enumerators compiled in above are those of the header's major version: a library of another major is refused
+        if (r.GetVersion(&r.version) != ncclSuccess || r.version / 10000 != NCCL_MAJOR) return;
+        r.lib = h;
     });
     return r;
 }
-constexpr int kNcclFloat = 7, kNcclDouble = 8;      // ncclFloat32 / ncclFloat64 (rccl.h)
+constexpr ncclDataType_t kNcclFloat = ncclFloat32, kNcclDouble = ncclFloat64;
 
 // communicator over the DISTINCT devices of the session; rank_of_shard[r] = rank of shard r's device
 struct GatherState {
@@ -488,7 +497,7 @@ int sharded_gather(ab_session *s, int root, const ab_shard_arrays *sh, const ab_
                 s->gather = g;
                 gather_release(s);
                 return sfail(AB_ERR_HIP, "ab_session_gather: ncclCommInitAll over %zu devices: %s", g->devs.size(),
-                             rccl().GetErrorString ? rccl().GetErrorString(rc) : "error");
+                             rccl().GetErrorString ? rccl().GetErrorString((ncclResult_t)rc) : "error");
             }
         }
         s->gather = g;
@@ -496,7 +505,7 @@ int sharded_gather(ab_session *s, int root, const ab_shard_arrays *sh, const ab_
     const int root_dev = s->shards[root]->device, root_rank = g->rank_of_shard[root];
     hipStream_t root_st = streams ? (hipStream_t)streams[root] : nullptr;
     void *d[6] = {dst->ql, dst->qh, dst->tau_x, dst->tau_y, dst->evap, dst->t_s};
-    const int dtype = s->esz == 4 ? kNcclFloat : kNcclDouble;
+    const ncclDataType_t dtype = s->esz == 4 ? kNcclFloat : kNcclDouble;
     auto src_of = [&](int r, int f) -> const void * {
         const void *p[6] = {sh[r].ql, sh[r].qh, sh[r].tau_x, sh[r].tau_y, sh[r].evap, sh[r].t_s};
         return p[f];
@@ -544,7 +553,7 @@ int sharded_gather(ab_session *s, int root, const ab_shard_arrays *sh, const ab_
             // the device-to-device copies of the local shards are already enqueued into dst: drain them, so that the caller does not
             // reuse or free the destination while they are in flight (round-3 advisory)
             if (hipSetDevice(root_dev) == hipSuccess) (void)hipStreamSynchronize(root_st);
-            return sfail(AB_ERR_HIP, "ab_session_gather: RCCL: %s (dst holds the rows of the root's own device only)", R.GetErrorString ? R.GetErrorString(rc) : "error");
+            return sfail(AB_ERR_HIP, "ab_session_gather: RCCL: %s (dst holds the rows of the root's own device only)", R.GetErrorString ? R.GetErrorString((ncclResult_t)rc) : "error");
         }
     }
     if (synchronize) {

@@ -238,64 +238,130 @@ def main_inprocess(a):
     torch.cuda.set_device(root_dev)
     nbuf = 1 if a.no_pipeline_gather else 2
 
-    sessions = [ab.Session(algo, ni, nj, 1, skin, precision=precision, device=devs) for algo, skin in passes]
-    for s_ in sessions:
-        s_.set_humidity("sh")
-    shards = sessions[0].shards()                      # [(j0, njl, device)]: the same cut for every pass
-    fields, cstream, mstream = [], [], []
-    for j0, njl, d in shards:
-        with torch.cuda.device(d):
-            fields.append(ab.synth_fields_device(ni, nj, j0, njl, precision=precision, device=torch.device("cuda", d), with_rad=True))
-            cstream.append(torch.cuda.Stream(device=d))
-            mstream.append(torch.cuda.Stream(device=d))
-    torch.cuda.synchronize()
-    # destinations on the root's device: [buffer set][pass] -> dict of whole-grid tensors; the root shard computes straight into its rows
-    dst = [[{k: torch.zeros(ni * nj, dtype=tdt, device=root_dev) for k in gnames} for _ in range(npass)] for _ in range(nbuf)]
-    outs = []                                          # [buffer set][pass][shard] -> dict of that shard's output tensors
-    for b in range(nbuf):
-        per_pass = []
-        for p, (algo, skin) in enumerate(passes):
-            per_shard = []
-            for r, (j0, njl, d) in enumerate(shards):
-                names = ("QL", "QH", "Tau_x", "Tau_y", "Evap") + (("T_s",) if skin else ())
-                if r == root:
-                    o = {k: (dst[b][p][k][j0 * ni:(j0 + njl) * ni] if k in dst[b][p] else torch.empty(ni * njl, dtype=tdt, device=root_dev)) for k in names}
-                else:
-                    o = {k: torch.empty(ni * njl, dtype=tdt, device=torch.device("cuda", d)) for k in names}
-                per_shard.append(o)
-            per_pass.append(per_shard)
-        outs.append(per_pass)
-    shard_in = [[{k: f[k] for k in (IN6 + (("rad_sw", "rad_lw") if skin else ()))} for f in fields] for _, skin in passes]
-    c_ptr = [st.cuda_stream for st in cstream]
-    m_ptr = [st.cuda_stream for st in mstream]
-    gdone = [[None] * len(shards) for _ in range(nbuf)]      # per buffer set and shard: event "the gathers that read this set are done"
-    nstep = [0]
+    class Setup:
+        """Sessions, resident fields and buffers for one cut of the grid into row blocks (`rows`: per shard, None = equal blocks)."""
+        pass
 
-    def step(with_gather=True, nit=None):
-        b = nstep[0] % nbuf
-        nstep[0] += 1
-        for r, (_, _, d) in enumerate(shards):               # the set is written again only after its gathers of nbuf steps ago
-            if gdone[b][r] is not None:
-                cstream[r].wait_event(gdone[b][r])
-        for p, sess in enumerate(sessions):
-            sess.compute_shards(1, zt, zu, shard_in[p], outs[b][p], Niter=niter if nit is None else nit, streams=c_ptr, check=False)
+    def setup(rows):
+        st = Setup()
+        sessions = [ab.Session(algo, ni, nj, 1, skin, precision=precision, device=devs, rows=rows) for algo, skin in passes]
+        for s_ in sessions:
+            s_.set_humidity("sh")
+        shards = sessions[0].shards()                      # [(j0, njl, device)]: the same cut for every pass
+        fields, cstream, mstream = [], [], []
+        for j0, njl, d in shards:
+            with torch.cuda.device(d):
+                fields.append(ab.synth_fields_device(ni, nj, j0, njl, precision=precision, device=torch.device("cuda", d), with_rad=True))
+                cstream.append(torch.cuda.Stream(device=d))
+                mstream.append(torch.cuda.Stream(device=d))
+        torch.cuda.synchronize()
+        # destinations on the root's device: [buffer set][pass] -> dict of whole-grid tensors; the root shard computes straight into its rows
+        dst = [[{k: torch.zeros(ni * nj, dtype=tdt, device=root_dev) for k in gnames} for _ in range(npass)] for _ in range(nbuf)]
+        outs = []                                          # [buffer set][pass][shard] -> dict of that shard's output tensors
+        for b in range(nbuf):
+            per_pass = []
+            for p, (algo, skin) in enumerate(passes):
+                per_shard = []
+                for r, (j0, njl, d) in enumerate(shards):
+                    names = ("QL", "QH", "Tau_x", "Tau_y", "Evap") + (("T_s",) if skin else ())
+                    if r == root:
+                        o = {k: (dst[b][p][k][j0 * ni:(j0 + njl) * ni] if k in dst[b][p] else torch.empty(ni * njl, dtype=tdt, device=root_dev)) for k in names}
+                    else:
+                        o = {k: torch.empty(ni * njl, dtype=tdt, device=torch.device("cuda", d)) for k in names}
+                    per_shard.append(o)
+                per_pass.append(per_shard)
+            outs.append(per_pass)
+        shard_in = [[{k: f[k] for k in (IN6 + (("rad_sw", "rad_lw") if skin else ()))} for f in fields] for _, skin in passes]
+        c_ptr = [st.cuda_stream for st in cstream]
+        m_ptr = [st.cuda_stream for st in mstream]
+        gdone = [[None] * len(shards) for _ in range(nbuf)]      # per buffer set and shard: event "the gathers that read this set are done"
+        nstep = [0]
+
+        def step(with_gather=True, nit=None):
+            b = nstep[0] % nbuf
+            nstep[0] += 1
+            for r, (_, _, d) in enumerate(shards):               # the set is written again only after its gathers of nbuf steps ago
+                if gdone[b][r] is not None:
+                    cstream[r].wait_event(gdone[b][r])
+            for p, sess in enumerate(sessions):
+                sess.compute_shards(1, zt, zu, shard_in[p], outs[b][p], Niter=niter if nit is None else nit, streams=c_ptr, check=False)
+                if with_gather:
+                    for r in range(len(shards)):                 # communication streams: behind the kernels of this pass
+                        mstream[r].wait_stream(cstream[r])
+                    sess.gather([{k: v for k, v in o.items() if k in gnames} for o in outs[b][p]], dst[b][p], root=root, streams=m_ptr, synchronize=False)
             if with_gather:
-                for r in range(len(shards)):                 # communication streams: behind the kernels of this pass
-                    mstream[r].wait_stream(cstream[r])
-                sess.gather([{k: v for k, v in o.items() if k in gnames} for o in outs[b][p]], dst[b][p], root=root, streams=m_ptr, synchronize=False)
-        if with_gather:
-            for r, (_, _, d) in enumerate(shards):
+                for r, (_, _, d) in enumerate(shards):
+                    ev = torch.cuda.Event()
+                    ev.record(mstream[r])
+                    gdone[b][r] = ev
+                # the root's compute stream also waits for what was received into this set before writing it again
                 ev = torch.cuda.Event()
-                ev.record(mstream[r])
-                gdone[b][r] = ev
-            # the root's compute stream also waits for what was received into this set before writing it again
-            ev = torch.cuda.Event()
-            ev.record(mstream[root])
-            gdone[b][root] = ev
+                ev.record(mstream[root])
+                gdone[b][root] = ev
 
-    def sync():
-        for d in sorted(set(devs)):
-            torch.cuda.synchronize(d)
+        def sync():
+            for d in sorted(set(devs)):
+                torch.cuda.synchronize(d)
+        st.sessions, st.shards, st.step, st.sync, st.cstream, st.c_ptr, st.shard_in, st.outs, st.dst, st.nstep = sessions, shards, step, sync, cstream, c_ptr, shard_in, outs, dst, nstep
+        return st
+
+    def kernel_ms(st, nrep):
+        """per device: events on every shard's compute stream around the launches of ALL passes of one step"""
+        kms = [0.0] * len(st.shards)
+        for _ in range(nrep):
+            evs = []
+            for r in range(len(st.shards)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st.cstream[r])
+                evs.append((e0, e1))
+            for p, sess in enumerate(st.sessions):
+                sess.compute_shards(1, zt, zu, st.shard_in[p], st.outs[0][p], Niter=niter, streams=st.c_ptr, check=False)
+            for r in range(len(st.shards)):
+                evs[r][1].record(st.cstream[r])
+            st.sync()
+            for r in range(len(st.shards)):
+                kms[r] += evs[r][0].elapsed_time(evs[r][1]) / nrep
+        return kms
+
+    # ---- the cut.  Shard 0 lives on the gather's destination: its rows never cross a link, so it is given MORE rows than its peers
+    # until its kernels take as long as a peer's kernels + that peer's share of the root's ingress (balanced_peer_rows, as the
+    # torchrun path).  Measured on the equal cut first: per-device kernel time and what a gather of these fields costs.
+    tune = None
+    rows = None
+    if nsh > 1 and a.peer_rows >= 0 and nj >= 2 * nsh:
+        if a.peer_rows > 0:
+            rp = max(1, min(a.peer_rows, nj // nsh))
+        else:
+            st = setup(None)
+            for _ in range(6):
+                st.step()
+            st.sync()
+            kms0 = kernel_ms(st, 4)
+            t_cell = max(kms0[r] * 1e-3 / (ni * st.shards[r][1]) for r in range(nsh))       # all passes, per cell
+            t0 = time.perf_counter()
+            for _ in range(4):
+                st.step(True)
+            st.sync()
+            t_g = (time.perf_counter() - t0) / 4
+            t0 = time.perf_counter()
+            for _ in range(4):
+                st.step(False)
+            st.sync()
+            t_c = (time.perf_counter() - t0) / 4
+            # ingress of the root per step beyond what the kernels hide: a lower bound of the link time of one peer's payload
+            peer_bytes = npass * len(gnames) * esz * ni * st.shards[1][1]
+            t_link = max(t_g - t_c, 1e-6)
+            link = peer_bytes * (nsh - 1) / t_link / max(nsh - 1, 1)                           # per peer, all sending at once
+            rp = balanced_peer_rows(nj, nsh, t_cell, npass * len(gnames) * esz, link)
+            tune = {"equal_cut_step_ms": round(t_g * 1e3, 4), "equal_cut_resident_step_ms": round(t_c * 1e3, 4),
+                    "link_GBps_per_peer": round(link / 1e9, 1), "kernel_Mcell_per_s_per_device": round(npass * 1e-6 / t_cell, 1)}
+            for s_ in st.sessions:
+                s_.close()
+            del st
+            torch.cuda.empty_cache()
+        rows = [nj - (nsh - 1) * rp] + [rp] * (nsh - 1)
+    st = setup(rows)
+    sessions, shards, step, sync, cstream, c_ptr, shard_in, outs, dst, nstep = st.sessions, st.shards, st.step, st.sync, st.cstream, st.c_ptr, st.shard_in, st.outs, st.dst, st.nstep
 
     def timed(nsteps, with_gather):
         sync()
@@ -315,21 +381,10 @@ def main_inprocess(a):
     for s_ in sessions:
         s_.check()
 
-    # per-device kernel duration: events on every shard's compute stream around the launch of the headline pass
-    kms = [0.0] * len(shards)
-    nrep = min(a.steps, 10)
-    for _ in range(nrep):
-        evs = []
-        for r, (_, _, d) in enumerate(shards):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cstream[r])
-            evs.append((e0, e1))
-        sessions[0].compute_shards(1, zt, zu, shard_in[0], outs[0][0], Niter=niter, streams=c_ptr, check=False)
-        for r in range(len(shards)):
-            evs[r][1].record(cstream[r])
-        sync()
-        for r in range(len(shards)):
-            kms[r] += evs[r][0].elapsed_time(evs[r][1]) / nrep
+    # per-device kernel duration of the headline pass alone (the roofline's kernel) and of all passes of a step
+    st1 = Setup()
+    st1.sessions, st1.shards, st1.cstream, st1.c_ptr, st1.shard_in, st1.outs, st1.sync = sessions[:1], shards, cstream, c_ptr, shard_in[:1], [o[:1] for o in outs], sync
+    kms = kernel_ms(st1, min(a.steps, 10))
 
     verify_msg = None
     if a.verify:
@@ -376,6 +431,9 @@ def main_inprocess(a):
                      "ms_per_step": round(elapsed_resident / a.steps * 1e3, 4),
                      "note": "the same K steps with the fluxes left on the device that computed them (no gather)"},
         "per_device_kernel_ms": {f"shard{r}@gpu{shards[r][2]}": round(kms[r], 4) for r in range(len(shards))},
+        "rows_per_shard": [sh[1] for sh in shards],
+        "split": ("equal j-blocks" if rows is None else f"root-heavy: shard 0 (on the gather's destination) owns {rows[0]} rows, its {nsh - 1} peers {rows[1]} each"
+                  + (" (--peer-rows)" if a.peer_rows > 0 else " (measured during set-up: ab_session_create_sharded_rows)")),
         "roofline": {"bound": "hbm", "limiter": "valu_fp64", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                      "traffic": None, "kernel": kernel_label(precision, head_algo, head_skin, n_slow, ab),
                      "kernel_ms": round(kms[slow], 4), "bytes_per_cell": bpc, "cells_per_launch": n_slow,
@@ -383,6 +441,8 @@ def main_inprocess(a):
     }
     if verify_msg:
         res["verify"] = verify_msg
+    if tune:
+        res["split_tuning"] = tune
     print(json.dumps(res), flush=True)
     for s_ in sessions:
         s_.close()

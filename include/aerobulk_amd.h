@@ -98,6 +98,11 @@ int ab_session_destroy(ab_session *s);
  * session per GPU instead.  Process-global AEROBULK_MODEL / aerobulk_cxx_*: environment AEROBULK_AMD_DEVICES = all | N | list. */
 int ab_session_create_sharded(ab_session **out, int algo, long ni, long nj, int nt, int use_skin,
                               int precision, const int *devices, int nshards);
+/* The same with the caller's row counts: shard r owns nj_per_shard[r] >= 1 rows (their sum must be nj), in order.  For layouts in
+ * which the shards are not peers: the GPU that also receives the gathered fluxes of the others (ab_session_gather's root) is given
+ * fewer rows, so that its kernel + its receives take as long as the others' kernels + their sends (bench.py: root_share). */
+int ab_session_create_sharded_rows(ab_session **out, int algo, long ni, long nj, int nt, int use_skin,
+                                   int precision, const int *devices, int nshards, const long *nj_per_shard);
 int ab_session_shard_count(const ab_session *s);    /* 1 for an ordinary session */
 int ab_session_shard_info(const ab_session *s, int shard, long *j0, long *nj_local, int *device);
 

@@ -66,6 +66,10 @@ def test_sharded_session_arguments_need_no_gpu(lib):
     assert lib.ab_session_create_sharded(C.byref(h), 2, 10, 2, 1, 0, 0, devs, 3) == 10     # more shards than rows: AB_ERR_ARG
     assert lib.ab_session_create_sharded(C.byref(h), 2, 10, 8, 1, 0, 0, None, 2) == 10     # no device list
     assert lib.ab_session_shard_count(None) == 0
+    rows = (C.c_long * 3)(4, 3, 2)
+    assert lib.ab_session_create_sharded_rows(C.byref(h), 2, 10, 8, 1, 0, 0, devs, 3, rows) == 10   # 9 rows for a grid of 8
+    assert b"9 rows" in lib.ab_last_error()
+    assert lib.ab_session_create_sharded_rows(C.byref(h), 2, 10, 8, 1, 0, 0, devs, 3, None) == 10
     if lib.ab_device_count() == 0:   # no GPU: the shards cannot be created, and the failure is loud
         assert lib.ab_session_create_sharded(C.byref(h), 2, 10, 8, 1, 0, 0, devs, 3) == 9
         assert lib.ab_session_create(C.byref(h), 2, 10, 8, 1, 0, 0, -2) == 9                # AB_DEVICE_ALL

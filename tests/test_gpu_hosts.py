@@ -186,25 +186,36 @@ def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
         assert "link_GBps" in res["config"]["sharding_tuning"], res["config"]
 
 
-@pytest.mark.parametrize("extra,env", [([], {}), (["--gather-ts"], {"AEROBULK_AMD_GATHER": "rccl"}), (["--config", "4", "--no-pipeline-gather"], {})],
-                         ids=["d2d", "rccl-one-device-communicator", "config4-unpipelined"])
-def test_bench_as_typed_runs_the_library_sharded_session(extra, env):
-    """`python3 bench.py --gpus 2` exactly as typed (no launcher, no WORLD_SIZE): one process, one sharded library session —
-    ab_session_compute_shards on device-resident rows + ab_session_gather — here with both shards on device 0 (--devices 0,0: the box
-    has one GPU); AEROBULK_AMD_GATHER=rccl makes the second shard's rows travel by ncclSend / ncclRecv on a one-device communicator.
+@pytest.mark.parametrize("nsh,extra,env", [(2, [], {}), (2, ["--gather-ts"], {"AEROBULK_AMD_GATHER": "rccl"}), (2, ["--config", "4", "--no-pipeline-gather"], {}),
+                                           (8, [], {"AEROBULK_AMD_GATHER": "rccl"}), (4, ["--peer-rows", "40"], {}), (3, ["--peer-rows", "-1"], {})],
+                         ids=["d2d", "rccl-one-device-communicator", "config4-unpipelined", "eight-shards-rccl-measured-split", "four-shards-given-split",
+                              "three-equal-shards"])
+def test_bench_as_typed_runs_the_library_sharded_session(nsh, extra, env):
+    """`python3 bench.py --gpus N` exactly as typed (no launcher, no WORLD_SIZE): one process, one sharded library session —
+    ab_session_compute_shards on device-resident rows + ab_session_gather — here with every shard on device 0 (--devices 0,0,...: the
+    box has one GPU); AEROBULK_AMD_GATHER=rccl makes the shards' rows travel by ncclSend / ncclRecv on a one-device communicator.
+    The cut is root-heavy (ab_session_create_sharded_rows): measured during set-up by default, --peer-rows gives it, -1 = equal blocks.
     --verify: the gathered fields are bit-identical to one unsharded session."""
     import sys
     e = dict(os.environ, **env)
     e.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--grid", "720x333", "--steps", "3", "--warmup", "1",
-           "--verify", *extra]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nsh), "--devices", ",".join(["0"] * nsh), "--grid", "720x333", "--steps", "3",
+           "--warmup", "1", "--verify", *extra]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["n_gpus"] == 2 and res["launcher"] == "inprocess" and res["verify"].startswith("gathered == single-GPU")
-    assert res["value"] > 0 and res["resident"]["value"] > 0 and len(res["per_device_kernel_ms"]) == 2
+    assert res["n_gpus"] == nsh and res["launcher"] == "inprocess" and res["verify"].startswith("gathered == single-GPU")
+    assert res["value"] > 0 and res["resident"]["value"] > 0 and len(res["per_device_kernel_ms"]) == nsh
     assert res["n_ranks_rccl"] == (1 if env else 0)
     assert res["roofline"]["achieved"] > 0
+    rows = res["rows_per_shard"]
+    assert len(rows) == nsh and sum(rows) == 333 and min(rows) >= 1
+    if "--peer-rows" in extra and extra[extra.index("--peer-rows") + 1] == "-1":
+        assert res["split"] == "equal j-blocks" and max(rows) - min(rows) <= 1
+    elif "--peer-rows" in extra:
+        assert rows[1:] == [40] * (nsh - 1) and rows[0] == 333 - 40 * (nsh - 1) and "root-heavy" in res["split"]
+    else:
+        assert "root-heavy" in res["split"] and len(set(rows[1:])) == 1 and rows[0] >= rows[1] and "kernel_Mcell_per_s_per_device" in res["split_tuning"]
 
 
 def test_sharded_init_statistics_match_global_init(oracle):

@@ -239,7 +239,7 @@ def test_two_ranks_each_with_a_sharded_session(oracle, tmp_path):
 # test box has ONE GPU: k shards on it exercise the shard bookkeeping, the per-shard launches, the placement of every shard's rows and
 # the stream ordering; AEROBULK_AMD_GATHER=rccl sends the same rows through ncclSend / ncclRecv on a one-device communicator (a rank
 # talking to itself).  No multi-device run has happened.
-def _shards_and_gather(ab, oracle, algo, skin, nsh, root, gather_ts, precision="f64"):
+def _shards_and_gather(ab, oracle, algo, skin, nsh, root, gather_ts, precision="f64", rows=None):
     import torch
     ni, nj, nt = 192, 100, 2
     f = oracle.synth_fields(ni, nj)
@@ -255,9 +255,11 @@ def _shards_and_gather(ab, oracle, algo, skin, nsh, root, gather_ts, precision="
                           rad_lw=whole["rad_lw"] if skin else None)
             ref.append({k: v.clone() for k, v in o.items()})
     dev_before = torch.cuda.current_device()
-    with ab.Session(algo, ni, nj, nt, skin, precision=precision, device=[0] * nsh) as s:
+    with ab.Session(algo, ni, nj, nt, skin, precision=precision, device=[0] * nsh, rows=rows) as s:
         assert torch.cuda.current_device() == dev_before          # round-2 advisory: the caller's device is the caller's
         sh = s.shards()
+        if rows is not None:
+            assert [x[1] for x in sh] == list(rows) and [x[0] for x in sh] == [sum(rows[:i]) for i in range(nsh)]
         fields = [{k: whole[k][j0 * ni:(j0 + njl) * ni].clone() for k in (keys if skin else keys[:6])} for j0, njl, _ in sh]
         for jt in range(1, nt + 1):
             shard_out = [{k: torch.empty(ni * njl, dtype=dt, device="cuda") for k in outs} for _, njl, _ in sh]
@@ -277,6 +279,18 @@ def test_device_resident_shards_and_gather(oracle, algo, skin, nsh, root, gather
     _shards_and_gather(ab, oracle, algo, skin, nsh, root, gather_ts)
 
 
+def test_unequal_row_blocks_and_their_gather(oracle):
+    """ab_session_create_sharded_rows: the caller's row counts (the gather's destination owns more rows than its peers); compute,
+    warm-layer state over two records and the gather land every shard's rows in their place; bad counts are refused."""
+    import aerobulk_amd as ab
+    _shards_and_gather(ab, oracle, "coare3p6", True, 4, 0, True, rows=[58, 14, 14, 14])
+    _shards_and_gather(ab, oracle, "ecmwf", True, 3, 2, False, rows=[1, 98, 1])
+    for rows in ([50, 49], [0, 100], [60, 60]):
+        with pytest.raises(ab.AerobulkError) as e:
+            ab.Session("ncar", 192, 100, 1, False, device=[0, 0], rows=rows)
+        assert e.value.status == 10
+
+
 def test_gather_through_rccl_on_a_one_device_communicator(oracle, tmp_path):
     """The RCCL leg of ab_session_gather — dlopen of librccl, ncclCommInitAll, one group of ncclSend / ncclRecv per gather straight
     into the rows of the destination — on the one GPU of the box: AEROBULK_AMD_GATHER=rccl makes every shard but the root's own travel
@@ -289,6 +303,7 @@ from oracle import pyoracle as po
 from test_gpu_sharded import _shards_and_gather
 _shards_and_gather(ab, po, "coare3p6", True, 3, 1, True)
 _shards_and_gather(ab, po, "ecmwf", True, 2, 0, False, precision="f32_mixed")
+_shards_and_gather(ab, po, "coare3p6", True, 8, 0, False, rows=[30] + [10] * 7)      # eight shards, root-heavy cut: 7 x 5 sends / receives in one group
 print("GATHER_OK")
 '''
     e = dict(os.environ, AEROBULK_AMD_GATHER="rccl")
