@@ -417,6 +417,14 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
     __shared__ unsigned s_bara[kCuTeams];
     const int team = (int)threadIdx.x / kBlock;
     const int tid0 = (int)threadIdx.x % kBlock;
+#ifdef AB_CU_TRACE      // diagnostic variant (tools/build_variant.sh trace -DAB_CU_TRACE): where a team's time goes, printed by team 0 / 1 of workgroup 0
+    long long tr[24], tr_last = 0;
+    int ntr = 0, ntile_tr = 0;
+#define AB_TR() do { if (ntr < 24) tr[ntr++] = wall_clock64(); } while (0)
+    AB_TR();
+#else
+#define AB_TR() ((void)0)
+#endif
     R (*s_f)[kCells] = s_fa[team];
     unsigned short *s_inv = s_inva[team];
     unsigned *s_cnt = s_cnta[team], *s_base = s_basea[team];
@@ -424,28 +432,48 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
     long *s_tile = &s_tilea[team];
     unsigned arrivals = 0;
     const TeamSync sync{&s_bara[team], &arrivals};
-    // the team's next tile: the two-round tiles first, then the one-round tiles of the launch's tail; -1 when both pools are empty
-    auto grab = [](const FluxArgs<R, S> &a, bool tail_first) -> long {            // thread 0 of the team
+#if defined(AB_CU_PRIO)
+    int ntile_ = 0;
+#endif
+    // The team's next tile: the two-round tiles first, then the one-round tiles of the launch's tail; -1 when both pools are empty.
+    // A team's FIRST tile is fixed by its position (no atomic): the k-th team of the even ones takes full tile k, the k-th of the odd ones
+    // tail tile k (a one-round tile first puts the teams of a CU out of phase), and the two counters count the tiles handed out BEYOND those.
+    // (Round 4 took the first tile from the counters too: 1 024 teams, one or two atomics each on one cache line at the same instant, served
+    // one after the other by one L2 channel — 10 us of every launch and 20 us of a short one before the first team could start,
+    // profiles/r5_notes.md.)
+    const long nhalf = (long)gridDim.x * (kCuTeams / 2);                            // teams of each parity
+    auto grab = [nhalf](const FluxArgs<R, S> &a, bool tail_first) -> long {         // thread 0 of the team
         int *q = a.queue;
         const long ntiles = a.nfull + a.ntail;
+        const long s0 = a.nfull < nhalf ? a.nfull : nhalf, s1 = a.ntail < nhalf ? a.ntail : nhalf;    // handed out by position
         if (tail_first) {
-            const long t = a.nfull + (long)atomicAdd(&q[1], 1);
+            const long t = a.nfull + s1 + (long)atomicAdd(&q[1], 1);
             if (t < ntiles) return t;
         }
-        long t = (long)atomicAdd(&q[0], 1);
+        long t = s0 + (long)atomicAdd(&q[0], 1);
         if (t < a.nfull) return t;
         if (tail_first) return -1;                                                 // (its look at the tail pool came back empty already)
-        t = a.nfull + (long)atomicAdd(&q[1], 1);
+        t = a.nfull + s1 + (long)atomicAdd(&q[1], 1);
         return t < ntiles ? t : -1;
     };
     if (tid0 == 0) {
         s_bara[team] = 0u;
         *s_next = 0;
-        *s_tile = grab(kernarg_at<FluxArgs<R, S>>(0), (team & 1) != 0);
+        const FluxArgs<R, S> &a = kernarg_at<FluxArgs<R, S>>(0);
+        const long k = (long)blockIdx.x * (kCuTeams / 2) + team / 2;
+        const bool odd = (team & 1) != 0;
+        // (a launch with fewer tiles than teams: the teams beyond them leave without touching the counters)
+        *s_tile = odd ? (k < a.ntail ? a.nfull + k : (a.nfull > nhalf ? grab(a, true) : -1))
+                      : (k < a.nfull ? k : ((a.nfull > nhalf || a.ntail > nhalf) ? grab(a, false) : -1));
     }
     tile_sort_reset(s_cnt, tid0);
+#ifdef AB_CU_FILL_LOOPS      // (A/B: the per-table copy loops, eight memory round trips in a row)
     esat_table_fill(); csg_table_fill(); cu_tables_fill();      // every thread of the workgroup: one copy for the CU
     math_tables_init<A>();                                       // (+ the workgroup's one and only s_barrier)
+#else
+    cu_fill_all();                                               // every table, one copy for the CU, one round trip (+ the workgroup's one and only s_barrier)
+#endif
+    AB_TR();
 #pragma unroll 1
     for (;;) {
         // what derives from the thread index (LDS addresses of the thread's cells, the masks of the sort's prefix scan ...) is formed again
@@ -464,6 +492,7 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
             tile_phase1<R, ALGO, SKIN, S, A>(a, tid, tile0, rounds, tile_fetch<R, S, SKIN>(a, tid, tile0, rounds, 0), s_f, s_cnt, s_inv);
         }
         sync();
+        AB_TR();
         // ---- phase 2: who computes which cell; thread 0 asks for the team's next tile
         {
             AB_ARGS;
@@ -471,9 +500,34 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
             tile_phase2<2>(a, tid, rounds, s_cnt, s_base, s_inv, sync);
         }
         sync();
+        AB_TR();
         // ---- phase 3: groups of 64 sorted cells, fetched from the team's queue
+#ifdef AB_CU_TRACE
+        ++ntile_tr;
+        tr_last = wall_clock64();
+#endif
+#if defined(AB_CU_PRIO)
+        // The SIMD's arbiter serves its oldest wave first: the four waves of a SIMD (one per team) progress at very different rates — team 0
+        // runs a tile in 45 us, team 3 in up to 120 (in-kernel trace, profiles/r5_notes.md).  The queue evens the COUNTS out, but the launch
+        // ends with the slow teams' last tiles.  1: a team on its last tile (its look-ahead came back empty) runs at the highest priority;
+        // 2: priorities rotate with the tile count; 3: both.
+        {
+            long nx = *s_tile;
+            const int last = __builtin_amdgcn_readfirstlane((int)(nx >> 32)) < 0;
+            ++ntile_;
+            int pr = 0;
+            if (AB_CU_PRIO & 2) pr = (team + ntile_) & 3;
+            if ((AB_CU_PRIO & 1) && last) pr = 3;
+            if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+        }
+#endif
         { AB_ARGS; AB_DIAGS; tile_phase3<R, ALGO, SKIN, false, S, A, 2>(a, dg, tid, tile0, rounds, s_f, s_inv, s_next); }
+#if defined(AB_CU_PRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        AB_TR();
         sync();
+        AB_TR();
         // ---- phase 4: owners store (coalesced).  No barrier behind it: phase 4 reads and the next phase 1 writes a thread's OWN tile slots, and
         // the group queue is re-armed by thread 0 two team barriers ahead of its next use
         {
@@ -481,7 +535,21 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
             tile_phase4<R, S>(a, tid, tile0, rounds, s_f);
             if (tid == 0) *s_next = 0;
         }
+        AB_TR();
     }
+#ifdef AB_CU_TRACE
+    AB_TR();
+#ifdef AB_CU_TRACE_END        // every team: entry, start of its last tile's phase 3, exit (absolute 10 ns ticks), tiles run
+    if (tid0 == 0) printf("CUEND %d %d %lld %lld %lld %d\n", (int)blockIdx.x, team, tr[0] % 100000000LL, tr_last % 100000000LL, tr[ntr - 1] % 100000000LL, ntile_tr);
+#endif
+    if ((blockIdx.x == 0 || blockIdx.x == 137) && tid0 == 0) {      // one printf per team: a line is one hostcall packet
+        for (int i = ntr; i < 24; ++i) tr[i] = tr[0];
+#define T(i) (int)((tr[i] - tr[0]) * 10)
+        printf("CUTRACE wg %d team %d n=%d : %d | %d %d %d %d %d | %d %d %d %d %d | %d %d %d %d %d | %d %d %d %d %d | %d %d (ns since entry)\n", (int)blockIdx.x, team, ntr,
+               T(1), T(2), T(3), T(4), T(5), T(6), T(7), T(8), T(9), T(10), T(11), T(12), T(13), T(14), T(15), T(16), T(17), T(18), T(19), T(20), T(21), T(22), T(23));
+#undef T
+    }
+#endif
     if (tid0 == 0) {   // the last team out re-arms the counters for the next launch
         AB_ARGS;
         int *q = a.queue;
@@ -524,7 +592,9 @@ template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipErro
     // large-grid rate gives 0.156) — or 2 398 long tiles followed by 1 280 short ones.
     long nfull = (c.n + tile - 1) / tile, nblk = nfull;
     if (ALGO != 3 && rounds > 1) {
-        const long tail = std::min<long>(c.n, resident_block_slots(T::kOcc) * (long)kBlock);
+        // (AEROBULK_AMD_TAIL_X: tuning knob of the probes — one-round tiles per resident slot, default 1)
+        static const double tail_x = []{ const char *e = getenv("AEROBULK_AMD_TAIL_X"); const double v = e ? atof(e) : 1.; return v >= 0. ? v : 1.; }();
+        const long tail = std::min<long>(c.n, (long)(tail_x * (double)(resident_block_slots(T::kOcc) * (long)kBlock)) / kBlock * kBlock);
         nfull = (c.n - tail) / tile;
         nblk = nfull + (c.n - nfull * tile + kBlock - 1) / kBlock;
     }
@@ -538,10 +608,13 @@ template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipErro
         static const int mode = []{ const char *e = getenv("AEROBULK_AMD_CU_KERNEL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
         const long cus = resident_block_slots(4) / 4;
         if (!diag && a.queue && rounds <= 2 && (mode == 1 || (mode < 0 && rounds == 2 && nblk >= 3 * cus * kCuTeams))) {   // from ~1.6 M cells (tools/cu_threshold_probe.py: 4320x450, what one rank of eight owns: 0.98 of the block kernel's time; 4320x225: 1.07)
-            // the tile queue (three counters behind the error flag) is re-armed by the last team of every launch; zeroing it in front of
-            // the launch as well makes a launch independent of how the previous one on this session ended (a fault, an abort, a
-            // caller that broke the one-stream rule): 12 bytes on the launch stream, capturable in a hipGraph
+            // the tile queue (three counters behind the error flag) is re-armed by the last team of every launch and must be zero here;
+            // ab_session_check reads the counters with the error flag and reports AB_ERR_STATE if a launch left them otherwise (a
+            // launch cut short, a caller that broke the one-stream rule).  (A 12-byte hipMemsetAsync in front of every launch was
+            // measured instead: a dispatch of its own, +4.5 us on every launch of a slab.)
+#ifdef AB_QUEUE_MEMSET      // (A/B: 4.5 us per launch, profiles/r5_notes.md)
             if (hipError_t e = hipMemsetAsync(a.queue, 0, 3 * sizeof(int), stream); e != hipSuccess) return e;
+#endif
             hipLaunchKernelGGL((flux_kernel_cu<R, ALGO, SKIN, S>), dim3((unsigned)cus), dim3(kCuBlock), 0, stream, a, dg);
             return hipGetLastError();
         }

@@ -817,12 +817,21 @@ int ab_session_check(ab_session *s)
     ab::DeviceGuard dguard_;
     AB_HIP(hipSetDevice(s->device));
     hipStream_t st = s->last_stream;
-    int flags = 0;
-    AB_HIP(hipMemcpyAsync(&flags, s->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    int fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [0] the error flag; [4..6] the tile counters of flux_kernel_cu
+    AB_HIP(hipMemcpyAsync(fl, s->d_flags, sizeof fl, hipMemcpyDeviceToHost, st));
     AB_HIP(hipStreamSynchronize(st));
-    if (flags) {
-        AB_HIP(hipMemsetAsync(s->d_flags, 0, sizeof(int), st));
+    const int flags = fl[0];
+    // The persistent kernel's tile counters are zero between launches (its last team re-arms them).  Anything else here means that a
+    // launch did not run to its end or that two launches of this session overlapped (the one-stream rule of ab_session_compute): tiles
+    // of the records since the last check may have been skipped or computed twice.  Reported, and the counters put right again.
+    const bool queue_bad = fl[4] != 0 || fl[5] != 0 || fl[6] != 0;
+    if (flags || queue_bad) {
+        AB_HIP(hipMemsetAsync(s->d_flags, 0, sizeof fl, st));
         AB_HIP(hipStreamSynchronize(st));
+        if (queue_bad)
+            return fail(AB_ERR_STATE, "the tile counters of the persistent flux kernel were left at %d / %d / %d: a launch of this session was cut "
+                                      "short, or two of its launches overlapped (one stream per session); the results since the last check are not valid",
+                        fl[4], fl[5], fl[6]);
         if (flags & 1) return fail(AB_ERR_TAU, "BULK_FORMULA_VCTR()@mod_phymbl: wind stress too strong!\n => > 10 N/m^2 !");
     }
     return AB_OK;

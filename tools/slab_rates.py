@@ -6,7 +6,8 @@ each in a fresh process.  Two clocks per slab:
    piped  : 40 launches enqueued back to back between two events, divided by 40 — what a time loop pays per record
 Rate per cell relative to the full grid is the figure the 8-GPU scaling estimate needs.
 
-    python tools/slab_rates.py [--passes 3] [--rows 225,450,900,1800,3600] [tags ...]      (GPU box; tags: build/var/libab_<tag>.so, `cur`)
+    python tools/slab_rates.py [--passes 3] [--rows 225,450,900,1800,3600] [tags ...]      (GPU box; tags: build/var/libab_<tag>.so, `cur`;
+    tag@ENV=VALUE runs that library with the environment variable set, e.g. cur@AEROBULK_AMD_TAIL_X=2)
 """
 import argparse
 import json
@@ -68,6 +69,9 @@ def main():
         for v in (variants if p % 2 == 0 else variants[::-1]):
             t, mode = v
             e = dict(os.environ, AEROBULK_AMD_CU_KERNEL=mode)
+            t, *envs = t.split("@")                          # tag@ENV=VALUE@...: the same library under other environment variables
+            for kv in envs:
+                e[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
             if t != "cur":
                 e["AEROBULK_AMD_LIB"] = os.path.join(ROOT, "build", "var", f"libab_{t}.so")
             else:
