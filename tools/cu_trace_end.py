@@ -36,12 +36,12 @@ for i, rows in enumerate(launches):
     ent, last, ext, nt = (a[:, 2] - t0) / 100., (a[:, 3] - t0) / 100., (a[:, 4] - t0) / 100., a[:, 5]
     print(f"launch {i}: {len(a)} teams, rows {nj}; times in us since the first team's entry")
     print(f"  entry      : max {ent.max():7.1f}")
-    print(f"  last tile  : starts at  p10 {np.percentile(last, 10):7.1f}  median {np.median(last):7.1f}  p90 {np.percentile(last, 90):7.1f}  max {last.max():7.1f}")
+    print(f"  own tiles end: p10 {np.percentile(last, 10):7.1f}  median {np.median(last):7.1f}  p90 {np.percentile(last, 90):7.1f}  max {last.max():7.1f}")
     print(f"  exit       :            p10 {np.percentile(ext, 10):7.1f}  median {np.median(ext):7.1f}  p90 {np.percentile(ext, 90):7.1f}  max {ext.max():7.1f}")
     for t in range(4):
         m = a[:, 1] == t
         print(f"  team {t}: tiles mean {nt[m].mean():5.2f} (min {nt[m].min()}, max {nt[m].max()}); exit median {np.median(ext[m]):7.1f}, p90 {np.percentile(ext[m], 90):7.1f}, max {ext[m].max():7.1f}; "
-              f"last tile took median {np.median((ext - last)[m]):6.1f}, max {(ext - last)[m].max():6.1f}")
-    busy = np.array([(ext > x).sum() for x in np.arange(0., ext.max(), 10.)])
-    print("  teams still running at t = 0, 10, 20 ... us:", " ".join(str(b) for b in busy))
+              f"own work ended median {np.median(last[m]):7.1f}, p90 {np.percentile(last[m], 90):7.1f}")
+    busy = np.array([(last > x).sum() for x in np.arange(0., min(last.max(), 600.), 10.)])
+    print("  teams still on tiles of their own at t = 0, 10, 20 ... us:", " ".join(str(b) for b in busy))
 print(pr.stderr[-800:])
