@@ -399,68 +399,6 @@ struct TeamSync {
     }
 };
 
-// Phase 3 of a team's tile in flux_kernel_cu: groups of 64 sorted cells handed out by the team's group word
-//     gen << 16 | number of groups << 8 | next group            (LDS, one per team)
-// to whichever wave of the WORKGROUP asks: the team's own four waves, and — once the launch has no tiles left for them — the waves of
-// the other teams of the CU (`target` is then another team: its tile rows, its permutation, its word).  Whoever takes an index below
-// the number of groups owns that group of that generation: the tile cannot be closed, re-sorted or reloaded before the group is counted
-// in the team's done counter, so the rows it reads and writes are stable.  Results go back to the cells' LDS slots.
-// ordering of this wave's LDS operations against those of the other waves of the workgroup: the LDS serves a wave's operations in order, so
-// all that is needed is that the compiler keeps them in place and that the returns have arrived (no wait for the vector-memory counter: a
-// workgroup-scope fence also drains the global stores in flight)
-#ifdef AB_CU_FULL_FENCE
-#define AB_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
-#else
-#define AB_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#endif
-template <class R, int ALGO, bool SKIN, class S, class A, int TEAMS, int FIELDS, int CELLS>
-__device__ __forceinline__ void cu_phase3(const FluxArgs<R, S> &a, const DiagArgs<S> &dg, int target, R (&s_fa)[TEAMS][FIELDS][CELLS],
-                                          const unsigned short (&s_inva)[TEAMS][CELLS], unsigned (&s_grpa)[TEAMS], unsigned (&s_donea)[TEAMS],
-                                          const long (&s_tile0a)[TEAMS])
-{
-    // (everything of the target team is addressed from the one scalar `target`: five separate base pointers cost the scalar registers the
-    // iteration's coefficients need)
-    target = __builtin_amdgcn_readfirstlane(target);
-    R (*s_f)[CELLS] = s_fa[target];
-    const unsigned short *s_inv = s_inva[target];
-    unsigned *s_grp = &s_grpa[target], *s_done = &s_donea[target];
-    const long *s_tile0 = &s_tile0a[target];
-    const int lane = (int)threadIdx.x & 63;
-    const Heights<R> hh = detached(a.h);      // loop invariants out of their scalar-load tuples (ab_tile.hpp)
-    int nb_iter = a.nb_iter;
-    uniform_scalar(nb_iter);
-    bool counted = true;        // false: the group this wave has just finished is not in the done counter yet
-#pragma unroll 1
-    for (;;) {
-        // ONE lane-0 block per turn: the finished group is counted and the next one asked for together.  (A second `if (lane == 0)` block at
-        // the loop's tail left lanes 1-63 of the wave's second group uncomputed — tools/cu_mismatch_probe.py —, and an add from all 64 lanes,
-        // 1 from lane 0 and 0 from the others, serialises on the one LDS word: +5 % on the whole kernel.)
-        unsigned w = 0;
-        if (lane == 0) {
-            if (!counted) __hip_atomic_fetch_add(s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            w = __hip_atomic_fetch_add(s_grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
-        const int g = (int)(w & 0xffu);
-        if (g >= (int)((w >> 8) & 0xffu)) break;
-        AB_LDS_FENCE();                                                      // the tile behind this word: rows, permutation, origin
-        long tile0 = *s_tile0;                                                  // wave-uniform: kept in scalar registers
-        tile0 = ((long)__builtin_amdgcn_readfirstlane((int)(tile0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)tile0);
-        const int j = s_inv[g * 64 + lane];
-        const long k = tile0 + j;
-        if (k < a.n) {
-            R QL, QH, tx, ty, zEvap;
-            A T_s;
-            compute_cell<R, ALGO, SKIN, false, true, S, A, 2>(a, dg, hh, nb_iter, k, A(s_f[0][j]), A(s_f[1][j]), A(s_f[2][j]), s_f[3][j], s_f[4][j], s_f[5][j],
-                                              s_f[6][j], s_f[7][j], QL, QH, tx, ty, zEvap, T_s, (lds_cvptr<R>)&s_f[3][j], (lds_cvptr<R>)&s_f[4][j],
-                                              (lds_vptr<R>)&s_f[0][j], CELLS);      // rows 0-2, 5, 6 are in registers by now: scratch words for turb_coare
-            s_f[0][j] = QL; s_f[1][j] = QH; s_f[2][j] = tx; s_f[3][j] = ty; s_f[4][j] = zEvap; s_f[5][j] = R(T_s);
-        }
-        AB_LDS_FENCE();                                                      // the results are in LDS before the group counts as done
-        counted = false;
-    }
-}
-
 template <class R, int ALGO, bool SKIN, class S = R>
 __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, S> a_in, const DiagArgs<S> dg_in)
 {
@@ -470,23 +408,19 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
 #define AB_ARGS const FluxArgs<R, S> &a = kernarg_at<FluxArgs<R, S>>(0)
 #define AB_DIAGS const DiagArgs<S> &dg = kernarg_at<DiagArgs<S>>(kDgOff)
     using T = Tile<R, ALGO, SKIN, false>;
-    static_assert(T::kFields == 8, "cu_phase3 reads the eight input rows");
     constexpr int kCells = 2 * kBlock;                      // two-round tiles, as in flux_kernel
     __shared__ R s_fa[kCuTeams][T::kFields][kCells];
     __shared__ unsigned short s_inva[kCuTeams][kCells];
     __shared__ unsigned s_cnta[kCuTeams][kSortCounters], s_basea[kCuTeams][kSortCounters];
-    __shared__ long s_tilea[kCuTeams];                      // the team's next tile (look-ahead), -1: none
-    __shared__ long s_tile0a[kCuTeams];                     // first cell of the tile whose phase 3 is open
-    __shared__ unsigned s_grpa[kCuTeams];                   // the group word of that tile (cu_phase3)
-    __shared__ unsigned s_donea[kCuTeams];                  // groups of that tile whose results are in LDS
-    __shared__ unsigned s_fina[kCuTeams];                   // 1: the open tile is the team's last (or it never had one)
+    __shared__ int s_nexta[kCuTeams];
+    __shared__ long s_tilea[kCuTeams];
     __shared__ unsigned s_bara[kCuTeams];
-    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kBlock);      // (wave-uniform: a scalar register)
+    const int team = (int)threadIdx.x / kBlock;
     const int tid0 = (int)threadIdx.x % kBlock;
-#ifdef AB_CU_TRACE      // diagnostic variant (tools/build_variant.sh trace -DAB_CU_TRACE): where a team's time goes, printed by the teams of two workgroups
-    long long tr[24], tr_own = 0;
+#ifdef AB_CU_TRACE      // diagnostic variant (tools/build_variant.sh trace -DAB_CU_TRACE): where a team's time goes, printed by team 0 / 1 of workgroup 0
+    long long tr[24];
     int ntr = 0;
-#define AB_TR() do { if (ntr < 24) tr[ntr++] = wall_clock64(); else tr[23] = wall_clock64(); } while (0)
+#define AB_TR() do { if (ntr < 24) tr[ntr++] = wall_clock64(); } while (0)
     AB_TR();
 #else
 #define AB_TR() ((void)0)
@@ -494,6 +428,7 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
     R (*s_f)[kCells] = s_fa[team];
     unsigned short *s_inv = s_inva[team];
     unsigned *s_cnt = s_cnta[team], *s_base = s_basea[team];
+    int *s_next = &s_nexta[team];
     long *s_tile = &s_tilea[team];
     unsigned arrivals = 0;
     const TeamSync sync{&s_bara[team], &arrivals};
@@ -518,19 +453,13 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
         t = a.nfull + s1 + (long)atomicAdd(&q[1], 1);
         return t < ntiles ? t : -1;
     };
-#ifdef AB_CU_TRACE_END
-    __shared__ unsigned s_exit;
-    if (threadIdx.x == 0) s_exit = 0u;                           // (before the workgroup's barrier)
-#endif
     if (tid0 == 0) {
         s_bara[team] = 0u;
-        s_grpa[team] = 0u;                                       // generation 0: no groups
-        s_donea[team] = 0u;
-        s_fina[team] = 0u;
+        *s_next = 0;
         const FluxArgs<R, S> &a = kernarg_at<FluxArgs<R, S>>(0);
         const long k = (long)blockIdx.x * (kCuTeams / 2) + team / 2;
         const bool odd = (team & 1) != 0;
-        // (a launch with fewer tiles than teams: the teams beyond them leave the counters alone)
+        // (a launch with fewer tiles than teams: the teams beyond them leave without touching the counters)
         *s_tile = odd ? (k < a.ntail ? a.nfull + k : (a.nfull > nhalf ? grab(a, true) : -1))
                       : (k < a.nfull ? k : ((a.nfull > nhalf || a.ntail > nhalf) ? grab(a, false) : -1));
     }
@@ -542,118 +471,49 @@ __global__ void __launch_bounds__(kCuBlock, 1) flux_kernel_cu(const FluxArgs<R, 
     cu_fill_all();                                               // every table, one copy for the CU, one round trip (+ the workgroup's one and only s_barrier)
 #endif
     AB_TR();
-    unsigned gen = 0;
-    bool own = true;          // the team still works on tiles of its own; false: its waves help the other teams of the CU finish theirs
 #pragma unroll 1
     for (;;) {
         // what derives from the thread index (LDS addresses of the thread's cells, the masks of the sort's prefix scan ...) is formed again
         // for every tile: hoisted out of the tile loop it is fifty registers held, or spilled, around the whole iteration
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        int target = team;
-        long tile0 = 0;
-        int rounds = 0;
-        if (own) {
-            // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126
-            {
-                AB_ARGS;
-                long t = *s_tile;      // grabbed by thread 0 two team barriers ago (the first one: before the workgroup's barrier)
-                t = ((long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-                if (t < 0) {           // no tile (left): from here on every wave of the team is on its own
-                    own = false;
-#ifdef AB_CU_TRACE
-                    tr_own = wall_clock64();
-#endif
-                    if (tid == 0) __hip_atomic_store(&s_fina[team], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    continue;
-                }
-                tile_of(a, t, tile0, rounds);
-                tile_phase1<R, ALGO, SKIN, S, A>(a, tid, tile0, rounds, tile_fetch<R, S, SKIN>(a, tid, tile0, rounds, 0), s_f, s_cnt, s_inv);
-            }
-            sync();
-            AB_TR();
-            // ---- phase 2: who computes which cell; thread 0 asks for the team's next tile
-            {
-                AB_ARGS;
-                if (tid == 0) *s_tile = grab(a, false);      // (every thread of the team has read the current one before the barrier above)
-                tile_phase2<2>(a, tid, rounds, s_cnt, s_base, s_inv, sync);
-            }
-            sync();
-            AB_TR();
-            // ---- the tile's phase 3 opens: thread 0 publishes its group word; the team's waves start when they see this generation
-            ++gen;
-            if (tid == 0) {
-                s_tile0a[team] = tile0;
-                s_donea[team] = 0u;
-                __hip_atomic_store(&s_grpa[team], (gen << 16) | ((unsigned)(rounds * (kBlock / 64)) << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (*s_tile < 0) __hip_atomic_store(&s_fina[team], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);    // (after the word: who sees the flag sees the last word)
-            }
-            for (;;) {
-                unsigned w = __hip_atomic_load(&s_grpa[team], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
-                if ((w >> 16) == gen) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-        } else {
-            // ---- no tile of its own: a team of the CU that still has groups to hand out?  The slow teams first (the SIMD's arbiter serves
-            // the oldest wave first: team 3 runs a tile in 2.5 times the time of team 0, in-kernel trace of profiles/r5_notes.md).
-            target = -1;
-            bool all_done = true;
-#ifdef AB_CU_NOSTEAL
-            break;
-#endif
-#pragma unroll
-            for (int d = 0; d < kCuTeams; ++d) {
-                const int v = kCuTeams - 1 - d;
-                if (v == team) continue;
-                unsigned fin = __hip_atomic_load(&s_fina[v], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                unsigned w = __hip_atomic_load(&s_grpa[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                fin = (unsigned)__builtin_amdgcn_readfirstlane((int)fin);
-                w = (unsigned)__builtin_amdgcn_readfirstlane((int)w);
-                const bool left = (w & 0xffu) < ((w >> 8) & 0xffu);
-                if (left && target < 0) target = v;
-                all_done = all_done && fin != 0u && !left;
-            }
-            if (target < 0) {
-                if (all_done) break;
-                __builtin_amdgcn_s_sleep(8);
-                continue;
-            }
+        long tile0;
+        int rounds;
+        // ---- phase 1: owners load their cells (coalesced), pre-processing mod_aerobulk_compute.f90:99-126
+        {
+            AB_ARGS;
+            long t = *s_tile;      // grabbed by thread 0 two team barriers ago (the first one: before the workgroup's barrier)
+            t = ((long)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+            if (t < 0) break;
+            tile_of(a, t, tile0, rounds);
+            tile_phase1<R, ALGO, SKIN, S, A>(a, tid, tile0, rounds, tile_fetch<R, S, SKIN>(a, tid, tile0, rounds, 0), s_f, s_cnt, s_inv);
         }
-        // ---- phase 3: groups of 64 sorted cells of team `target`'s tile (one call site: the team's own tile, or a neighbour's)
-        { AB_ARGS; AB_DIAGS; cu_phase3<R, ALGO, SKIN, S, A>(a, dg, target, s_fa, s_inva, s_grpa, s_donea, s_tile0a); }
-        AB_TR();
-        if (!own) continue;
-        // every group of the tile in LDS (the team's own waves may have had help)
-        for (;;) {
-            unsigned dn = __hip_atomic_load(&s_donea[team], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            dn = (unsigned)__builtin_amdgcn_readfirstlane((int)dn);
-            if (dn == (unsigned)(rounds * (kBlock / 64))) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#ifdef AB_CU_SYNC4
         sync();
-#endif
         AB_TR();
-        // ---- phase 4: owners store (coalesced).  No barrier behind it: phase 4 reads and the next phase 1 writes a thread's OWN tile slots
+        // ---- phase 2: who computes which cell; thread 0 asks for the team's next tile
+        {
+            AB_ARGS;
+            if (tid == 0) *s_tile = grab(a, false);      // (every thread of the team has read the current one before the barrier above)
+            tile_phase2<2>(a, tid, rounds, s_cnt, s_base, s_inv, sync);
+        }
+        sync();
+        AB_TR();
+        // ---- phase 3: groups of 64 sorted cells, fetched from the team's queue
+        { AB_ARGS; AB_DIAGS; tile_phase3<R, ALGO, SKIN, false, S, A, 2>(a, dg, tid, tile0, rounds, s_f, s_inv, s_next); }
+        AB_TR();
+        sync();
+        AB_TR();
+        // ---- phase 4: owners store (coalesced).  No barrier behind it: phase 4 reads and the next phase 1 writes a thread's OWN tile slots, and
+        // the group queue is re-armed by thread 0 two team barriers ahead of its next use
         {
             AB_ARGS;
             tile_phase4<R, S>(a, tid, tile0, rounds, s_f);
+            if (tid == 0) *s_next = 0;
         }
         AB_TR();
     }
 #ifdef AB_CU_TRACE
     AB_TR();
-#ifdef AB_CU_TRACE_END      // every team: entry, end of its own last tile, exit (absolute 10 ns ticks), own tiles — printed when the whole workgroup is through
-    {
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&s_exit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (tid0 == 0) {
-            while (__hip_atomic_load(&s_exit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(kCuBlock / 64)) __builtin_amdgcn_s_sleep(16);
-            printf("CUEND %d %d %lld %lld %lld %d\n", (int)blockIdx.x, team, tr[0] % 100000000LL, tr_own % 100000000LL, tr[ntr - 1] % 100000000LL, (int)gen);
-        }
-    }
-#endif
     if ((blockIdx.x == 0 || blockIdx.x == 137) && tid0 == 0) {      // one printf per team: a line is one hostcall packet
         for (int i = ntr; i < 24; ++i) tr[i] = tr[0];
 #define T(i) (int)((tr[i] - tr[0]) * 10)
