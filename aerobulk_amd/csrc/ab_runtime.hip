@@ -832,6 +832,9 @@ int ab_session_check(ab_session *s)
             return fail(AB_ERR_STATE, "the tile counters of the persistent flux kernel were left at %d / %d / %d: a launch of this session was cut "
                                       "short, or two of its launches overlapped (one stream per session); the results since the last check are not valid",
                         fl[4], fl[5], fl[6]);
+        if (flags & 2)
+            return fail(AB_ERR_HIP, "the flux kernel read other arguments from its kernarg segment than it was passed by value: this build of the "
+                                    "library does not match the HIP runtime's argument layout (kernarg_at, ab_kernels.hip); results are not valid");
         if (flags & 1) return fail(AB_ERR_TAU, "BULK_FORMULA_VCTR()@mod_phymbl: wind stress too strong!\n => > 10 N/m^2 !");
     }
     return AB_OK;
@@ -1072,7 +1075,7 @@ int ab_model(int jt, int nt, const char *calgo, int calgo_len, double zt, double
         }
         if (g_sess->sharded()) {
             // every shard's copy streams make their first transfer alone (leaf_prepare_staging: the concurrency trap)
-            int rc = ab::sharded_prepare_staging(g_sess, lsrad, lsrad && t_s);
+            int rc = ab::sharded_prepare_staging(g_sess, lsrad && use_skin, lsrad && t_s);   // (radiation without l_use_skin is never read: mod_aerobulk_compute.f90:132; no staging for it)
             if (rc) return rc;
             // fused, sharded: every shard on its own device and PCIe link, the verdict on the combined statistics.  EVERY shard has
             // to qualify (the first shards are one row taller: the last may sit just under the threshold; round-3 advisory)

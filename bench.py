@@ -37,7 +37,7 @@ FP64_VECTOR_PEAK_TF = 78.6   # fp64 vector (VALU) peak, same guide: half the 157
 IN6 = ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp")
 SKIN_ALGOS = ("coare3p0", "coare3p6", "ecmwf")
 ALL_ALGOS = ("coare3p0", "coare3p6", "ncar", "ecmwf", "andreas")
-PMC_JSON = os.path.join(ROOT, "profiles", "r4_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r5_pmc.json")
 
 
 def kernel_label(precision, algo, skin, n_cells, ab):
@@ -73,7 +73,7 @@ def kernel_source_hash():
 
 
 def committed_pmc(algo, skin, ni, nj, niter, precision):
-    """Hardware-counter figures of the committed rocprofv3 run of exactly this workload (profiles/r4_pmc.json, written by
+    """Hardware-counter figures of the committed rocprofv3 run of exactly this workload (profiles/r5_pmc.json, written by
     tools/update_pmc.py from a tools/prof_quick.sh run), or None.  bench.py cannot collect counters itself.  They are only
     quoted when the profile was taken with the device code that is running now (source hash), and every figure derived from
     them uses the PROFILE's own kernel duration, never a live timing."""

@@ -149,8 +149,6 @@ def tier_of(nodeid):
     name = nodeid.split("::", 1)[1] if "::" in nodeid else ""
     if f in ("test_gpu_golden.py", "test_gpu_parity.py", "test_illcond_cells.py", "test_bistable_cells.py", "test_gpu_cu_kernel.py", "test_phymbl.py"):
         return 1                                                           # (test_phymbl.py: the Fortran side of the drop-in boundary, incl. the reference's unchanged example)
-    if f == "test_cx_vs_wind.py":
-        return 3 if "unchanged_sweep_driver" in name else 2                # the reference's driver itself: two million one-cell launches
     if f == "test_gpu_hosts.py":
         if name.startswith("test_bench_sharded_path_several_ranks_one_gpu"):
             return 2 if any(t in name for t in _BENCH_T2) else 3
