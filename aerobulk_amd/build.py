@@ -69,7 +69,8 @@ REF = os.environ.get("AEROBULK_REFERENCE", "/root/reference")
 # Callers of the reference compiled UNCHANGED, where they lie, against the modules above (the drop-in check of SURVEY §8b): binaries
 # go to oracle/_ref/dropin/ (git-ignored, travels to the GPU box like the other reference builds).  Build container only.
 REF_CALLERS = ["src/tests/example_call_aerobulk.f90", "src/tests/test_cx_vs_wind.f90", "src/tests/test_coef_n10.f90",
-               "src/tests/aerobulk_toy.F90", "src/tests/test_phymbl.f90", "src/ice/test_ice.f90", "src/ice/test_aerobulk_ice.f90"]
+               "src/tests/aerobulk_toy.F90", "src/tests/test_phymbl.f90", "src/ice/test_ice.f90", "src/ice/test_aerobulk_ice.f90",
+               "src/ice/test_aerobulk_oce+ice.f90"]
 DROPIN = os.path.join(ROOT, "oracle", "_ref", "dropin")
 
 

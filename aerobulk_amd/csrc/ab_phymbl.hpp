@@ -24,7 +24,7 @@ enum {
     kPhGammaMoist, kPhOneOnL, kPhRiBulk, kPhEsat, kPhEsatIce, kPhDEsatDtIce, kPhQsat, kPhDQsatDtIce, kPhQairRh, kPhQairDp,
     kPhRhoAirAdv, kPhQsatCrude, kPhDryStaticEnergy, kPhUpdateQnsolTau, kPhBulkFormula, kPhAlphaSw, kPhQlwNet, kPhZ0FromCd,
     kPhZ0FromUstar, kPhCdFromZ0, kPhFmLouis, kPhFhLouis, kPhUN10FromUstar, kPhUN10FromCdn, kPhUN10FromCd, kPhZ0tqLkb, kPhEair,
-    kPhRhAir, kPhDeltaSkinLayer, kPhCount
+    kPhRhAir, kPhDeltaSkinLayer, kPhRoughLengM, kPhRoughLengTq, kPhCount
 };
 
 template <class R> struct KPh {   // the constants of mod_const.f90 / mod_phymbl.f90 that the flux kernels do not need
@@ -237,6 +237,12 @@ template <int FN, class R> __device__ __forceinline__ void ph_cell(const R *x, u
         y[0] = R(100.) * M::div(x[3], e_sat<R, false>(x[1]));
     } else if constexpr (FN == kPhDeltaSkinLayer) {  // delta_skin_layer_sclr :2010-2046  ( palpha, pQd, pustar_a, [Qlat] )
         y[0] = delta_skin_layer<R>(x[0], x[1], x[2], (present & 8u) != 0, (present & 8u) ? x[3] : R(0.));
+    } else if constexpr (FN == kPhRoughLengM) {      // rough_leng_m, src/ice/mod_blk_ice_an05.f90:232-255  ( pus, pnua ): Andreas et al. 2005 eq. 19
+        y[0] = an05_rough_leng_m<R>(x[0], x[1]);
+    } else if constexpr (FN == kPhRoughLengTq) {     // rough_leng_tq, src/ice/mod_blk_ice_an05.f90:257-312  ( pz0, pus, pnua ) -> z0t, z0q (eq. 22)
+        R lt, lq;
+        an05_log_z0tq<R>(x[0], R(0.), x[1], x[2], lt, lq);       // LOG(z0s / z0)
+        y[0] = x[0] * M::exp(lt); y[1] = x[0] * M::exp(lq);
     }
 }
 
@@ -272,6 +278,8 @@ constexpr PhShape ph_shape(int fn)
     case kPhEair: return {2, 2, 1};
     case kPhRhAir: return {3, 3, 1};
     case kPhDeltaSkinLayer: return {4, 3, 1};
+    case kPhRoughLengM: return {2, 2, 1};
+    case kPhRoughLengTq: return {3, 3, 2};
     default: return {0, 0, 0};
     }
 }

@@ -16,7 +16,7 @@ MODULE mod_ab_ice
    USE mod_const, ONLY: wp, nb_iter
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: ab_ice_generic, ab_ice_easy
+   PUBLIC :: ab_ice_generic, ab_ice_easy, ab_ice_helper
 
    !! mirror of `ab_ice_fields` (include/aerobulk_amd.h)
    TYPE, BIND(C) :: ab_ice_fields
@@ -45,6 +45,16 @@ MODULE mod_ab_ice
          TYPE(C_PTR),     VALUE :: stream
          INTEGER(C_INT) :: istat
       END FUNCTION ab_turb_ice_easy
+      FUNCTION ab_phymbl( fn, n, pin, n_in, pout, n_out, par, iflag, mem, stream, info ) BIND(C, NAME='ab_phymbl') RESULT(istat)
+         IMPORT :: C_INT, C_LONG, C_PTR, C_DOUBLE
+         INTEGER(C_INT),  VALUE :: fn, n_in, n_out, iflag, mem
+         INTEGER(C_LONG), VALUE :: n
+         TYPE(C_PTR), DIMENSION(*), INTENT(in) :: pin, pout
+         REAL(C_DOUBLE), DIMENSION(2), INTENT(in) :: par
+         TYPE(C_PTR),     VALUE :: stream
+         REAL(C_DOUBLE), DIMENSION(2), INTENT(out) :: info
+         INTEGER(C_INT) :: istat
+      END FUNCTION ab_phymbl
       FUNCTION ab_last_error() BIND(C, NAME='ab_last_error') RESULT(cptr)
          IMPORT :: C_PTR
          TYPE(C_PTR) :: cptr
@@ -57,6 +67,27 @@ MODULE mod_ab_ice
    END INTERFACE
 
 CONTAINS
+
+   SUBROUTINE ab_ice_helper( fn, n, a1, a2, o1, a3, o2 )
+      !! the PUBLIC helper functions of mod_blk_ice_an05 (rough_leng_m, rough_leng_tq) on the engine: `ab_phymbl` functions 40 / 41
+      INTEGER, INTENT(in) :: fn, n
+      REAL(wp), DIMENSION(n), INTENT(in),  TARGET           :: a1, a2
+      REAL(wp), DIMENSION(n), INTENT(out), TARGET           :: o1
+      REAL(wp), DIMENSION(n), INTENT(in),  TARGET, OPTIONAL :: a3
+      REAL(wp), DIMENSION(n), INTENT(out), TARGET, OPTIONAL :: o2
+      TYPE(C_PTR), DIMENSION(3) :: pin
+      TYPE(C_PTR), DIMENSION(2) :: pout
+      REAL(C_DOUBLE), DIMENSION(2) :: par, zinfo
+      INTEGER(C_INT) :: istat
+      pin = (/ C_LOC(a1), C_LOC(a2), C_NULL_PTR /) ; pout = (/ C_LOC(o1), C_NULL_PTR /) ; par = 0._C_DOUBLE
+      IF( PRESENT(a3) ) pin(3)  = C_LOC(a3)
+      IF( PRESENT(o2) ) pout(2) = C_LOC(o2)
+      istat = ab_phymbl( INT(fn,C_INT), INT(n,C_LONG), pin, 3_C_INT, pout, 2_C_INT, par, 0_C_INT, 0_C_INT, C_NULL_PTR, zinfo )
+      IF( istat /= 0 ) THEN
+         WRITE(6,*) ' *** E R R O R : mod_blk_ice_an05 (aerobulk_amd): ab_phymbl status', INT(istat)
+         STOP
+      END IF
+   END SUBROUTINE ab_ice_helper
 
    SUBROUTINE stop_with_library_message()
       TYPE(C_PTR) :: cp
@@ -175,7 +206,22 @@ MODULE mod_blk_ice_an05
    IMPLICIT NONE
    PRIVATE
    PUBLIC :: TURB_ICE_AN05
+   PUBLIC :: rough_leng_m, rough_leng_tq
 CONTAINS
+   FUNCTION rough_leng_m( pus , pnua )                                        !! reference :232-255 (Andreas et al. 2005, eq. 19)
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pus, pnua
+      REAL(wp), DIMENSION(SIZE(pus,1),SIZE(pus,2)) :: rough_leng_m
+      CALL ab_ice_helper( 40, SIZE(pus), pus, pnua, rough_leng_m )
+   END FUNCTION rough_leng_m
+
+   FUNCTION rough_leng_tq( pz0, pus , pnua )                                  !! :257-312 (eq. 22): (:,:,1) temperature, (:,:,2) humidity
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pz0, pus, pnua
+      REAL(wp), DIMENSION(SIZE(pus,1),SIZE(pus,2),2) :: rough_leng_tq
+      REAL(wp), DIMENSION(SIZE(pus,1),SIZE(pus,2)) :: zt, zq
+      CALL ab_ice_helper( 41, SIZE(pus), pz0, pus, zt, a3=pnua, o2=zq )
+      rough_leng_tq(:,:,1) = zt ; rough_leng_tq(:,:,2) = zq
+   END FUNCTION rough_leng_tq
+
    SUBROUTINE TURB_ICE_AN05( zt, zu, Ts_i, t_zt, qs_i, q_zt, U_zu,         &
       &                      Cd_i, Ch_i, Ce_i, t_zu_i, q_zu_i, Ubzu,                   &
       &                      CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )

@@ -334,7 +334,10 @@ enum ab_phymbl_fn {
     AB_PH_Z0TQ_LKB = 36,            /* pRer, pz0 ; iflag ; z0t | z0q                         :1635-1701 */
     AB_PH_E_AIR = 37,               /* pqa, pslp ; - ; e  (fixed point on the WHOLE array: SUM |change| <= 1e-6)   :1706-1736 */
     AB_PH_RH_AIR = 38,              /* pqa, pTa, pslp ; - ; RH [%]                           :1741-1753 */
-    AB_PH_DELTA_SKIN_LAYER = 39     /* palpha, pQd, pustar_a, [Qlat] ; - ; delta             :2010-2046 */
+    AB_PH_DELTA_SKIN_LAYER = 39,    /* palpha, pQd, pustar_a, [Qlat] ; - ; delta             :2010-2046 */
+    /* the two PUBLIC helpers of src/ice/mod_blk_ice_an05.f90 (Andreas et al. 2005), used by src/ice/test_ice.f90:49,55 */
+    AB_PH_ROUGH_LENG_M = 40,        /* pus, pnua ; - ; z0 over sea ice                       mod_blk_ice_an05.f90:232-255 */
+    AB_PH_ROUGH_LENG_TQ = 41        /* pz0, pus, pnua ; - ; z0t, z0q                         mod_blk_ice_an05.f90:257-312 */
 };
 int ab_phymbl(int fn, long n, const double *const *in, int n_in, double *const *out, int n_out, const double *par, int flag,
               int mem, void *stream, double *info);

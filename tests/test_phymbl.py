@@ -140,7 +140,7 @@ def test_reference_callers_compile_unchanged():
     from aerobulk_amd import build
     built = [os.path.basename(p) for p in build.build_reference_callers()]
     for want in ("example_call_aerobulk.x", "example_call_aerobulk_cxx.x", "test_cx_vs_wind.x", "aerobulk_toy.x", "test_phymbl.x",
-                 "test_aerobulk_ice.x"):
+                 "test_aerobulk_ice.x", "test_aerobulk_oce_ice.x"):
         assert want in built, (want, built)
 
 
