@@ -14,4 +14,5 @@ rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F6
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o bench -- python3 $ARGS > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o bench -- python3 $ARGS > $O/pmc_write.log 2>&1
 python3 tools/rocpd_summary.py $O/stats/bench_results.db $O/pmc_sq/bench_results.db $O/pmc_f64/bench_results.db $O/pmc_fetch/bench_results.db $O/pmc_write/bench_results.db 2>&1 | grep -E "^==|flux_kernel|kernel  |-- PMC" | cut -c1-175 > $O/summary.txt
-tail -3 $O/stats.log | cut -c1-400
+rm -rf $O/stats $O/pmc_sq $O/pmc_f64 $O/pmc_fetch $O/pmc_write      # (the rocpd databases: only the summary travels back)
+tail -1 $O/stats.log | cut -c1-300

@@ -50,6 +50,9 @@ def main():
             "trans_f32_insts_per_launch": val("SQ_INSTS_VALU_TRANS_F32"),
             "waves_per_launch": val("SQ_WAVES"),
         }
+        if rec["valu_busy"] and rec["valu_busy"] > 1.:      # the formula is calibrated on fp64 kernels (four cycles per issued instruction); fp32 kernels
+            rec["valu_busy_uncalibrated"] = rec.pop("valu_busy")   # with more than four waves per SIMD exceed it: reported, not interpreted
+            rec["valu_busy"] = None
         recs[k] = rec
     doc = {"source": f"profiles/{a.name}_flux_kernel.txt (rocprofv3 --pmc in separate passes, MI355X; tools/prof_quick.sh): {a.what}",
            "cells_per_launch": a.cells, "source_hash": bench.kernel_source_hash(), "kernels": recs}
