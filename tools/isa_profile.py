@@ -277,7 +277,7 @@ def cmd_build(a):
     host = os.path.join(var, f"k_{a.tag}.o")
     subprocess.check_call(["hipcc", *flags, *inc, "-DAB_ISA_PROFILE", "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, "-c", src, "-o", host])
     lib = os.path.join(var, f"libab_{a.tag}.so")
-    others = [os.path.join(CSRC, f) for f in ("ab_turb_kernels.o", "ab_ice_kernels.o", "ab_runtime.o", "ab_sharded.o", "ab_cxx.o")]
+    others = [os.path.join(CSRC, f) for f in ("ab_turb_kernels.o", "ab_ice_kernels.o", "ab_phymbl.o", "ab_runtime.o", "ab_sharded.o", "ab_cxx.o")]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, host, *others])
     for f in (s_out, obj, hsaco, fb, host):      # intermediates: tens of MB each, and build/var travels to the GPU box
         os.remove(f)

@@ -75,7 +75,7 @@ def build(kernel):
         host = os.path.join(var, f"k_{tag}.o")
         subprocess.check_call(["hipcc", *flags, *inc, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, "-c", src, "-o", host])
         lib = os.path.join(var, f"libab_{tag}.so")
-        others = [os.path.join(ip.CSRC, f) for f in ("ab_turb_kernels.o", "ab_ice_kernels.o", "ab_runtime.o", "ab_sharded.o", "ab_cxx.o")]
+        others = [os.path.join(ip.CSRC, f) for f in ("ab_turb_kernels.o", "ab_ice_kernels.o", "ab_phymbl.o", "ab_runtime.o", "ab_sharded.o", "ab_cxx.o")]
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, host, *others])
         for f in (s_out, obj, hsaco, fb, host):
             os.remove(f)
