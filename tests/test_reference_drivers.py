@@ -1,4 +1,4 @@
-"""The reference's own drivers — the interactive toy src/tests/aerobulk_toy.F90 and src/ice/test_ice.f90, not a character changed — compiled against this repository's
+"""The reference's own drivers — the interactive toy src/tests/aerobulk_toy.F90, src/tests/test_phymbl.f90 and src/ice/test_ice.f90, not a character changed — compiled against this repository's
 Fortran modules (mod_const, mod_phymbl, mod_blk_coare3p0 / coare3p6 / ncar / ecmwf / andreas -> libaerobulk_amd.so -> HIP kernels;
 oracle/_ref/dropin/aerobulk_toy.x, aerobulk_amd/build.py) and fed the inputs of the reference's test_algos.sh: every number it prints
 (TURB_* with all OPTIONAL outputs, BULK_FORMULA, Ri_bulk, Theta_from_z_P0_T_q, q_sat, rho_air ... the five algorithms side by side, the
@@ -38,7 +38,7 @@ def test_golden_holds_the_readme_table():
     cd = labelled(toy["stdout"], "C_D    ")
     assert len(cd) == 5
     np.testing.assert_allclose(cd, [1.1954, 1.0775, 1.2038, 1.2862, 1.0167], rtol=3e-3)     # coare3p0 coare3p6 ncar ecmwf andreas
-    assert all(len(numbers(c["stdout"])) > 150 for c in CASES)
+    assert all(len(numbers(c["stdout"])) > (10 if c.get("exe") == "test_phymbl" else 150) for c in CASES)
 
 
 @pytest.mark.gpu
@@ -50,7 +50,12 @@ def test_unchanged_driver_prints_what_it_prints_with_the_reference(case):
     pr = subprocess.run([exe, *case["args"]], input=case["stdin"], capture_output=True, text=True, timeout=600)
     assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-2000:]
     got, ref = numbers(pr.stdout), numbers(case["stdout"])
-    assert len(got) == len(ref) and len(ref) > 150, (len(got), len(ref))
+    assert len(got) == len(ref) and len(ref) > (10 if case.get("exe") == "test_phymbl" else 150), (len(got), len(ref))
+    if case.get("exe") == "test_phymbl":
+        # src/tests/test_phymbl.f90, its potential-temperature / pressure branch: q_sat, Theta_from_z_P0_T_q, Pz_from_P0_tz_qz, pot_temp with the
+        # OPTIONAL pPref, gamma_moist — scalar specifics (one-cell kernels); f7.3 / REAL(.,4) fields and two numbers at full precision
+        np.testing.assert_allclose(got, ref, rtol=3e-7, atol=1e-9)
+        return
     if case.get("exe") == "test_ice":
         # rough_leng_m / rough_leng_tq of mod_blk_ice_an05 (here: ab_phymbl functions 40 / 41) on 101 friction velocities, printed at 17 digits
         np.testing.assert_allclose(got, ref, rtol=1e-12)

@@ -11,6 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     {"name": "test_ice", "exe": "test_ice", "args": [], "stdin": "-10.\n"},                       # air temperature [deg.C]; 17-digit output
+    {"name": "test_phymbl", "exe": "test_phymbl", "args": [], "stdin": "10.\n15.\n8.\n"},      # height [m], T [deg.C], q [g/kg]: theta / pressure branch
     {"name": "test_algos.sh", "args": [], "stdin": "10.\n2.\n22.\n20.\n12.\n5\n"},              # zu zt SST t_zt q_zt[g/kg] wind: the README's table
     {"name": "skin schemes", "args": ["-S"], "stdin": "10.\n2.\n22.\n20.\n12.\n5\n600.\n350.\n"},    # + rad_sw, rad_lw
     {"name": "relative humidity, stable", "args": ["-r"], "stdin": "10.\n2.\n22.\n25.\n80.\n9\n"},
