@@ -459,6 +459,7 @@ def main():
     ap.add_argument("--no-skin", action="store_true")
     ap.add_argument("--skin", action="store_true", help="config 4: switch the skin scheme on for the three algorithms that have one")
     ap.add_argument("--niter", type=int, default=None)
+    ap.add_argument("--no-nb-iter-8", action="store_true", help="skip the headline's companion pass at nb_iter = 8 (profiling runs: one kernel configuration per trace)")
     ap.add_argument("--grid", default=None)
     ap.add_argument("--precision", default=None, choices=["f64", "f32", "f32_storage", "f32_mixed"],
                     help="f32_storage: fp32 arrays with fp64 arithmetic (AB_F32_STORAGE); f32_mixed: fp32 arrays, fp64 anchors (SST, theta, "
@@ -799,7 +800,7 @@ def main():
     # BASELINE config 3 is quoted at nb_iter = 5; the reference's default is nb_iter0 = 8 (mod_const.f90:25): the same K steps at 8, reported
     # beside the headline (never as `value`)
     alt8 = None
-    if world == 1 and a.config == 3 and a.niter is None and not gathered:
+    if world == 1 and a.config == 3 and a.niter is None and not gathered and not a.no_nb_iter_8 and (head_algo, head_skin, ni, nj) == ("coare3p6", True, 4320, 3600):
         def step8():
             for w in work:
                 if w is not None:
