@@ -1,21 +1,22 @@
 ! phymbl_driver.f90 -- calls every public function of `mod_phymbl` on columns of numbers read from a file and writes the results.
 !
-! Own source (it only USEs the public interface of mod_const / mod_phymbl).  Built twice: against this repository's modules
+! Own source (it only USEs the public interface of mod_const / mod_phymbl and the two helper functions of mod_blk_ice_an05).  Built twice: against this repository's modules
 ! (aerobulk_amd/build.py -> phymbl_driver.x: Fortran host -> C ABI -> HIP kernels) and, in the build container, against the
 ! UNMODIFIED reference modules (oracle/Makefile -> oracle/_ref/ref_phymbl_driver.x), whose output is the golden data of
 ! tests/test_phymbl.py (tools/gen_phymbl_golden.py).
 !
 !   phymbl_driver.x <in.bin> <out.bin>
-!   in : int32 n ; 29 columns of n doubles (order below)
+!   in : int32 n ; 30 columns of n doubles (order below)
 !   out: records { character(24) name ; int32 m ; m doubles }.  `_s` records: the scalar specific on the first min(n,8) cells.
 PROGRAM phymbl_driver
 
    USE mod_const
    USE mod_phymbl
+   USE mod_blk_ice_an05, ONLY: rough_leng_m, rough_leng_tq     ! the two PUBLIC helper functions of the sea-ice module (ice/test_ice.f90 calls them)
 
    IMPLICIT NONE
 
-   INTEGER, PARAMETER :: ncol = 29, ns_max = 8
+   INTEGER, PARAMETER :: ncol = 30, ns_max = 8
    REAL(wp), PARAMETER :: pz = 2._wp, pzu = 10._wp
    INTEGER(4) :: n4
    INTEGER :: n, ns, k
@@ -26,7 +27,7 @@ PROGRAM phymbl_driver
    !! columns
    INTEGER, PARAMETER :: iTa=1, iTs=2, iP=3, iqa=4, iqs=5, iTh=6, iPz=7, ius=8, itst=9, iqst=10, iW=11, iUb=12, iCd=13, iCh=14, &
       &                  iCe=15, ipsi=16, iz0=17, iRib=18, irlw=19, irh=20, idp=21, irho=22, iRer=23, ialp=24, iQd=25, iQlt=26,   &
-      &                  iTly=27, iqly=28, iTi=29
+      &                  iTly=27, iqly=28, iTi=29, inua=30
 
    CALL GET_COMMAND_ARGUMENT(1, cfin)
    CALL GET_COMMAND_ARGUMENT(2, cfout)
@@ -179,6 +180,16 @@ PROGRAM phymbl_driver
    END DO
    CALL puts('z0_from_cd_psi_s', s1) ; CALL puts('z0_from_ustar_s', s2) ; CALL puts('f_m_louis_s', s3) ; CALL puts('f_h_louis_s', s4)
    CALL puts('un10_from_cd_s', s5)
+
+   !! ---- roughness lengths over sea ice (Andreas et al. 2005), functions of u* and the air's viscosity
+   BLOCK
+      REAL(wp), DIMENSION(:,:,:), ALLOCATABLE :: ztq
+      ALLOCATE( ztq(n,1,2) )
+      r1 = rough_leng_m( c(:,:,ius), c(:,:,inua) )                 ; CALL put('rough_leng_m', r1)
+      ztq = rough_leng_tq( c(:,:,iz0), c(:,:,ius), c(:,:,inua) )
+      r3 = ztq(:,:,1)                                              ; CALL put('rough_leng_t', r3)
+      r3 = ztq(:,:,2)                                              ; CALL put('rough_leng_q', r3)
+   END BLOCK
 
    !! ---- host-side statistics
    s1(1) = VARIANCE( c(:,1,iTa) ) ; s1(2) = VMEAN( c(:,1,iTa) )

@@ -46,7 +46,7 @@ def test_golden_covers_every_function(gold):
     cols, rec = gold
     assert cols.shape == (len(pc.COLUMNS), 512)
     fns = {c[0] for c in pc.CALLS.values()}
-    assert fns == set(range(1, 40)), sorted(set(range(1, 40)) - fns)       # all 39 ids of enum ab_phymbl_fn
+    assert fns == set(range(1, 42)), sorted(set(range(1, 42)) - fns)       # all 41 ids of enum ab_phymbl_fn
     for name in list(pc.CALLS) + pc.EXTRA:
         assert name in rec, name
     # every `_s` record of the driver (the scalar specifics) equals the array record on the first cells IN THE REFERENCE ITSELF to
