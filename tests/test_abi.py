@@ -76,6 +76,30 @@ def test_sharded_session_arguments_need_no_gpu(lib):
         assert not h.value
 
 
+def test_helper_entry_argument_errors_need_no_gpu(lib):
+    """ab_phymbl (the mod_phymbl helpers, include/aerobulk_amd.h) rejects malformed calls with AB_ERR_ARG before it looks for a device."""
+    import numpy as np
+    x = np.full(8, 290.0)
+    y = np.zeros(8)
+    pin = (C.c_void_p * 3)(x.ctypes.data, x.ctypes.data, None)
+    pout = (C.c_void_p * 2)(y.ctypes.data, None)
+    par = (C.c_double * 2)(2.0, 0.0)
+    f = lib.ab_phymbl
+    ARG = 10
+    assert f(0, 8, pin, 2, pout, 1, par, 0, 0, None, None) == ARG and b"unknown function" in lib.ab_last_error()
+    assert f(42, 8, pin, 2, pout, 1, par, 0, 0, None, None) == ARG
+    assert f(3, 0, pin, 2, pout, 1, par, 0, 0, None, None) == ARG                      # virt_temp on no cells
+    assert f(3, 8, None, 2, pout, 1, par, 0, 0, None, None) == ARG
+    assert f(3, 8, pin, 1, pout, 1, par, 0, 0, None, None) == ARG                      # virt_temp needs two arrays
+    assert f(3, 8, pin, 2, pout, 1, par, 0, 7, None, None) == ARG and b"bad mem" in lib.ab_last_error()
+    pin_hole = (C.c_void_p * 3)(x.ctypes.data, None, None)
+    assert f(3, 8, pin_hole, 2, pout, 1, par, 0, 0, None, None) == ARG and b"required input" in lib.ab_last_error()
+    pout_none = (C.c_void_p * 2)(None, None)
+    assert f(3, 8, pin, 2, pout_none, 1, par, 0, 0, None, None) == ARG and b"no output" in lib.ab_last_error()
+    if lib.ab_device_count() == 0:      # a well-formed call without a GPU: AB_ERR_HIP, the arrays untouched
+        assert f(3, 8, pin, 2, pout, 1, par, 0, 0, None, None) == 9 and not y.any()
+
+
 def test_no_cpu_fallback(lib):
     """Without a visible GPU the product path must fail loudly (AB_ERR_HIP), never compute on the host."""
     if lib.ab_device_count() > 0:
