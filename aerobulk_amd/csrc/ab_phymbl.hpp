@@ -24,8 +24,12 @@ enum {
     kPhGammaMoist, kPhOneOnL, kPhRiBulk, kPhEsat, kPhEsatIce, kPhDEsatDtIce, kPhQsat, kPhDQsatDtIce, kPhQairRh, kPhQairDp,
     kPhRhoAirAdv, kPhQsatCrude, kPhDryStaticEnergy, kPhUpdateQnsolTau, kPhBulkFormula, kPhAlphaSw, kPhQlwNet, kPhZ0FromCd,
     kPhZ0FromUstar, kPhCdFromZ0, kPhFmLouis, kPhFhLouis, kPhUN10FromUstar, kPhUN10FromCdn, kPhUN10FromCd, kPhZ0tqLkb, kPhEair,
-    kPhRhAir, kPhDeltaSkinLayer, kPhRoughLengM, kPhRoughLengTq, kPhCount
+    kPhRhAir, kPhDeltaSkinLayer, kPhRoughLengM, kPhRoughLengTq,
+    // the PUBLIC functions of the algorithm modules (mod_common_coare, mod_blk_coare3p0 / coare3p6 / ncar / ecmwf / andreas)
+    kPhPsiMCoare, kPhPsiHCoare, kPhPsiMNcar, kPhPsiHNcar, kPhPsiMEcmwf, kPhPsiHEcmwf, kPhPsiMAndreas, kPhPsiHAndreas,
+    kPhCharnCoare3p0, kPhCharnCoare3p6, kPhCdN10Ncar, kPhChN10Ncar, kPhCeN10Ncar, kPhUStarAndreas, kPhCount
 };
+static_assert(kPhPsiMCoare == 42 && kPhUStarAndreas == 55, "enum ab_phymbl_fn of include/aerobulk_amd.h");
 
 template <class R> struct KPh {   // the constants of mod_const.f90 / mod_phymbl.f90 that the flux kernels do not need
     static constexpr R rtt0 = R(273.16);                    // mod_const.f90:61
@@ -243,6 +247,37 @@ template <int FN, class R> __device__ __forceinline__ void ph_cell(const R *x, u
         R lt, lq;
         an05_log_z0tq<R>(x[0], R(0.), x[1], x[2], lt, lq);       // LOG(z0s / z0)
         y[0] = x[0] * M::exp(lt); y[1] = x[0] * M::exp(lq);
+    // ---- the stability functions and neutral coefficients the algorithm modules export: the very device functions of the flux kernels
+    // (ab_physics.hpp), in their forms without LDS tables, valid on the whole real axis of zeta (the closed forms beyond the tables' range)
+    } else if constexpr (FN == kPhPsiMCoare) {       // psi_m_coare, mod_common_coare.f90:217-302  ( pzeta )
+        psi_coare<R>(x[0], &y[0], nullptr);
+    } else if constexpr (FN == kPhPsiHCoare) {       // psi_h_coare :305-392
+        psi_coare<R>(x[0], nullptr, &y[0]);
+    } else if constexpr (FN == kPhPsiMNcar) {        // psi_m_ncar, mod_blk_ncar.f90:333-376
+        psi_ncar<R, false>(x[0], &y[0], nullptr);
+    } else if constexpr (FN == kPhPsiHNcar) {        // psi_h_ncar :379-420
+        psi_ncar<R, false>(x[0], nullptr, &y[0]);
+    } else if constexpr (FN == kPhPsiMEcmwf) {       // psi_m_ecmwf, mod_blk_ecmwf.f90:441-495
+        psi_ecmwf<R>(x[0], &y[0], nullptr);
+    } else if constexpr (FN == kPhPsiHEcmwf) {       // psi_h_ecmwf :498-548
+        psi_ecmwf<R>(x[0], nullptr, &y[0]);
+    } else if constexpr (FN == kPhPsiMAndreas) {     // psi_m_andreas, mod_blk_andreas.f90:307-360
+        y[0] = psi_m_andreas<R, false>(x[0]);
+    } else if constexpr (FN == kPhPsiHAndreas) {     // psi_h_andreas :363-410
+        y[0] = psi_h_andreas<R>(x[0]);
+    } else if constexpr (FN == kPhCharnCoare3p0) {   // charn_coare3p0, mod_blk_coare3p0.f90:420-447  ( pwnd )
+        y[0] = charn_coare3p0<R>(x[0]);
+    } else if constexpr (FN == kPhCharnCoare3p6) {   // charn_coare3p6, mod_blk_coare3p6.f90:417-445  ( pwnd )
+        y[0] = charn_coare3p6<R>(x[0]);
+    } else if constexpr (FN == kPhCdN10Ncar) {       // cd_n10_ncar, mod_blk_ncar.f90:244-284  ( pw10 )
+        y[0] = cd_n10_ncar<R>(x[0]);
+    } else if constexpr (FN == kPhChN10Ncar) {       // ch_n10_ncar :287-310  ( psqrtcdn10, pstab in [0, 1] )
+        y[0] = vmax(R(1.e-3) * x[0] * (R(18.) * x[1] + R(32.7) * (R(1.) - x[1])), K<R>::Cx_min);
+    } else if constexpr (FN == kPhCeN10Ncar) {       // ce_n10_ncar :313-330  ( psqrtcdn10 )
+        y[0] = vmax(R(1.e-3) * (R(34.6) * x[0]), K<R>::Cx_min);
+    } else if constexpr (FN == kPhUStarAndreas) {    // u_star_andreas, mod_blk_andreas.f90:275-305  ( pun10 )
+        const R za = x[0] - R(8.271);
+        y[0] = R(0.239) + R(0.0433) * (za + M::sqrt(R(0.12) * za * za + R(0.181)));
     }
 }
 
@@ -280,6 +315,10 @@ constexpr PhShape ph_shape(int fn)
     case kPhDeltaSkinLayer: return {4, 3, 1};
     case kPhRoughLengM: return {2, 2, 1};
     case kPhRoughLengTq: return {3, 3, 2};
+    case kPhPsiMCoare: case kPhPsiHCoare: case kPhPsiMNcar: case kPhPsiHNcar: case kPhPsiMEcmwf: case kPhPsiHEcmwf:
+    case kPhPsiMAndreas: case kPhPsiHAndreas: case kPhCharnCoare3p0: case kPhCharnCoare3p6: case kPhCdN10Ncar: case kPhCeN10Ncar:
+    case kPhUStarAndreas: return {1, 1, 1};
+    case kPhChN10Ncar: return {2, 2, 1};
     default: return {0, 0, 0};
     }
 }

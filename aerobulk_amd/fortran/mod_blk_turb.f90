@@ -18,7 +18,7 @@ MODULE mod_ab_turb
    USE mod_const, ONLY: wp, nb_iter
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: ab_turb_generic
+   PUBLIC :: ab_turb_generic, ab_fn_arrays, ab_fn_scalar
 
    !! mirror of `ab_diag` (include/aerobulk_amd.h)
    TYPE, BIND(C) :: ab_diag
@@ -36,6 +36,16 @@ MODULE mod_ab_turb
          INTEGER(C_LONG), VALUE :: ni, nj
          INTEGER(C_INT) :: istat
       END FUNCTION ab_turb
+      FUNCTION ab_phymbl( fn, n, pin, n_in, pout, n_out, par, iflag, mem, stream, info ) BIND(C, NAME='ab_phymbl') RESULT(istat)
+         IMPORT :: C_INT, C_LONG, C_PTR, C_DOUBLE
+         INTEGER(C_INT),  VALUE :: fn, n_in, n_out, iflag, mem
+         INTEGER(C_LONG), VALUE :: n
+         TYPE(C_PTR), DIMENSION(*), INTENT(in) :: pin, pout
+         REAL(C_DOUBLE), DIMENSION(2), INTENT(in) :: par
+         TYPE(C_PTR),     VALUE :: stream
+         REAL(C_DOUBLE), DIMENSION(2), INTENT(out) :: info
+         INTEGER(C_INT) :: istat
+      END FUNCTION ab_phymbl
       FUNCTION ab_last_error() BIND(C, NAME='ab_last_error') RESULT(cptr)
          IMPORT :: C_PTR
          TYPE(C_PTR) :: cptr
@@ -48,6 +58,40 @@ MODULE mod_ab_turb
    END INTERFACE
 
 CONTAINS
+
+   SUBROUTINE ab_fn_arrays( fn, n, a1, o1, a2 )
+      !! the PUBLIC functions of the algorithm modules (psi_m / psi_h of the five algorithms, the Charnock parameters, NCAR's neutral coefficients,
+      !! ANDREAS' friction velocity) on the engine: helper functions 42-55 of `ab_phymbl` (include/aerobulk_amd.h), one elementwise HIP kernel each
+      INTEGER, INTENT(in) :: fn, n
+      REAL(wp), DIMENSION(n), INTENT(in),  TARGET           :: a1
+      REAL(wp), DIMENSION(n), INTENT(out), TARGET           :: o1
+      REAL(wp), DIMENSION(n), INTENT(in),  TARGET, OPTIONAL :: a2
+      TYPE(C_PTR), DIMENSION(2) :: pin
+      TYPE(C_PTR), DIMENSION(1) :: pout
+      REAL(C_DOUBLE), DIMENSION(2) :: par, zinfo
+      INTEGER(C_INT) :: istat
+      pin = (/ C_LOC(a1), C_NULL_PTR /) ; pout = (/ C_LOC(o1) /) ; par = 0._C_DOUBLE
+      IF( PRESENT(a2) ) pin(2) = C_LOC(a2)
+      istat = ab_phymbl( INT(fn,C_INT), INT(n,C_LONG), pin, 2_C_INT, pout, 1_C_INT, par, 0_C_INT, 0_C_INT, C_NULL_PTR, zinfo )
+      IF( istat /= 0 ) CALL stop_with_library_message()
+   END SUBROUTINE ab_fn_arrays
+
+   FUNCTION ab_fn_scalar( fn, x1, x2 )
+      !! the scalar specifics: a one-cell array through the same kernel (the engine has no host arithmetic)
+      INTEGER,  INTENT(in)           :: fn
+      REAL(wp), INTENT(in)           :: x1
+      REAL(wp), INTENT(in), OPTIONAL :: x2
+      REAL(wp) :: ab_fn_scalar
+      REAL(wp), DIMENSION(1) :: a1, a2, o1
+      a1(1) = x1
+      IF( PRESENT(x2) ) THEN
+         a2(1) = x2
+         CALL ab_fn_arrays( fn, 1, a1, o1, a2 )
+      ELSE
+         CALL ab_fn_arrays( fn, 1, a1, o1 )
+      END IF
+      ab_fn_scalar = o1(1)
+   END FUNCTION ab_fn_scalar
 
    SUBROUTINE stop_with_library_message()
       TYPE(C_PTR) :: cp
@@ -135,13 +179,66 @@ CONTAINS
 END MODULE mod_ab_turb
 
 
+MODULE mod_common_coare
+   !! psi_m_coare / psi_h_coare of the reference's src/mod_common_coare.f90:217-392 (PUBLIC there: src/tests/test_psi_stab.f90:26).
+   !! (FIRST_GUESS_COARE, the module's third public name, is the first block of the engine's TURB_COARE* / TURB_ECMWF kernels and has no
+   !! entry of its own.)
+   USE mod_const, ONLY: wp
+   USE mod_ab_turb
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: psi_m_coare, psi_h_coare
+   INTERFACE psi_m_coare
+      MODULE PROCEDURE psi_m_coare_vctr, psi_m_coare_sclr
+   END INTERFACE
+   INTERFACE psi_h_coare
+      MODULE PROCEDURE psi_h_coare_vctr, psi_h_coare_sclr
+   END INTERFACE
+CONTAINS
+   FUNCTION psi_m_coare_vctr( pzeta )                                          !! reference mod_common_coare.f90:217-302
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
+      REAL(wp), DIMENSION(SIZE(pzeta,1),SIZE(pzeta,2)) :: psi_m_coare_vctr
+      CALL ab_fn_arrays( 42, SIZE(pzeta), pzeta, psi_m_coare_vctr )
+   END FUNCTION psi_m_coare_vctr
+   FUNCTION psi_m_coare_sclr( pzeta )
+      REAL(wp), INTENT(in) :: pzeta
+      REAL(wp) :: psi_m_coare_sclr
+      psi_m_coare_sclr = ab_fn_scalar( 42, pzeta )
+   END FUNCTION psi_m_coare_sclr
+   FUNCTION psi_h_coare_vctr( pzeta )                                          !! reference mod_common_coare.f90:305-392
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
+      REAL(wp), DIMENSION(SIZE(pzeta,1),SIZE(pzeta,2)) :: psi_h_coare_vctr
+      CALL ab_fn_arrays( 43, SIZE(pzeta), pzeta, psi_h_coare_vctr )
+   END FUNCTION psi_h_coare_vctr
+   FUNCTION psi_h_coare_sclr( pzeta )
+      REAL(wp), INTENT(in) :: pzeta
+      REAL(wp) :: psi_h_coare_sclr
+      psi_h_coare_sclr = ab_fn_scalar( 43, pzeta )
+   END FUNCTION psi_h_coare_sclr
+END MODULE mod_common_coare
+
+
 MODULE mod_blk_coare3p6
    USE mod_const, ONLY: wp
    USE mod_ab_turb
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: TURB_COARE3P6
+   PUBLIC :: TURB_COARE3P6, charn_coare3p6
+   INTERFACE charn_coare3p6
+      MODULE PROCEDURE charn_coare3p6_vctr, charn_coare3p6_sclr
+   END INTERFACE charn_coare3p6
 CONTAINS
+   FUNCTION charn_coare3p6_vctr( pwnd )                                          !! reference mod_blk_coare3p6.f90:417-445
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pwnd
+      REAL(wp), DIMENSION(SIZE(pwnd,1),SIZE(pwnd,2)) :: charn_coare3p6_vctr
+      CALL ab_fn_arrays( 51, SIZE(pwnd), pwnd, charn_coare3p6_vctr )
+   END FUNCTION charn_coare3p6_vctr
+   FUNCTION charn_coare3p6_sclr( pwnd )
+      REAL(wp), INTENT(in) :: pwnd
+      REAL(wp) :: charn_coare3p6_sclr
+      charn_coare3p6_sclr = ab_fn_scalar( 51, pwnd )
+   END FUNCTION charn_coare3p6_sclr
+
    SUBROUTINE TURB_COARE3P6( kt, zt, zu, T_s, t_zt, q_s, q_zt, U_zu, l_use_cs, l_use_wl, &
       &                      Cd, Ch, Ce, t_zu, q_zu, Ubzu,                               &
       &                      Qsw, rad_lw, slp, pdT_cs,                                   &
@@ -174,8 +271,14 @@ MODULE mod_blk_coare3p0
    USE mod_ab_turb
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: TURB_COARE3P0
+   PUBLIC :: TURB_COARE3P0, charn_coare3p0
 CONTAINS
+   FUNCTION charn_coare3p0( pwnd )                                             !! reference mod_blk_coare3p0.f90:420-447 (a scalar function there too)
+      REAL(wp), INTENT(in) :: pwnd
+      REAL(wp) :: charn_coare3p0
+      charn_coare3p0 = ab_fn_scalar( 50, pwnd )
+   END FUNCTION charn_coare3p0
+
    SUBROUTINE TURB_COARE3P0( kt, zt, zu, pT_s, pt_zt, pq_s, pq_zt, pU_zu, l_use_cs, l_use_wl, &
       &                      pCd, pCh, pCe, pt_zu, pq_zu, pUbzu,                             &
       &                      pQsw, prad_lw, pslp, pdT_cs,                                    &
@@ -209,8 +312,43 @@ MODULE mod_blk_ecmwf
    USE mod_ab_turb
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: TURB_ECMWF
+   PUBLIC :: ECMWF_INIT, TURB_ECMWF, psi_m_ecmwf, psi_h_ecmwf
+   INTERFACE psi_m_ecmwf
+      MODULE PROCEDURE psi_m_ecmwf_scl, psi_m_ecmwf_vct
+   END INTERFACE
+   INTERFACE psi_h_ecmwf
+      MODULE PROCEDURE psi_h_ecmwf_scl, psi_h_ecmwf_vct
+   END INTERFACE
 CONTAINS
+   SUBROUTINE ECMWF_INIT( nx, ny, l_use_wl )                                   !! reference mod_blk_ecmwf.f90:387-411
+      !! The reference allocates the warm layer's module arrays here.  The engine keeps that state in its session, created by the first
+      !! TURB_ECMWF call (kt = 1): nothing to do, the routine exists so that callers of the reference's interface compile and run.
+      INTEGER, INTENT(in) :: nx, ny
+      LOGICAL, INTENT(in) :: l_use_wl
+      IF( nx < 1 .OR. ny < 1 ) STOP 'ECMWF_INIT: bad shape'
+      IF( l_use_wl ) CONTINUE
+   END SUBROUTINE ECMWF_INIT
+   FUNCTION psi_m_ecmwf_vct( pzeta )                                          !! reference mod_blk_ecmwf.f90:441-495
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
+      REAL(wp), DIMENSION(SIZE(pzeta,1),SIZE(pzeta,2)) :: psi_m_ecmwf_vct
+      CALL ab_fn_arrays( 46, SIZE(pzeta), pzeta, psi_m_ecmwf_vct )
+   END FUNCTION psi_m_ecmwf_vct
+   FUNCTION psi_m_ecmwf_scl( pzeta )
+      REAL(wp), INTENT(in) :: pzeta
+      REAL(wp) :: psi_m_ecmwf_scl
+      psi_m_ecmwf_scl = ab_fn_scalar( 46, pzeta )
+   END FUNCTION psi_m_ecmwf_scl
+   FUNCTION psi_h_ecmwf_vct( pzeta )                                          !! reference mod_blk_ecmwf.f90:498-548
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
+      REAL(wp), DIMENSION(SIZE(pzeta,1),SIZE(pzeta,2)) :: psi_h_ecmwf_vct
+      CALL ab_fn_arrays( 47, SIZE(pzeta), pzeta, psi_h_ecmwf_vct )
+   END FUNCTION psi_h_ecmwf_vct
+   FUNCTION psi_h_ecmwf_scl( pzeta )
+      REAL(wp), INTENT(in) :: pzeta
+      REAL(wp) :: psi_h_ecmwf_scl
+      psi_h_ecmwf_scl = ab_fn_scalar( 47, pzeta )
+   END FUNCTION psi_h_ecmwf_scl
+
    SUBROUTINE TURB_ECMWF(    kt, zt, zu, pT_s, pt_zt, pq_s, pq_zt, pU_zu, l_use_cs, l_use_wl, &
       &                      pCd, pCh, pCe, pt_zu, pq_zu, pUbzu,                             &
       &                      pQsw, prad_lw, pslp, pdT_cs,                                    &
@@ -237,8 +375,79 @@ MODULE mod_blk_ncar
    USE mod_ab_turb
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: TURB_NCAR
+   PUBLIC :: TURB_NCAR, cd_n10_ncar, ch_n10_ncar, ce_n10_ncar, psi_m_ncar, psi_h_ncar
+   INTERFACE cd_n10_ncar
+      MODULE PROCEDURE cd_n10_ncar_vctr, cd_n10_ncar_sclr
+   END INTERFACE
+   INTERFACE ch_n10_ncar
+      MODULE PROCEDURE ch_n10_ncar_vctr, ch_n10_ncar_sclr
+   END INTERFACE
+   INTERFACE ce_n10_ncar
+      MODULE PROCEDURE ce_n10_ncar_vctr, ce_n10_ncar_sclr
+   END INTERFACE
+   INTERFACE psi_m_ncar
+      MODULE PROCEDURE psi_m_ncar_vctr, psi_m_ncar_sclr
+   END INTERFACE
+   INTERFACE psi_h_ncar
+      MODULE PROCEDURE psi_h_ncar_vctr, psi_h_ncar_sclr
+   END INTERFACE
 CONTAINS
+   FUNCTION cd_n10_ncar_vctr( pw10 )                                          !! reference mod_blk_ncar.f90:244-284
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pw10
+      REAL(wp), DIMENSION(SIZE(pw10,1),SIZE(pw10,2)) :: cd_n10_ncar_vctr
+      CALL ab_fn_arrays( 52, SIZE(pw10), pw10, cd_n10_ncar_vctr )
+   END FUNCTION cd_n10_ncar_vctr
+   FUNCTION cd_n10_ncar_sclr( pw10 )
+      REAL(wp), INTENT(in) :: pw10
+      REAL(wp) :: cd_n10_ncar_sclr
+      cd_n10_ncar_sclr = ab_fn_scalar( 52, pw10 )
+   END FUNCTION cd_n10_ncar_sclr
+   FUNCTION ch_n10_ncar_vctr( psqrtcdn10 , pstab )                            !! reference mod_blk_ncar.f90:287-310
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: psqrtcdn10, pstab
+      REAL(wp), DIMENSION(SIZE(psqrtcdn10,1),SIZE(psqrtcdn10,2)) :: ch_n10_ncar_vctr
+      CALL ab_fn_arrays( 53, SIZE(psqrtcdn10), psqrtcdn10, ch_n10_ncar_vctr, pstab )
+   END FUNCTION ch_n10_ncar_vctr
+   FUNCTION ch_n10_ncar_sclr( psqrtcdn10 , pstab )
+      REAL(wp), INTENT(in) :: psqrtcdn10, pstab
+      REAL(wp) :: ch_n10_ncar_sclr
+      IF( (pstab < -0.00001).OR.(pstab >  1.00001) ) THEN                      ! (the scalar version's own check, :292-296)
+         PRINT *, 'ERROR: ch_n10_ncar_sclr@mod_blk_ncar.f90: pstab ='
+         PRINT *, pstab
+         STOP
+      END IF
+      ch_n10_ncar_sclr = ab_fn_scalar( 53, psqrtcdn10, pstab )
+   END FUNCTION ch_n10_ncar_sclr
+   FUNCTION ce_n10_ncar_vctr( psqrtcdn10 )                                          !! reference mod_blk_ncar.f90:313-330
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: psqrtcdn10
+      REAL(wp), DIMENSION(SIZE(psqrtcdn10,1),SIZE(psqrtcdn10,2)) :: ce_n10_ncar_vctr
+      CALL ab_fn_arrays( 54, SIZE(psqrtcdn10), psqrtcdn10, ce_n10_ncar_vctr )
+   END FUNCTION ce_n10_ncar_vctr
+   FUNCTION ce_n10_ncar_sclr( psqrtcdn10 )
+      REAL(wp), INTENT(in) :: psqrtcdn10
+      REAL(wp) :: ce_n10_ncar_sclr
+      ce_n10_ncar_sclr = ab_fn_scalar( 54, psqrtcdn10 )
+   END FUNCTION ce_n10_ncar_sclr
+   FUNCTION psi_m_ncar_vctr( pzeta )                                          !! reference mod_blk_ncar.f90:333-376
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
+      REAL(wp), DIMENSION(SIZE(pzeta,1),SIZE(pzeta,2)) :: psi_m_ncar_vctr
+      CALL ab_fn_arrays( 44, SIZE(pzeta), pzeta, psi_m_ncar_vctr )
+   END FUNCTION psi_m_ncar_vctr
+   FUNCTION psi_m_ncar_sclr( pzeta )
+      REAL(wp), INTENT(in) :: pzeta
+      REAL(wp) :: psi_m_ncar_sclr
+      psi_m_ncar_sclr = ab_fn_scalar( 44, pzeta )
+   END FUNCTION psi_m_ncar_sclr
+   FUNCTION psi_h_ncar_vctr( pzeta )                                          !! reference mod_blk_ncar.f90:379-420
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
+      REAL(wp), DIMENSION(SIZE(pzeta,1),SIZE(pzeta,2)) :: psi_h_ncar_vctr
+      CALL ab_fn_arrays( 45, SIZE(pzeta), pzeta, psi_h_ncar_vctr )
+   END FUNCTION psi_h_ncar_vctr
+   FUNCTION psi_h_ncar_sclr( pzeta )
+      REAL(wp), INTENT(in) :: pzeta
+      REAL(wp) :: psi_h_ncar_sclr
+      psi_h_ncar_sclr = ab_fn_scalar( 45, pzeta )
+   END FUNCTION psi_h_ncar_sclr
+
    SUBROUTINE TURB_NCAR( zt, zu, sst, t_zt, ssq, q_zt, U_zu,   &
       &                        Cd, Ch, Ce, t_zu, q_zu, Ubzu,   &
       &                  CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
@@ -261,8 +470,32 @@ MODULE mod_blk_andreas
    USE mod_ab_turb
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: TURB_ANDREAS
+   PUBLIC :: TURB_ANDREAS, u_star_andreas, psi_m_andreas, psi_h_andreas
+   INTERFACE u_star_andreas
+      MODULE PROCEDURE u_star_andreas_vctr, u_star_andreas_sclr
+   END INTERFACE
 CONTAINS
+   FUNCTION u_star_andreas_vctr( pun10 )                                          !! reference mod_blk_andreas.f90:275-305
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pun10
+      REAL(wp), DIMENSION(SIZE(pun10,1),SIZE(pun10,2)) :: u_star_andreas_vctr
+      CALL ab_fn_arrays( 55, SIZE(pun10), pun10, u_star_andreas_vctr )
+   END FUNCTION u_star_andreas_vctr
+   FUNCTION u_star_andreas_sclr( pun10 )
+      REAL(wp), INTENT(in) :: pun10
+      REAL(wp) :: u_star_andreas_sclr
+      u_star_andreas_sclr = ab_fn_scalar( 55, pun10 )
+   END FUNCTION u_star_andreas_sclr
+   FUNCTION psi_m_andreas( pzeta )                                             !! reference mod_blk_andreas.f90:307-360 (array functions there too)
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
+      REAL(wp), DIMENSION(SIZE(pzeta,1),SIZE(pzeta,2)) :: psi_m_andreas
+      CALL ab_fn_arrays( 48, SIZE(pzeta), pzeta, psi_m_andreas )
+   END FUNCTION psi_m_andreas
+   FUNCTION psi_h_andreas( pzeta )                                             !! :363-410
+      REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
+      REAL(wp), DIMENSION(SIZE(pzeta,1),SIZE(pzeta,2)) :: psi_h_andreas
+      CALL ab_fn_arrays( 49, SIZE(pzeta), pzeta, psi_h_andreas )
+   END FUNCTION psi_h_andreas
+
    SUBROUTINE TURB_ANDREAS( zt, zu, psst, pt_zt, pssq, pq_zt, pU_zu, &
       &                     pCd, pCh, pCe, pt_zu, pq_zu, pUbzu,       &
       &                    pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10 )

@@ -6,17 +6,24 @@
 ! tests/test_phymbl.py (tools/gen_phymbl_golden.py).
 !
 !   phymbl_driver.x <in.bin> <out.bin>
-!   in : int32 n ; 30 columns of n doubles (order below)
+!   in : int32 n ; 33 columns of n doubles (order below)
 !   out: records { character(24) name ; int32 m ; m doubles }.  `_s` records: the scalar specific on the first min(n,8) cells.
 PROGRAM phymbl_driver
 
    USE mod_const
    USE mod_phymbl
    USE mod_blk_ice_an05, ONLY: rough_leng_m, rough_leng_tq     ! the two PUBLIC helper functions of the sea-ice module (ice/test_ice.f90 calls them)
+   !! the PUBLIC functions of the algorithm modules (src/tests/test_psi_stab.f90:25-28 imports the psi's)
+   USE mod_common_coare,  ONLY: psi_m_coare,   psi_h_coare
+   USE mod_blk_ncar,      ONLY: psi_m_ncar,    psi_h_ncar, cd_n10_ncar, ch_n10_ncar, ce_n10_ncar
+   USE mod_blk_ecmwf,     ONLY: psi_m_ecmwf,   psi_h_ecmwf
+   USE mod_blk_andreas,   ONLY: psi_m_andreas, psi_h_andreas, u_star_andreas
+   USE mod_blk_coare3p0,  ONLY: charn_coare3p0
+   USE mod_blk_coare3p6,  ONLY: charn_coare3p6
 
    IMPLICIT NONE
 
-   INTEGER, PARAMETER :: ncol = 30, ns_max = 8
+   INTEGER, PARAMETER :: ncol = 33, ns_max = 8
    REAL(wp), PARAMETER :: pz = 2._wp, pzu = 10._wp
    INTEGER(4) :: n4
    INTEGER :: n, ns, k
@@ -27,7 +34,7 @@ PROGRAM phymbl_driver
    !! columns
    INTEGER, PARAMETER :: iTa=1, iTs=2, iP=3, iqa=4, iqs=5, iTh=6, iPz=7, ius=8, itst=9, iqst=10, iW=11, iUb=12, iCd=13, iCh=14, &
       &                  iCe=15, ipsi=16, iz0=17, iRib=18, irlw=19, irh=20, idp=21, irho=22, iRer=23, ialp=24, iQd=25, iQlt=26,   &
-      &                  iTly=27, iqly=28, iTi=29, inua=30
+      &                  iTly=27, iqly=28, iTi=29, inua=30, izeta=31, istab=32, isqcd=33
 
    CALL GET_COMMAND_ARGUMENT(1, cfin)
    CALL GET_COMMAND_ARGUMENT(2, cfout)
@@ -190,6 +197,31 @@ PROGRAM phymbl_driver
       r3 = ztq(:,:,1)                                              ; CALL put('rough_leng_t', r3)
       r3 = ztq(:,:,2)                                              ; CALL put('rough_leng_q', r3)
    END BLOCK
+
+   !! ---- stability functions of zeta = z/L, Charnock parameters, NCAR's neutral coefficients, ANDREAS' u*
+   r1 = psi_m_coare( c(:,:,izeta) )                                ; CALL put('psi_m_coare', r1)
+   r1 = psi_h_coare( c(:,:,izeta) )                                ; CALL put('psi_h_coare', r1)
+   r1 = psi_m_ncar( c(:,:,izeta) )                                 ; CALL put('psi_m_ncar', r1)
+   r1 = psi_h_ncar( c(:,:,izeta) )                                 ; CALL put('psi_h_ncar', r1)
+   r1 = psi_m_ecmwf( c(:,:,izeta) )                                ; CALL put('psi_m_ecmwf', r1)
+   r1 = psi_h_ecmwf( c(:,:,izeta) )                                ; CALL put('psi_h_ecmwf', r1)
+   r1 = psi_m_andreas( c(:,:,izeta) )                              ; CALL put('psi_m_andreas', r1)
+   r1 = psi_h_andreas( c(:,:,izeta) )                              ; CALL put('psi_h_andreas', r1)
+   r1 = charn_coare3p6( c(:,:,iW) )                                ; CALL put('charn_coare3p6', r1)
+   r1 = cd_n10_ncar( c(:,:,iW) )                                   ; CALL put('cd_n10_ncar', r1)
+   r3 = ch_n10_ncar( c(:,:,isqcd), c(:,:,istab) )                  ; CALL put('ch_n10_ncar', r3)
+   r3 = ce_n10_ncar( c(:,:,isqcd) )                                ; CALL put('ce_n10_ncar', r3)
+   r1 = u_star_andreas( c(:,:,iW) )                                ; CALL put('u_star_andreas', r1)
+   DO k = 1, n
+      r1(k,1) = charn_coare3p0( c(k,1,iW) )                        ! a scalar function in the reference
+   END DO
+   CALL put('charn_coare3p0', r1)
+   DO k = 1, ns
+      s1(k) = psi_m_coare( c(k,1,izeta) ) ; s2(k) = psi_h_ecmwf( c(k,1,izeta) ) ; s3(k) = psi_m_ncar( c(k,1,izeta) )
+      s4(k) = u_star_andreas( c(k,1,iW) ) ; s5(k) = charn_coare3p6( c(k,1,iW) )
+   END DO
+   CALL puts('psi_m_coare_s', s1) ; CALL puts('psi_h_ecmwf_s', s2) ; CALL puts('psi_m_ncar_s', s3) ; CALL puts('u_star_andreas_s', s4)
+   CALL puts('charn_coare3p6_s', s5)
 
    !! ---- host-side statistics
    s1(1) = VARIANCE( c(:,1,iTa) ) ; s1(2) = VMEAN( c(:,1,iTa) )

@@ -337,7 +337,23 @@ enum ab_phymbl_fn {
     AB_PH_DELTA_SKIN_LAYER = 39,    /* palpha, pQd, pustar_a, [Qlat] ; - ; delta             :2010-2046 */
     /* the two PUBLIC helpers of src/ice/mod_blk_ice_an05.f90 (Andreas et al. 2005), used by src/ice/test_ice.f90:49,55 */
     AB_PH_ROUGH_LENG_M = 40,        /* pus, pnua ; - ; z0 over sea ice                       mod_blk_ice_an05.f90:232-255 */
-    AB_PH_ROUGH_LENG_TQ = 41        /* pz0, pus, pnua ; - ; z0t, z0q                         mod_blk_ice_an05.f90:257-312 */
+    AB_PH_ROUGH_LENG_TQ = 41,       /* pz0, pus, pnua ; - ; z0t, z0q                         mod_blk_ice_an05.f90:257-312 */
+    /* the PUBLIC functions of the algorithm modules: stability functions of zeta = z/L, Charnock parameters, NCAR's neutral
+     * coefficients, ANDREAS' friction velocity (the device functions the flux kernels iterate with) */
+    AB_PH_PSI_M_COARE = 42,         /* pzeta ; - ; psi_m                                     mod_common_coare.f90:217-302 */
+    AB_PH_PSI_H_COARE = 43,         /* pzeta ; - ; psi_h                                     mod_common_coare.f90:305-392 */
+    AB_PH_PSI_M_NCAR = 44,          /* pzeta ; - ; psi_m                                     mod_blk_ncar.f90:333-376 */
+    AB_PH_PSI_H_NCAR = 45,          /* pzeta ; - ; psi_h                                     mod_blk_ncar.f90:379-420 */
+    AB_PH_PSI_M_ECMWF = 46,         /* pzeta ; - ; psi_m                                     mod_blk_ecmwf.f90:441-495 */
+    AB_PH_PSI_H_ECMWF = 47,         /* pzeta ; - ; psi_h                                     mod_blk_ecmwf.f90:498-548 */
+    AB_PH_PSI_M_ANDREAS = 48,       /* pzeta ; - ; psi_m                                     mod_blk_andreas.f90:307-360 */
+    AB_PH_PSI_H_ANDREAS = 49,       /* pzeta ; - ; psi_h                                     mod_blk_andreas.f90:363-410 */
+    AB_PH_CHARN_COARE3P0 = 50,      /* pwnd ; - ; Charnock parameter                         mod_blk_coare3p0.f90:420-447 */
+    AB_PH_CHARN_COARE3P6 = 51,      /* pwnd ; - ; Charnock parameter                         mod_blk_coare3p6.f90:417-445 */
+    AB_PH_CD_N10_NCAR = 52,         /* pw10 ; - ; CdN10                                      mod_blk_ncar.f90:244-284 */
+    AB_PH_CH_N10_NCAR = 53,         /* psqrtcdn10, pstab ; - ; ChN10                         mod_blk_ncar.f90:287-310 */
+    AB_PH_CE_N10_NCAR = 54,         /* psqrtcdn10 ; - ; CeN10                                mod_blk_ncar.f90:313-330 */
+    AB_PH_U_STAR_ANDREAS = 55       /* pun10 ; - ; u*                                        mod_blk_andreas.f90:275-305 */
 };
 int ab_phymbl(int fn, long n, const double *const *in, int n_in, double *const *out, int n_out, const double *par, int flag,
               int mem, void *stream, double *info);

@@ -1,12 +1,12 @@
 """Inputs and call table of the mod_phymbl helper tests (tests/test_phymbl.py, tools/gen_phymbl_golden.py).
 
-COLUMNS: the 30 columns aerobulk_amd/fortran/phymbl_driver.f90 reads, in its order.  CALLS: for every array record that driver
+COLUMNS: the 33 columns aerobulk_amd/fortran/phymbl_driver.f90 reads, in its order.  CALLS: for every array record that driver
 writes, the `ab_phymbl` call (include/aerobulk_amd.h) that must reproduce it: (fn, par0, flag, input columns | None, index of the
 output).  The same table drives the C ABI on the GPU and the host instantiation of the product header (tests/phymbl_host.cpp)."""
 import numpy as np
 
 COLUMNS = ["Ta", "Ts", "P", "qa", "qs", "Th", "Pz", "us", "tst", "qst", "W", "Ub", "Cd", "Ch", "Ce", "psi", "z0", "Rib", "rlw", "rh",
-           "dp", "rho", "Rer", "alp", "Qd", "Qlt", "Tly", "qly", "Ti", "nua"]
+           "dp", "rho", "Rer", "alp", "Qd", "Qlt", "Tly", "qly", "Ti", "nua", "zeta", "stab", "sqcd"]
 Z_T, Z_U = 2.0, 10.0       # the driver's pz and pzu
 PATM = 101000.0
 
@@ -51,6 +51,12 @@ def make_columns(n=512, seed=20251003):
     c["qly"] = c["qa"] * u(0.9, 1.1)
     c["Ti"] = u(230., 272.)
     c["nua"] = u(1.15e-5, 1.55e-5)        # kinematic viscosity of air (appended last: the draws of the columns before it are unchanged)
+    z = u(-15., 15.)                      # z/L: the range of src/tests/test_psi_stab.f90:36, + what lies beyond the engine's tables and caps
+    z[:8] = [0., 1e-9, -1e-9, -49.9, -50.1, -75., -400., 60.]
+    z[8:40] = u(-1e-3, 1e-3)[:32]
+    c["zeta"] = z
+    c["stab"] = np.where(u(0., 1.) < 0.5, 0., 1.) * u(0.9999, 1.)       # NCAR's stable / unstable switch (a real number in [0, 1])
+    c["sqcd"] = np.sqrt(u(0.3e-3, 3e-3))                                 # SQRT(CdN10); the low end reaches the floor Cx_min of the products
     return np.stack([c[k] for k in COLUMNS], axis=0)     # (29, n)
 
 
@@ -58,7 +64,8 @@ def make_columns(n=512, seed=20251003):
 (POT_TEMP, ABS_TEMP, VIRT_TEMP, PZ, THETA, TABS, RHO_AIR, VISC_AIR, L_VAP, CP_AIR, GAMMA_MOIST, ONE_ON_L, RI_BULK, E_SAT, E_SAT_ICE,
  DE_SAT_DT_ICE, Q_SAT, DQ_SAT_DT_ICE, Q_AIR_RH, Q_AIR_DP, RHO_AIR_ADV, Q_SAT_CRUDE, DRY_STATIC_ENERGY, UPDATE_QNSOL_TAU, BULK_FORMULA,
  ALPHA_SW, QLW_NET, Z0_FROM_CD, Z0_FROM_USTAR, CD_FROM_Z0, F_M_LOUIS, F_H_LOUIS, UN10_FROM_USTAR, UN10_FROM_CDN, UN10_FROM_CD, Z0TQ_LKB,
- E_AIR, RH_AIR, DELTA_SKIN, ROUGH_LENG_M, ROUGH_LENG_TQ) = range(1, 42)
+ E_AIR, RH_AIR, DELTA_SKIN, ROUGH_LENG_M, ROUGH_LENG_TQ, PSI_M_COARE, PSI_H_COARE, PSI_M_NCAR, PSI_H_NCAR, PSI_M_ECMWF, PSI_H_ECMWF, PSI_M_ANDREAS,
+ PSI_H_ANDREAS, CHARN_COARE3P0, CHARN_COARE3P6, CD_N10_NCAR, CH_N10_NCAR, CE_N10_NCAR, U_STAR_ANDREAS) = range(1, 56)
 
 _UQT = ["Ts", "qs", "Th", "qa", "us", "tst", "qst", "W", "Ub", "P", "rlw"]
 _BF = ["Ts", "qs", "Th", "qa", "Cd", "Ch", "Ce", "W", "Ub", "P"]
@@ -127,6 +134,14 @@ CALLS = {
     "rough_leng_m": (ROUGH_LENG_M, 0., 0, ["us", "nua"], 0),
     "rough_leng_t": (ROUGH_LENG_TQ, 0., 0, ["z0", "us", "nua"], 0),
     "rough_leng_q": (ROUGH_LENG_TQ, 0., 0, ["z0", "us", "nua"], 1),
+    # the PUBLIC functions of the algorithm modules
+    "psi_m_coare": (PSI_M_COARE, 0., 0, ["zeta"], 0), "psi_h_coare": (PSI_H_COARE, 0., 0, ["zeta"], 0),
+    "psi_m_ncar": (PSI_M_NCAR, 0., 0, ["zeta"], 0), "psi_h_ncar": (PSI_H_NCAR, 0., 0, ["zeta"], 0),
+    "psi_m_ecmwf": (PSI_M_ECMWF, 0., 0, ["zeta"], 0), "psi_h_ecmwf": (PSI_H_ECMWF, 0., 0, ["zeta"], 0),
+    "psi_m_andreas": (PSI_M_ANDREAS, 0., 0, ["zeta"], 0), "psi_h_andreas": (PSI_H_ANDREAS, 0., 0, ["zeta"], 0),
+    "charn_coare3p0": (CHARN_COARE3P0, 0., 0, ["W"], 0), "charn_coare3p6": (CHARN_COARE3P6, 0., 0, ["W"], 0),
+    "cd_n10_ncar": (CD_N10_NCAR, 0., 0, ["W"], 0), "u_star_andreas": (U_STAR_ANDREAS, 0., 0, ["W"], 0),
+    "ch_n10_ncar": (CH_N10_NCAR, 0., 0, ["sqcd", "stab"], 0), "ce_n10_ncar": (CE_N10_NCAR, 0., 0, ["sqcd"], 0),
     # scalar-only in the reference: checked on the first cells
     "delta_skin_s": (DELTA_SKIN, 0., 0, ["alp", "Qd", "us"], 0),
     "delta_skin_qlat_s": (DELTA_SKIN, 0., 0, ["alp", "Qd", "us", "Qlt"], 0),

@@ -87,7 +87,7 @@ def test_helper_entry_argument_errors_need_no_gpu(lib):
     f = lib.ab_phymbl
     ARG = 10
     assert f(0, 8, pin, 2, pout, 1, par, 0, 0, None, None) == ARG and b"unknown function" in lib.ab_last_error()
-    assert f(42, 8, pin, 2, pout, 1, par, 0, 0, None, None) == ARG
+    assert f(99, 8, pin, 2, pout, 1, par, 0, 0, None, None) == ARG
     assert f(3, 0, pin, 2, pout, 1, par, 0, 0, None, None) == ARG                      # virt_temp on no cells
     assert f(3, 8, None, 2, pout, 1, par, 0, 0, None, None) == ARG
     assert f(3, 8, pin, 1, pout, 1, par, 0, 0, None, None) == ARG                      # virt_temp needs two arrays

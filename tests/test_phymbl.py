@@ -37,6 +37,8 @@ def close(got, ref, label, tol=TOL):
     assert got.shape == ref.shape, label
     assert np.all(np.isfinite(got)), label
     scale = np.maximum(np.abs(ref), tol * max(float(np.max(np.abs(ref))), 1e-300))
+    if "psi_" in label:      # the stability functions vanish at zeta = 0 as differences of O(10) terms (in the reference's closed forms too: their
+        scale = np.maximum(scale, 1e-2)      # own rounding is 2e-15 there) and only ever enter sums with LOG(z/z0) = O(10): 1e-14 absolutely
     err = np.abs(got - ref) / scale
     assert float(err.max()) <= tol, (label, float(err.max()), int(np.argmax(err)), got[np.argmax(err)], ref[np.argmax(err)])
     return float(err.max())
@@ -46,7 +48,7 @@ def test_golden_covers_every_function(gold):
     cols, rec = gold
     assert cols.shape == (len(pc.COLUMNS), 512)
     fns = {c[0] for c in pc.CALLS.values()}
-    assert fns == set(range(1, 42)), sorted(set(range(1, 42)) - fns)       # all 41 ids of enum ab_phymbl_fn
+    assert fns == set(range(1, 56)), sorted(set(range(1, 56)) - fns)       # all 55 ids of enum ab_phymbl_fn
     for name in list(pc.CALLS) + pc.EXTRA:
         assert name in rec, name
     # every `_s` record of the driver (the scalar specifics) equals the array record on the first cells IN THE REFERENCE ITSELF to
