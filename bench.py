@@ -58,16 +58,27 @@ def algorithmic_bytes_per_cell(skin, esz):
 
 
 def kernel_source_hash():
-    """Identity of the device code the committed PMC profile was taken with: the kernel sources and the compile flags
-    (aerobulk_amd/build.py rebuilds libaerobulk_amd.so whenever one of them changes)."""
+    """Identity of the device code the committed PMC profile was taken with: the flux kernels' translation unit (ab_kernels.hip), every
+    header of this repository it includes (the closure of its `#include "..."` lines, so that a change to a header of ANOTHER translation
+    unit — the helper kernels of ab_phymbl.hip — does not disown the profile) and the compile flags."""
+    import re
     from aerobulk_amd import build as b
-    h = hashlib.sha256()
     csrc = os.path.join(ROOT, "aerobulk_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name == "ab_kernels.hip" or name.endswith(".hpp"):      # the flux kernels' translation unit and every header it may include
-            h.update(name.encode())
-            with open(os.path.join(csrc, name), "rb") as fh:
-                h.update(fh.read())
+    seen, todo = [], ["ab_kernels.hip"]
+    while todo:
+        name = todo.pop()
+        path = os.path.normpath(os.path.join(csrc, name))
+        if path in seen or not os.path.exists(path):
+            continue
+        seen.append(path)
+        with open(path, "r", errors="replace") as fh:
+            for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), flags=re.M):
+                todo.append(os.path.join(os.path.dirname(os.path.relpath(path, csrc)), inc))
+    h = hashlib.sha256()
+    for path in sorted(seen):
+        h.update(os.path.relpath(path, ROOT).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
     h.update(" ".join(b.HIPFLAGS).encode())
     return h.hexdigest()[:16]
 
