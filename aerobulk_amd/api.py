@@ -498,12 +498,12 @@ def turb_neutral_10m(calgo, U_N10, nb_iter=5, precision="f64"):
     return out
 
 
-def phymbl(fn, inputs, par0=0.0, flag=0, n_out=1, want=None):
+def phymbl(fn, inputs, par0=0.0, flag=0, n_out=1, want=None, par1=0.0):
     """One public function of the reference's mod_phymbl (mod_phymbl.f90:33-139) on arrays: `ab_phymbl` of the C ABI.
 
     fn: enum ab_phymbl_fn (include/aerobulk_amd.h); inputs: the function's array arguments in the reference's order, None for an
     OPTIONAL one that is not passed (numpy: host arrays, staged; torch CUDA tensors: used in place); par0 / flag: its scalar REAL /
-    LOGICAL-or-INTEGER argument.  Returns (list of n_out arrays — None where `want` says not wanted —, info) with info =
+    LOGICAL-or-INTEGER argument (par1: zu of FIRST_GUESS_COARE, whose par0 is zt).  Returns (list of n_out arrays — None where `want` says not wanted —, info) with info =
     (first cell beyond 10 N/m^2 or -1, its stress) for BULK_FORMULA.  Raises AerobulkError except for AB_ERR_TAU, which is reported
     through info like BULK_FORMULA_VCTR's STOP message."""
     lib = _lib.load()
@@ -525,7 +525,7 @@ def phymbl(fn, inputs, par0=0.0, flag=0, n_out=1, want=None):
         outs = [np.empty(n, dtype=np.float64) if w else None for w in want]
         stream = 0
     pout = (C.c_void_p * n_out)(*[_ptr(o, np.float64, n)[0] for o in outs])
-    par = (C.c_double * 2)(float(par0), 0.0)
+    par = (C.c_double * 2)(float(par0), float(par1))
     info = (C.c_double * 2)(-1.0, 0.0)
     rc = lib.ab_phymbl(int(fn), n, pin, len(inputs), pout, n_out, par, int(flag), AB_MEM_DEVICE if dev else AB_MEM_HOST,
                        C.c_void_p(stream or 0), info)

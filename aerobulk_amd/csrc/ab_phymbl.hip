@@ -14,7 +14,7 @@
 namespace ab {
 void set_last_error(const std::string &msg);
 
-constexpr int kPhMaxIn = 11, kPhMaxOut = 5, kPhBlock = 256;
+constexpr int kPhMaxIn = 11, kPhMaxOut = 7, kPhBlock = 256;
 
 struct PhArgs {
     const double *in[kPhMaxIn + 1];   // (+1: the e_air iterate the two-pass functions add)

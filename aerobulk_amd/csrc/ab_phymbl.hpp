@@ -27,9 +27,9 @@ enum {
     kPhRhAir, kPhDeltaSkinLayer, kPhRoughLengM, kPhRoughLengTq,
     // the PUBLIC functions of the algorithm modules (mod_common_coare, mod_blk_coare3p0 / coare3p6 / ncar / ecmwf / andreas)
     kPhPsiMCoare, kPhPsiHCoare, kPhPsiMNcar, kPhPsiHNcar, kPhPsiMEcmwf, kPhPsiHEcmwf, kPhPsiMAndreas, kPhPsiHAndreas,
-    kPhCharnCoare3p0, kPhCharnCoare3p6, kPhCdN10Ncar, kPhChN10Ncar, kPhCeN10Ncar, kPhUStarAndreas, kPhCount
+    kPhCharnCoare3p0, kPhCharnCoare3p6, kPhCdN10Ncar, kPhChN10Ncar, kPhCeN10Ncar, kPhUStarAndreas, kPhFirstGuessCoare, kPhCount
 };
-static_assert(kPhPsiMCoare == 42 && kPhUStarAndreas == 55, "enum ab_phymbl_fn of include/aerobulk_amd.h");
+static_assert(kPhPsiMCoare == 42 && kPhUStarAndreas == 55 && kPhFirstGuessCoare == 56, "enum ab_phymbl_fn of include/aerobulk_amd.h");
 
 template <class R> struct KPh {   // the constants of mod_const.f90 / mod_phymbl.f90 that the flux kernels do not need
     static constexpr R rtt0 = R(273.16);                    // mod_const.f90:61
@@ -278,6 +278,18 @@ template <int FN, class R> __device__ __forceinline__ void ph_cell(const R *x, u
     } else if constexpr (FN == kPhUStarAndreas) {    // u_star_andreas, mod_blk_andreas.f90:275-305  ( pun10 )
         const R za = x[0] - R(8.271);
         y[0] = R(0.239) + R(0.0433) * (za + M::sqrt(R(0.12) * za * za + R(0.181)));
+    } else if constexpr (FN == kPhFirstGuessCoare) {   // FIRST_GUESS_COARE, mod_common_coare.f90:33-179  ( zt, zu ; psst, t_zt, pssq, q_zt, U_zu, pcharn )
+        // -> pus, pts, pqs, t_zu, q_zu, Ubzu, pz0: the first block of the engine's TURB_COARE* / TURB_ECMWF kernels, with the heights' logarithms
+        // formed here (the flux kernels get them from the host once per launch: ab_launch.hpp make_heights)
+        Heights<R> h;
+        h.zt = par[0]; h.zu = par[1];
+        h.log_zt = ph_log(par[0]); h.log_zu = ph_log(par[1]); h.log_10 = ph_log(R(10.));
+        h.log_ztu = ph_log(M::div(par[0], par[1])); h.log_zu10 = ph_log(par[1] * R(0.1));
+        h.fg_ca = M::div(R(0.035) * ph_log(R(10. / 0.0001)), ph_log(par[1] * R(1. / 0.0001)));
+        h.inv_zu = M::rcp(par[1]); h.zt_o_zu = M::div(par[0], par[1]);
+        h.fg_cb = -R(0.004 * 600. * 1.2 * 1.2 * 1.2) * h.inv_zu;
+        h.zt_eq_zu = M::abs(par[1] - par[0]) < R(0.01) ? 1 : 0;
+        first_guess_coare<R, R>(h, x[0], x[1], x[2], x[3], x[4], x[5], y[0], y[1], y[2], y[3], y[4], y[5], y[6]);
     }
 }
 
@@ -319,6 +331,7 @@ constexpr PhShape ph_shape(int fn)
     case kPhPsiMAndreas: case kPhPsiHAndreas: case kPhCharnCoare3p0: case kPhCharnCoare3p6: case kPhCdN10Ncar: case kPhCeN10Ncar:
     case kPhUStarAndreas: return {1, 1, 1};
     case kPhChN10Ncar: return {2, 2, 1};
+    case kPhFirstGuessCoare: return {6, 6, 7};
     default: return {0, 0, 0};
     }
 }

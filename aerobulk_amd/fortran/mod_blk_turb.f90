@@ -18,7 +18,7 @@ MODULE mod_ab_turb
    USE mod_const, ONLY: wp, nb_iter
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: ab_turb_generic, ab_fn_arrays, ab_fn_scalar
+   PUBLIC :: ab_turb_generic, ab_fn_arrays, ab_fn_scalar, ab_fn_pointers
 
    !! mirror of `ab_diag` (include/aerobulk_amd.h)
    TYPE, BIND(C) :: ab_diag
@@ -75,6 +75,19 @@ CONTAINS
       istat = ab_phymbl( INT(fn,C_INT), INT(n,C_LONG), pin, 2_C_INT, pout, 1_C_INT, par, 0_C_INT, 0_C_INT, C_NULL_PTR, zinfo )
       IF( istat /= 0 ) CALL stop_with_library_message()
    END SUBROUTINE ab_fn_arrays
+
+   SUBROUTINE ab_fn_pointers( fn, n, pin, pout, par1, par2 )
+      !! any helper function on arrays handed over as C pointers (FIRST_GUESS_COARE: six in, seven out)
+      INTEGER, INTENT(in) :: fn, n
+      TYPE(C_PTR), DIMENSION(:), INTENT(in) :: pin, pout
+      REAL(wp), INTENT(in) :: par1, par2
+      REAL(C_DOUBLE), DIMENSION(2) :: par, zinfo
+      INTEGER(C_INT) :: istat
+      par = (/ REAL(par1,C_DOUBLE), REAL(par2,C_DOUBLE) /)
+      istat = ab_phymbl( INT(fn,C_INT), INT(n,C_LONG), pin, INT(SIZE(pin),C_INT), pout, INT(SIZE(pout),C_INT), par, 0_C_INT, 0_C_INT, &
+         &               C_NULL_PTR, zinfo )
+      IF( istat /= 0 ) CALL stop_with_library_message()
+   END SUBROUTINE ab_fn_pointers
 
    FUNCTION ab_fn_scalar( fn, x1, x2 )
       !! the scalar specifics: a one-cell array through the same kernel (the engine has no host arithmetic)
@@ -180,14 +193,17 @@ END MODULE mod_ab_turb
 
 
 MODULE mod_common_coare
-   !! psi_m_coare / psi_h_coare of the reference's src/mod_common_coare.f90:217-392 (PUBLIC there: src/tests/test_psi_stab.f90:26).
-   !! (FIRST_GUESS_COARE, the module's third public name, is the first block of the engine's TURB_COARE* / TURB_ECMWF kernels and has no
-   !! entry of its own.)
+   !! the three public names of the reference's src/mod_common_coare.f90: FIRST_GUESS_COARE :33-214 (the first block of the engine's TURB_COARE* /
+   !! TURB_ECMWF kernels, here as helper function 56 of `ab_phymbl`), psi_m_coare / psi_h_coare :217-392 (src/tests/test_psi_stab.f90:26)
+   USE, INTRINSIC :: ISO_C_BINDING
    USE mod_const, ONLY: wp
    USE mod_ab_turb
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: psi_m_coare, psi_h_coare
+   PUBLIC :: first_guess_coare, psi_m_coare, psi_h_coare
+   INTERFACE first_guess_coare
+      MODULE PROCEDURE first_guess_coare_vctr, first_guess_coare_sclr
+   END INTERFACE
    INTERFACE psi_m_coare
       MODULE PROCEDURE psi_m_coare_vctr, psi_m_coare_sclr
    END INTERFACE
@@ -215,6 +231,44 @@ CONTAINS
       REAL(wp) :: psi_h_coare_sclr
       psi_h_coare_sclr = ab_fn_scalar( 43, pzeta )
    END FUNCTION psi_h_coare_sclr
+   SUBROUTINE FIRST_GUESS_COARE_VCTR( zt, zu, psst, t_zt, pssq, q_zt, U_zu, pcharn, &
+      &                               pus, pts, pqs, t_zu, q_zu, Ubzu,  qz0 )
+      REAL(wp), INTENT(in)                  ::   zt, zu
+      REAL(wp), INTENT(in),  DIMENSION(:,:) ::   psst, t_zt, pssq, q_zt, U_zu, pcharn
+      REAL(wp), INTENT(out), DIMENSION(:,:) ::   pus, pts, pqs, t_zu, q_zu, Ubzu
+      REAL(wp), INTENT(out), DIMENSION(:,:), OPTIONAL :: qz0    ! roughness length [m]
+      REAL(wp), DIMENSION(:,:), ALLOCATABLE, TARGET :: zi, zo   ! contiguous copies: (n,6) in, (n,7) out
+      INTEGER :: n, k
+      TYPE(C_PTR), DIMENSION(6) :: pin
+      TYPE(C_PTR), DIMENSION(7) :: pout
+      n = SIZE(psst)
+      ALLOCATE( zi(n,6), zo(n,7) )
+      zi(:,1) = RESHAPE(psst, (/n/)) ; zi(:,2) = RESHAPE(t_zt, (/n/)) ; zi(:,3) = RESHAPE(pssq, (/n/))
+      zi(:,4) = RESHAPE(q_zt, (/n/)) ; zi(:,5) = RESHAPE(U_zu, (/n/)) ; zi(:,6) = RESHAPE(pcharn, (/n/))
+      DO k = 1, 6
+         pin(k) = C_LOC(zi(1,k))
+      END DO
+      DO k = 1, 7
+         pout(k) = C_LOC(zo(1,k))
+      END DO
+      CALL ab_fn_pointers( 56, n, pin, pout, zt, zu )
+      pus  = RESHAPE(zo(:,1), SHAPE(pus))  ; pts  = RESHAPE(zo(:,2), SHAPE(pts))  ; pqs  = RESHAPE(zo(:,3), SHAPE(pqs))
+      t_zu = RESHAPE(zo(:,4), SHAPE(t_zu)) ; q_zu = RESHAPE(zo(:,5), SHAPE(q_zu)) ; Ubzu = RESHAPE(zo(:,6), SHAPE(Ubzu))
+      IF( PRESENT(qz0) ) qz0 = RESHAPE(zo(:,7), SHAPE(qz0))
+      DEALLOCATE( zi, zo )
+   END SUBROUTINE FIRST_GUESS_COARE_VCTR
+
+   SUBROUTINE FIRST_GUESS_COARE_SCLR( zt, zu, psst, t_zt, pssq, q_zt, U_zu, pcharn, &
+      &                               pus, pts, pqs, t_zu, q_zu, Ubzu,  pz0 )
+      REAL(wp), INTENT(in)  ::   zt, zu, psst, t_zt, pssq, q_zt, U_zu, pcharn
+      REAL(wp), INTENT(out) ::   pus, pts, pqs, t_zu, q_zu, Ubzu
+      REAL(wp), INTENT(out), OPTIONAL :: pz0
+      REAL(wp), DIMENSION(1,1) :: a1, a2, a3, a4, a5, a6, o1, o2, o3, o4, o5, o6, o7
+      a1 = psst ; a2 = t_zt ; a3 = pssq ; a4 = q_zt ; a5 = U_zu ; a6 = pcharn
+      CALL FIRST_GUESS_COARE_VCTR( zt, zu, a1, a2, a3, a4, a5, a6, o1, o2, o3, o4, o5, o6, qz0=o7 )
+      pus = o1(1,1) ; pts = o2(1,1) ; pqs = o3(1,1) ; t_zu = o4(1,1) ; q_zu = o5(1,1) ; Ubzu = o6(1,1)
+      IF( PRESENT(pz0) ) pz0 = o7(1,1)
+   END SUBROUTINE FIRST_GUESS_COARE_SCLR
 END MODULE mod_common_coare
 
 

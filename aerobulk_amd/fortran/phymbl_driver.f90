@@ -6,7 +6,7 @@
 ! tests/test_phymbl.py (tools/gen_phymbl_golden.py).
 !
 !   phymbl_driver.x <in.bin> <out.bin>
-!   in : int32 n ; 33 columns of n doubles (order below)
+!   in : int32 n ; 34 columns of n doubles (order below)
 !   out: records { character(24) name ; int32 m ; m doubles }.  `_s` records: the scalar specific on the first min(n,8) cells.
 PROGRAM phymbl_driver
 
@@ -14,7 +14,7 @@ PROGRAM phymbl_driver
    USE mod_phymbl
    USE mod_blk_ice_an05, ONLY: rough_leng_m, rough_leng_tq     ! the two PUBLIC helper functions of the sea-ice module (ice/test_ice.f90 calls them)
    !! the PUBLIC functions of the algorithm modules (src/tests/test_psi_stab.f90:25-28 imports the psi's)
-   USE mod_common_coare,  ONLY: psi_m_coare,   psi_h_coare
+   USE mod_common_coare,  ONLY: psi_m_coare,   psi_h_coare, first_guess_coare
    USE mod_blk_ncar,      ONLY: psi_m_ncar,    psi_h_ncar, cd_n10_ncar, ch_n10_ncar, ce_n10_ncar
    USE mod_blk_ecmwf,     ONLY: psi_m_ecmwf,   psi_h_ecmwf
    USE mod_blk_andreas,   ONLY: psi_m_andreas, psi_h_andreas, u_star_andreas
@@ -23,7 +23,7 @@ PROGRAM phymbl_driver
 
    IMPLICIT NONE
 
-   INTEGER, PARAMETER :: ncol = 33, ns_max = 8
+   INTEGER, PARAMETER :: ncol = 34, ns_max = 8
    REAL(wp), PARAMETER :: pz = 2._wp, pzu = 10._wp
    INTEGER(4) :: n4
    INTEGER :: n, ns, k
@@ -34,7 +34,7 @@ PROGRAM phymbl_driver
    !! columns
    INTEGER, PARAMETER :: iTa=1, iTs=2, iP=3, iqa=4, iqs=5, iTh=6, iPz=7, ius=8, itst=9, iqst=10, iW=11, iUb=12, iCd=13, iCh=14, &
       &                  iCe=15, ipsi=16, iz0=17, iRib=18, irlw=19, irh=20, idp=21, irho=22, iRer=23, ialp=24, iQd=25, iQlt=26,   &
-      &                  iTly=27, iqly=28, iTi=29, inua=30, izeta=31, istab=32, isqcd=33
+      &                  iTly=27, iqly=28, iTi=29, inua=30, izeta=31, istab=32, isqcd=33, icharn=34
 
    CALL GET_COMMAND_ARGUMENT(1, cfin)
    CALL GET_COMMAND_ARGUMENT(2, cfout)
@@ -106,6 +106,20 @@ PROGRAM phymbl_driver
       s2(k) = Ri_bulk( pzu, c(k,1,iTs), c(k,1,iTh), c(k,1,iqs), c(k,1,iqa), c(k,1,iUb) )
    END DO
    CALL puts('one_on_l_s', s1) ; CALL puts('ri_bulk_s', s2)
+   !! FIRST_GUESS_COARE (zt = 2 m, zu = 10 m; a Charnock parameter per cell).  Here, BEFORE Ri_bulk is given its layer arguments: the routine calls
+   !! Ri_bulk_sclr without them, and the reference's function, once it has had them, reads them for ever (absent: a segmentation fault)
+   BLOCK
+      REAL(wp), DIMENSION(:,:), ALLOCATABLE :: g1, g2, g3, g4, g5, g6, g7
+      ALLOCATE( g1(n,1), g2(n,1), g3(n,1), g4(n,1), g5(n,1), g6(n,1), g7(n,1) )
+      CALL first_guess_coare( pz, pzu, c(:,:,iTs), c(:,:,iTh), c(:,:,iqs), c(:,:,iqa), c(:,:,iW), c(:,:,icharn), g1, g2, g3, g4, g5, g6, qz0=g7 )
+      CALL put('fg_us', g1) ; CALL put('fg_ts', g2) ; CALL put('fg_qs', g3) ; CALL put('fg_t_zu', g4) ; CALL put('fg_q_zu', g5)
+      CALL put('fg_ub', g6) ; CALL put('fg_z0', g7)
+      DO k = 1, ns
+         CALL first_guess_coare( pz, pzu, c(k,1,iTs), c(k,1,iTh), c(k,1,iqs), c(k,1,iqa), c(k,1,iW), c(k,1,icharn), &
+            &                    s1(k), s2(k), s3(k), s4(k), s5(k), g6(k,1) )
+      END DO
+      CALL puts('fg_us_s', s1) ; CALL puts('fg_t_zu_s', s4)
+   END BLOCK
    !! (the layer arguments last: the reference's Ri_bulk never forgets that it once had them)
    r1 = Ri_bulk( pzu, c(:,:,iTs), c(:,:,iTh), c(:,:,iqs), c(:,:,iqa), c(:,:,iUb), pTa_layer=c(:,:,iTly), pqa_layer=c(:,:,iqly) )
    CALL put('ri_bulk_layer', r1)
@@ -245,6 +259,7 @@ CONTAINS
       CHARACTER(len=24) :: c24
       c24 = cname
       WRITE(12) c24, INT(SIZE(pr),4), pr
+      FLUSH(12)
    END SUBROUTINE put
 
    SUBROUTINE putk( cname, ps, km )

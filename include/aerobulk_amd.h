@@ -287,7 +287,7 @@ int ab_turb_ice_easy(double zt, double zu, int nb_iter, double CdN, double ChN, 
  *                 an OPTIONAL array that is not passed is NULL (or beyond n_in)
  *   out[0..n_out) the results; NULL members are not written (at least one must be given)
  *   par[0]        the function's scalar REAL argument if it has one: pz / pzu, or pPref when in[2] is NULL (pot_temp, abs_temp);
- *                 par[1] reserved (pass 0)
+ *                 par[1]: zu of AB_PH_FIRST_GUESS_COARE (par[0] = zt); else reserved (pass 0)
  *   flag          its LOGICAL / INTEGER argument: l_ice (0 / 1), iflag of z0tq_LKB (1 temperature, 2 humidity)
  *   mem           AB_MEM_HOST: arrays staged through HBM; AB_MEM_DEVICE: device arrays, enqueued on `stream` (hipStream_t).  Both
  *                 return when the results are complete.
@@ -353,7 +353,9 @@ enum ab_phymbl_fn {
     AB_PH_CD_N10_NCAR = 52,         /* pw10 ; - ; CdN10                                      mod_blk_ncar.f90:244-284 */
     AB_PH_CH_N10_NCAR = 53,         /* psqrtcdn10, pstab ; - ; ChN10                         mod_blk_ncar.f90:287-310 */
     AB_PH_CE_N10_NCAR = 54,         /* psqrtcdn10 ; - ; CeN10                                mod_blk_ncar.f90:313-330 */
-    AB_PH_U_STAR_ANDREAS = 55       /* pun10 ; - ; u*                                        mod_blk_andreas.f90:275-305 */
+    AB_PH_U_STAR_ANDREAS = 55,      /* pun10 ; - ; u*                                        mod_blk_andreas.f90:275-305 */
+    AB_PH_FIRST_GUESS_COARE = 56    /* psst, t_zt, pssq, q_zt, U_zu, pcharn ; zt, zu (par[0], par[1]) ; pus, pts, pqs, t_zu, q_zu, Ubzu, pz0
+                                                                                              mod_common_coare.f90:33-214 */
 };
 int ab_phymbl(int fn, long n, const double *const *in, int n_in, double *const *out, int n_out, const double *par, int flag,
               int mem, void *stream, double *info);

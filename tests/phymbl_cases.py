@@ -1,12 +1,12 @@
 """Inputs and call table of the mod_phymbl helper tests (tests/test_phymbl.py, tools/gen_phymbl_golden.py).
 
-COLUMNS: the 33 columns aerobulk_amd/fortran/phymbl_driver.f90 reads, in its order.  CALLS: for every array record that driver
+COLUMNS: the 34 columns aerobulk_amd/fortran/phymbl_driver.f90 reads, in its order.  CALLS: for every array record that driver
 writes, the `ab_phymbl` call (include/aerobulk_amd.h) that must reproduce it: (fn, par0, flag, input columns | None, index of the
 output).  The same table drives the C ABI on the GPU and the host instantiation of the product header (tests/phymbl_host.cpp)."""
 import numpy as np
 
 COLUMNS = ["Ta", "Ts", "P", "qa", "qs", "Th", "Pz", "us", "tst", "qst", "W", "Ub", "Cd", "Ch", "Ce", "psi", "z0", "Rib", "rlw", "rh",
-           "dp", "rho", "Rer", "alp", "Qd", "Qlt", "Tly", "qly", "Ti", "nua", "zeta", "stab", "sqcd"]
+           "dp", "rho", "Rer", "alp", "Qd", "Qlt", "Tly", "qly", "Ti", "nua", "zeta", "stab", "sqcd", "charn"]
 Z_T, Z_U = 2.0, 10.0       # the driver's pz and pzu
 PATM = 101000.0
 
@@ -57,6 +57,7 @@ def make_columns(n=512, seed=20251003):
     c["zeta"] = z
     c["stab"] = np.where(u(0., 1.) < 0.5, 0., 1.) * u(0.9999, 1.)       # NCAR's stable / unstable switch (a real number in [0, 1])
     c["sqcd"] = np.sqrt(u(0.3e-3, 3e-3))                                 # SQRT(CdN10); the low end reaches the floor Cx_min of the products
+    c["charn"] = u(0.005, 0.03)                                          # Charnock parameter handed to FIRST_GUESS_COARE
     return np.stack([c[k] for k in COLUMNS], axis=0)     # (29, n)
 
 
@@ -65,7 +66,7 @@ def make_columns(n=512, seed=20251003):
  DE_SAT_DT_ICE, Q_SAT, DQ_SAT_DT_ICE, Q_AIR_RH, Q_AIR_DP, RHO_AIR_ADV, Q_SAT_CRUDE, DRY_STATIC_ENERGY, UPDATE_QNSOL_TAU, BULK_FORMULA,
  ALPHA_SW, QLW_NET, Z0_FROM_CD, Z0_FROM_USTAR, CD_FROM_Z0, F_M_LOUIS, F_H_LOUIS, UN10_FROM_USTAR, UN10_FROM_CDN, UN10_FROM_CD, Z0TQ_LKB,
  E_AIR, RH_AIR, DELTA_SKIN, ROUGH_LENG_M, ROUGH_LENG_TQ, PSI_M_COARE, PSI_H_COARE, PSI_M_NCAR, PSI_H_NCAR, PSI_M_ECMWF, PSI_H_ECMWF, PSI_M_ANDREAS,
- PSI_H_ANDREAS, CHARN_COARE3P0, CHARN_COARE3P6, CD_N10_NCAR, CH_N10_NCAR, CE_N10_NCAR, U_STAR_ANDREAS) = range(1, 56)
+ PSI_H_ANDREAS, CHARN_COARE3P0, CHARN_COARE3P6, CD_N10_NCAR, CH_N10_NCAR, CE_N10_NCAR, U_STAR_ANDREAS, FIRST_GUESS_COARE) = range(1, 57)
 
 _UQT = ["Ts", "qs", "Th", "qa", "us", "tst", "qst", "W", "Ub", "P", "rlw"]
 _BF = ["Ts", "qs", "Th", "qa", "Cd", "Ch", "Ce", "W", "Ub", "P"]
@@ -142,12 +143,16 @@ CALLS = {
     "charn_coare3p0": (CHARN_COARE3P0, 0., 0, ["W"], 0), "charn_coare3p6": (CHARN_COARE3P6, 0., 0, ["W"], 0),
     "cd_n10_ncar": (CD_N10_NCAR, 0., 0, ["W"], 0), "u_star_andreas": (U_STAR_ANDREAS, 0., 0, ["W"], 0),
     "ch_n10_ncar": (CH_N10_NCAR, 0., 0, ["sqcd", "stab"], 0), "ce_n10_ncar": (CE_N10_NCAR, 0., 0, ["sqcd"], 0),
+    # FIRST_GUESS_COARE(zt = 2, zu = 10; ...): par0 = zt, par1 = zu (PAR1)
+    **{"fg_" + k: (FIRST_GUESS_COARE, Z_T, 0, ["Ts", "Th", "qs", "qa", "W", "charn"], i)
+       for i, k in enumerate(("us", "ts", "qs", "t_zu", "q_zu", "ub", "z0"))},
     # scalar-only in the reference: checked on the first cells
     "delta_skin_s": (DELTA_SKIN, 0., 0, ["alp", "Qd", "us"], 0),
     "delta_skin_qlat_s": (DELTA_SKIN, 0., 0, ["alp", "Qd", "us", "Qlt"], 0),
 }
 # outputs each function has (to size the `out` table)
-N_OUT = {UPDATE_QNSOL_TAU: 3, BULK_FORMULA: 5, ROUGH_LENG_TQ: 2}
+N_OUT = {UPDATE_QNSOL_TAU: 3, BULK_FORMULA: 5, ROUGH_LENG_TQ: 2, FIRST_GUESS_COARE: 7}
+PAR1 = {FIRST_GUESS_COARE: Z_U}
 # records of the driver that are NOT array results of one call: the `_s` twins (scalar specifics = same numbers on the first cells),
 # the SAVE quirks and the host-side bookkeeping
 EXTRA = ["pref_sticky_s", "variance_vmean", "type_of_humidity", "mod_const"]

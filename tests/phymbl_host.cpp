@@ -25,9 +25,9 @@ struct Call {
 template <int FN> static void run_fn(const Call &c, const std::vector<const double *> &in, unsigned present, long n, std::vector<double> &out)
 {
     constexpr PhShape sh = ph_shape(FN);
-    const double par[2] = {c.par0, 0.};
+    const double par[2] = {c.par0, c.fn == kPhFirstGuessCoare ? 10. : 0.};      // (FIRST_GUESS_COARE: zt = par0, zu = 10 m)
     for (long k = 0; k < n; ++k) {
-        double x[12] = {0.}, y[5] = {0.};
+        double x[12] = {0.}, y[8] = {0.};
         for (int i = 0; i < 12; ++i)
             if ((present >> i) & 1u) x[i] = in[i][k];
         ph_cell<FN, double>(x, present, par, c.flag, y);
@@ -85,7 +85,7 @@ int main(int argc, char **argv)
         unsigned present = 0;
         for (int i = 0; i < c.n_in; ++i)
             if (c.col[i] >= 0) { in[i] = cols.data() + (size_t)c.col[i] * n; present |= 1u << i; }
-        std::vector<double> out((size_t)5 * n, 0.), e;
+        std::vector<double> out((size_t)8 * n, 0.), e;
         if (c.fn == kPhEair) {
             e = e_air_host(in[0], in[1], n);
             for (long k = 0; k < n; ++k) out[k] = e[k];

@@ -48,7 +48,7 @@ def test_golden_covers_every_function(gold):
     cols, rec = gold
     assert cols.shape == (len(pc.COLUMNS), 512)
     fns = {c[0] for c in pc.CALLS.values()}
-    assert fns == set(range(1, 56)), sorted(set(range(1, 56)) - fns)       # all 55 ids of enum ab_phymbl_fn
+    assert fns == set(range(1, 57)), sorted(set(range(1, 57)) - fns)       # all 56 ids of enum ab_phymbl_fn
     for name in list(pc.CALLS) + pc.EXTRA:
         assert name in rec, name
     # every `_s` record of the driver (the scalar specifics) equals the array record on the first cells IN THE REFERENCE ITSELF to
@@ -153,7 +153,7 @@ def _call_gpu(ab, cols, name, device=None):
     if device is not None:
         import torch
         arrs = [None if a is None else torch.from_numpy(a).to(device) for a in arrs]
-    outs, info = ab.phymbl(fn, arrs, par0, flag, pc.N_OUT.get(fn, 1))
+    outs, info = ab.phymbl(fn, arrs, par0, flag, pc.N_OUT.get(fn, 1), par1=pc.PAR1.get(fn, 0.))
     o = outs[oi]
     return (o.cpu().numpy() if device is not None else o), info
 
@@ -189,7 +189,7 @@ def test_scalars_are_one_cell_arrays(gold):
         fn, par0, flag, ins, oi = pc.CALLS[name]
         full, _ = _call_gpu(ab, cols, name)
         for k in (0, 3):
-            outs, _ = ab.phymbl(fn, [None if c is None else col(cols, c)[k:k + 1] for c in ins], par0, flag, pc.N_OUT.get(fn, 1))
+            outs, _ = ab.phymbl(fn, [None if c is None else col(cols, c)[k:k + 1] for c in ins], par0, flag, pc.N_OUT.get(fn, 1), par1=pc.PAR1.get(fn, 0.))
             assert outs[oi][0] == full[k], (name, k)
 
 
