@@ -164,3 +164,19 @@ def test_gathers_of_two_steps_in_flight_deliver_each_steps_fields(oracle):
     for t in range(nsteps):
         ref = oracle.OracleSession("coare3p6", ni * nj, 1, False).compute(1, 2.0, 10.0, 2 + t, f["sst"], f["t_zt"], f["hum_zt"], f["u_zu"], f["v_zu"], f["slp"])
         np.testing.assert_array_equal(got[t], ref["ql"], err_msg=f"step {t}")
+
+
+def test_committed_profile_is_of_this_device_code():
+    """bench.py quotes the committed counter profile (HBM traffic, VALU share) only when it was taken with the very device code of this tree:
+    the hash covers the flux kernels' translation unit, every header it includes and the compile flags.  A change to any of them must be
+    followed by a re-take (tools/prof_quick.sh, tools/update_pmc.py --headline) before the round closes."""
+    import json
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16
+    pmc = json.load(open(bench.PMC_JSON))
+    assert pmc["source_hash"] == h, "profiles/r5_pmc.json was taken with other kernel sources: re-take it"
+    got = bench.committed_pmc("coare3p6", True, 4320, 3600, 5, "f64")
+    assert got and not got.get("stale") and got["valu_insts_per_cell"] > 1000
+    # a header of another translation unit (the helper kernels') does not enter the hash
+    assert "ab_phymbl.hpp" not in open(os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_kernels.hip")).read()
