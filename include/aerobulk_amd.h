@@ -136,7 +136,10 @@ int ab_session_set_humidity(ab_session *s, int hum_type);
  * AB_MEM_DEVICE: enqueued on `stream` (hipStream_t, NULL = default stream); call
  * ab_session_check() to synchronise and fetch the AB_ERR_TAU flag.  The calls of ONE session must be ordered among themselves (one
  * stream, or the caller's own dependencies between streams): they share the warm-layer state, the error flag and the tile counters
- * of the persistent kernel.  Independent streams take independent sessions. */
+ * of the persistent kernel.  Independent streams take independent sessions.
+ * ab_session_check also VERIFIES the persistent kernel's tile counters (zero after a launch that handed out every tile): AB_ERR_STATE if
+ * a launch did not finish its queue (aborted, or two computes of one session overlapped) — the counters are re-armed, the fluxes of that
+ * record must be recomputed; AB_ERR_HIP if the kernel found its argument block laid out otherwise than the host assumed. */
 int ab_session_compute(ab_session *s, int jt, double zt, double zu, int niter,
                        const void *sst, const void *t_zt, const void *hum_zt,
                        const void *u_zu, const void *v_zu, const void *slp,
