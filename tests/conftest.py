@@ -211,6 +211,24 @@ def oracle_pool():
     return _POOL
 
 
+_TIER_COUNTS = {}
+
+
+def pytest_runtest_logreport(report):
+    # what ran in which tier: a green exit with the soak tier skipped by the budget must not read like a full run (one line at the end)
+    if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+        if "gpu" in getattr(report, "keywords", {}):
+            t = int(tier_of(report.nodeid))
+            c = _TIER_COUNTS.setdefault(t, {"passed": 0, "failed": 0, "skipped": 0})
+            c[report.outcome] = c.get(report.outcome, 0) + 1
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _TIER_COUNTS:
+        parts = [f"tier {t}: {c['passed']} passed, {c['failed']} failed, {c['skipped']} skipped" for t, c in sorted(_TIER_COUNTS.items())]
+        terminalreporter.write_line("[ab-test] GPU tiers — " + "; ".join(parts) + (f" (soak budget {BUDGET_S:.0f} s)" if BUDGET_S > 0 else " (no budget)"))
+
+
 def pytest_sessionfinish(session, exitstatus):
     global _POOL
     if _POOL is not None:
