@@ -231,6 +231,12 @@ def main():
     rows, err = bits_table(wl_abs, -4, 5, 8, lo=mp.mpf("0.1"), hi=mp.mpf(20), rel=True)
     print("kLWlAbs", err, file=sys.stderr)
     emit10("kLWlAbs", rows, err, "WL_COARE absorbed fraction vs depth H for LDS (relative error on [0.1, 20])")
+    if "--psik-bits" in sys.argv:      # experiment of round 5 (profiles/r5_notes.md section 8): the Kansas pair indexed by the bits of y = |1 - 16 zeta|
+        out.append("constexpr int kLPsikN = 80;")
+        for nm, fsel in (("kLPsikM", psik_m), ("kLPsikH", psik_h)):
+            rows, err = bits_table(lambda y, fsel=fsel: fsel(mp.log(y)), 0, 10, 8)
+            print(nm, err, file=sys.stderr)
+            emit10(nm, rows, err, "Kansas " + nm + " vs y = |1 - 16 zeta| (bit-indexed)")
     DEG = 7
     out.append("}  // namespace ab")
     print("\n".join(out))
