@@ -64,7 +64,7 @@ FLIB = os.path.join(FDIR, "libaerobulk_amd_fortran.a")
 FMODS = ["mod_const", "mod_phymbl", "mod_aerobulk", "mod_blk_turb", "mod_blk_ice"]
 # the repo's own drivers (test harnesses of tests/test_turb_series.py, test_neutral10.py, test_sea_ice.py, test_gpu_hosts.py,
 # test_phymbl.py)
-FDRIVERS = ["example_call_aerobulk", "turb_series_driver", "neutral10_driver", "turb_ice_driver", "phymbl_driver"]
+FDRIVERS = ["example_call_aerobulk", "turb_series_driver", "neutral10_driver", "turb_ice_driver", "phymbl_driver", "oce_ice_driver"]
 REF = os.environ.get("AEROBULK_REFERENCE", "/root/reference")
 # Callers of the reference compiled UNCHANGED, where they lie, against the modules above (the drop-in check of SURVEY §8b): binaries
 # go to oracle/_ref/dropin/ (git-ignored, travels to the GPU box like the other reference builds).  Build container only.
