@@ -74,6 +74,7 @@ SYMBOLS = {
     "ab_session_turb": (C.c_int, [vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(TurbFields), C.c_int, vp]),
     "ab_turb": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, dp] + [dp] * 8 + [dp] * 6
                 + [C.POINTER(Diag), C.c_long, C.c_long]),
+    "ab_turb_get_wl_state": (C.c_int, [C.c_int, dp, dp, dp, dp, C.c_long]),
     "ab_turb_neutral_10m": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, vp]),
     "ab_turb_ice": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(IceFields), C.c_long, C.c_int, C.c_int, vp]),
     "ab_turb_ice_easy": (C.c_int, [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(IceFields), C.c_long,
@@ -89,6 +90,7 @@ SYMBOLS = {
     "ab_session_last_kernel_ms": (C.c_double, [vp]),
     "ab_synth_fields_device": (C.c_int, [vp] * 8 + [C.c_long, C.c_long, C.c_long, C.c_int, vp]),
     "ab_test_math": (C.c_int, [C.c_int, dp, dp, dp, C.c_long]),
+    "ab_calibrate": (C.c_int, [C.c_int, C.c_int, vp, dp, dp]),
     "ab_phymbl": (C.c_int, [C.c_int, C.c_long, C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_int, dp, C.c_int, C.c_int, vp, dp]),
     "ab_model": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_double] + [dp] * 6 + [dp] * 5
                  + [C.c_int, C.c_int, dp, dp, dp, C.c_long, C.c_long, C.POINTER(InitReport)]),

@@ -424,6 +424,20 @@ def synth_fields_device(Ni, Nj, j0=0, nj_local=None, precision="f64", device="cu
     return f
 
 
+CALIB = {"fma_f64": 0, "hbm_copy": 1}
+
+
+def calibrate(what="fma_f64", device=0, stream=None):
+    """ab_calibrate (include/aerobulk_amd.h): a fixed device workload that depends on the box alone -> (ms of the timed launch, rate);
+    rate in fp64 TFLOP/s ("fma_f64") or GB/s read + written ("hbm_copy")."""
+    lib = _lib.load()
+    ms, rate = C.c_double(0.), C.c_double(0.)
+    rc = lib.ab_calibrate(CALIB[what], int(device), C.c_void_p(stream or 0), C.byref(ms), C.byref(rate))
+    if rc:
+        _raise(rc)
+    return ms.value, rate.value
+
+
 ICE_ALGOS = {"nemo": 1, "an05": 2, "lu12": 3, "lg15": 4, "easy": 5}
 ICE_OUT = ("Cd", "Ch", "Ce", "t_zu", "q_zu", "Ub", "CdN", "ChN", "CeN", "z0", "u_star", "L", "UN10")
 ICE_OUT_LG15 = ICE_OUT + ("CdN_frm",)      # TURB_ICE_LG15_IO's form-drag output (mod_blk_ice_lg15_io.f90:71)

@@ -22,7 +22,7 @@ ARCH = "gfx950"
 # -target-feature -fmacf64-inst: without the 2-address v_fmac_f64 the Horner steps a*b + C are selected as the 3-address
 # v_fma_f64 with the coefficient C read straight from an SGPR pair; with it every step pays a v_mov_b64 (VALU) to bring C
 # into the accumulator register (10 % of the VALU instructions of the iteration loop, profiles/r1_notes.md)
-HIPFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+HIPFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast-honor-pragmas",
             "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-mllvm", "-disable-machine-licm",
             "-Xclang", "-target-feature", "-Xclang", "-fmacf64-inst"]
 
@@ -40,7 +40,7 @@ def _run(cmd, **kw):
 
 
 def build_engine(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_ice_kernels.hip", "ab_phymbl.hip", "ab_runtime.hip", "ab_sharded.hip", "ab_cxx.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("ab_kernels.hip", "ab_turb_kernels.hip", "ab_ice_kernels.hip", "ab_phymbl.hip", "ab_calib.hip", "ab_runtime.hip", "ab_sharded.hip", "ab_cxx.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [
         os.path.join(ROOT, "include", "aerobulk_amd.h"), os.path.join(ROOT, "include", "aerobulk.hpp"), os.path.abspath(__file__)]
     if not force and not _newer(LIB, deps):
@@ -64,7 +64,7 @@ FLIB = os.path.join(FDIR, "libaerobulk_amd_fortran.a")
 FMODS = ["mod_const", "mod_phymbl", "mod_aerobulk", "mod_blk_turb", "mod_blk_ice"]
 # the repo's own drivers (test harnesses of tests/test_turb_series.py, test_neutral10.py, test_sea_ice.py, test_gpu_hosts.py,
 # test_phymbl.py)
-FDRIVERS = ["example_call_aerobulk", "turb_series_driver", "neutral10_driver", "turb_ice_driver", "phymbl_driver", "oce_ice_driver"]
+FDRIVERS = ["example_call_aerobulk", "turb_series_driver", "neutral10_driver", "turb_ice_driver", "phymbl_driver", "oce_ice_driver", "skin_driver"]
 REF = os.environ.get("AEROBULK_REFERENCE", "/root/reference")
 # Callers of the reference compiled UNCHANGED, where they lie, against the modules above (the drop-in check of SURVEY §8b): binaries
 # go to oracle/_ref/dropin/ (git-ignored, travels to the GPU box like the other reference builds).  Build container only.

@@ -5,6 +5,7 @@
 #include "../../include/aerobulk_amd.h"
 #include "ab_kernels.hpp"
 #include "ab_phymbl.hpp"
+#include "ab_session.hpp"
 
 #include <cstdio>
 #include <cstring>
@@ -77,8 +78,9 @@ template <int FN = 1> static hipError_t launch_fn(int fn, const PhArgs &a, hipSt
 // e_air (mod_phymbl.f90:1706-1736): e <- q/eps (p - (1 - eps) e) from e = q p/eps until the SUM over the array of |change| is
 // <= 1e-6 — a whole-array criterion, so the sweeps are separate launches with the sum brought to the host in between.  `e` ends up in
 // d_e (device, n doubles); d_tmp is a second buffer of the same size.
-static hipError_t e_air_device(const double *d_q, const double *d_p, double *d_e, double *d_tmp, long n, hipStream_t stream)
+static hipError_t e_air_device(const double *d_q, const double *d_p, double *d_e, double *d_tmp, long n, hipStream_t stream, bool *converged)
 {
+    *converged = false;
     const long nblk = (n + kPhBlock - 1) / kPhBlock;
     double *d_sums = nullptr;
     hipError_t e = hipMalloc((void **)&d_sums, sizeof(double) * (size_t)nblk);
@@ -105,7 +107,7 @@ static hipError_t e_air_device(const double *d_q, const double *d_p, double *d_e
         double zdiff = 0.;
         for (long b = 0; b < nblk; ++b) zdiff += sums[(size_t)b];
         double *t = cur; cur = nxt; nxt = t;
-        if (!(zdiff > 1.e-6)) break;      // DO WHILE ( zdiff > repsilon )
+        if (!(zdiff > 1.e-6)) { *converged = true; break; }     // DO WHILE ( zdiff > repsilon ): a NaN sum leaves the loop there too
     }
     if (e == hipSuccess && cur != d_e) e = hipMemcpyAsync(d_e, cur, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream);
     (void)hipFree(d_sums);
@@ -135,7 +137,7 @@ extern "C" int ab_phymbl(int fn, long n, const double *const *in, int n_in, doub
     using namespace ab;
     const PhShape sh = ph_shape(fn);
     if (sh.n_out == 0) return ph_fail(AB_ERR_ARG, "ab_phymbl: unknown function id");
-    if (n <= 0 || !in || !out) return ph_fail(AB_ERR_ARG, "ab_phymbl: bad n / NULL argument tables");
+    if (n < 0 || !in || !out) return ph_fail(AB_ERR_ARG, "ab_phymbl: bad n / NULL argument tables");
     if (n_in < sh.n_in_required || n_in > kPhMaxIn || n_out < 1) return ph_fail(AB_ERR_ARG, "ab_phymbl: wrong number of arrays for this function");
     if (n_in > sh.n_in) n_in = sh.n_in;          // the tables may be longer than this function needs: the rest is ignored
     if (n_out > sh.n_out) n_out = sh.n_out;
@@ -148,15 +150,31 @@ extern "C" int ab_phymbl(int fn, long n, const double *const *in, int n_in, doub
     for (int i = 0; i < n_out; ++i) any_out = any_out || out[i];
     if (!any_out) return ph_fail(AB_ERR_ARG, "ab_phymbl: no output array");
     if (info) { info[0] = -1.; info[1] = 0.; }
+    if (n == 0) return AB_OK;                    // zero-size arrays: the reference's elemental loops run no trip
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return ph_fail(AB_ERR_HIP, "no HIP device visible: this engine has no CPU fallback");
 
+    // AB_MEM_DEVICE: the work goes to the device that OWNS the caller's arrays (scratch, block sums, launches), not to whatever device
+    // is current in the calling thread; the caller's device is restored on return (as ab_session_* do)
+    ab::DeviceGuard dguard_;
+    if (mem == AB_MEM_DEVICE) {
+        const void *first = nullptr;
+        for (int i = 0; i < n_in && !first; ++i) first = in[i];
+        hipPointerAttribute_t at;
+        if (first && hipPointerGetAttributes(&at, first) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            if (hipSetDevice(at.device) != hipSuccess) return ph_fail(AB_ERR_HIP, "ab_phymbl: hipSetDevice to the arrays' device failed");
+        } else {
+            (void)hipGetLastError();
+            return ph_fail(AB_ERR_ARG, "ab_phymbl: AB_MEM_DEVICE arrays are not device memory");
+        }
+    }
     const bool two_pass = fn == kPhRhoAirAdv || fn == kPhRhAir || fn == kPhEair;
     const bool tau_check = fn == kPhBulkFormula;
     const size_t bytes = sizeof(double) * (size_t)n;
     hipStream_t s = (hipStream_t)(mem == AB_MEM_DEVICE ? stream : nullptr);
     hipError_t e = hipSuccess;
+    bool e_air_converged = true;
 
     // device scratch: staged inputs / outputs of a host call, the e_air iterates, the wind-stress flag
     const int n_stage = mem == AB_MEM_HOST ? n_in + n_out : 0;
@@ -197,7 +215,7 @@ extern "C" int ab_phymbl(int fn, long n, const double *const *in, int n_in, doub
             // e_air( pqa, pslp ): argument positions differ per function
             const double *d_q = fn == kPhRhoAirAdv ? a.in[1] : a.in[0];
             const double *d_p = fn == kPhEair ? a.in[1] : a.in[2];
-            e = e_air_device(d_q, d_p, d_e, d_tmp, n, s);
+            e = e_air_device(d_q, d_p, d_e, d_tmp, n, s, &e_air_converged);
             if (e == hipSuccess) {
                 if (fn == kPhEair) {
                     e = hipMemcpyAsync(a.out[0], d_e, bytes, hipMemcpyDeviceToDevice, s);
@@ -225,6 +243,8 @@ extern "C" int ab_phymbl(int fn, long n, const double *const *in, int n_in, doub
         e = hipMemcpy(&bad_tau, a.out[0] + bad, sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(scratch);
     if (e != hipSuccess) return ph_hip_fail(e, "kernel / copy");
+    if (!e_air_converged)      // the reference would sweep for ever; the last iterate is in the output arrays
+        return ph_fail(AB_ERR_NOCONV, "e_air()@mod_phymbl: SUM(ABS(ee - e_old)) still above 1e-6 after 200 sweeps over the array");
     if (tau_check && bad != ~0ull) {
         if (info) { info[0] = (double)bad; info[1] = bad_tau; }
         char buf[160];

@@ -27,9 +27,11 @@ enum {
     kPhRhAir, kPhDeltaSkinLayer, kPhRoughLengM, kPhRoughLengTq,
     // the PUBLIC functions of the algorithm modules (mod_common_coare, mod_blk_coare3p0 / coare3p6 / ncar / ecmwf / andreas)
     kPhPsiMCoare, kPhPsiHCoare, kPhPsiMNcar, kPhPsiHNcar, kPhPsiMEcmwf, kPhPsiHEcmwf, kPhPsiMAndreas, kPhPsiHAndreas,
-    kPhCharnCoare3p0, kPhCharnCoare3p6, kPhCdN10Ncar, kPhChN10Ncar, kPhCeN10Ncar, kPhUStarAndreas, kPhFirstGuessCoare, kPhCount
+    kPhCharnCoare3p0, kPhCharnCoare3p6, kPhCdN10Ncar, kPhChN10Ncar, kPhCeN10Ncar, kPhUStarAndreas, kPhFirstGuessCoare,
+    // the skin schemes as their modules export them (mod_skin_coare.f90:28, mod_skin_ecmwf.f90:49)
+    kPhCsCoare, kPhCsEcmwf, kPhWlCoare, kPhWlEcmwf, kPhCount
 };
-static_assert(kPhPsiMCoare == 42 && kPhUStarAndreas == 55 && kPhFirstGuessCoare == 56, "enum ab_phymbl_fn of include/aerobulk_amd.h");
+static_assert(kPhPsiMCoare == 42 && kPhUStarAndreas == 55 && kPhFirstGuessCoare == 56 && kPhWlEcmwf == 60, "enum ab_phymbl_fn of include/aerobulk_amd.h");
 
 template <class R> struct KPh {   // the constants of mod_const.f90 / mod_phymbl.f90 that the flux kernels do not need
     static constexpr R rtt0 = R(273.16);                    // mod_const.f90:61
@@ -290,6 +292,25 @@ template <int FN, class R> __device__ __forceinline__ void ph_cell(const R *x, u
         h.fg_cb = -R(0.004 * 600. * 1.2 * 1.2 * 1.2) * h.inv_zu;
         h.zt_eq_zu = M::abs(par[1] - par[0]) < R(0.01) ? 1 : 0;
         first_guess_coare<R, R>(h, x[0], x[1], x[2], x[3], x[4], x[5], y[0], y[1], y[2], y[3], y[4], y[5], y[6]);
+    // ---- the skin schemes standing alone: the device functions TURB_COARE3P0 / 3P6 / ECMWF iterate with, one call per cell
+    } else if constexpr (FN == kPhCsCoare) {         // CS_COARE, mod_skin_coare.f90:48-93  ( pQsw, pQnsol, pustar, pSST, pQlat ) -> pdT_cs
+        y[0] = cool_skin<R, true, false>(x[0], x[1], x[2], alpha_sw<R>(x[3]), x[4]);
+    } else if constexpr (FN == kPhCsEcmwf) {         // CS_ECMWF, mod_skin_ecmwf.f90:68-110  ( pQsw, pQnsol, pustar, pSST ) -> pdT_cs
+        y[0] = cool_skin<R, false, false>(x[0], x[1], x[2], alpha_sw<R>(x[3]), R(0.));
+    } else if constexpr (FN == kPhWlCoare) {         // WL_COARE, mod_skin_coare.f90:97-250  ( isd ; pQsw, pQnsol, pTau, pSST, plon, dT_wl, Hz_wl, Qnt_ac, Tau_ac ; iwait )
+        // -> the four state variables after the call (unchanged when iwait /= 0, :239-248); isd travels as par[0] (an integer below 86400: exact)
+        const R zalpha = alpha_sw<R>(x[3]);
+        WlCoareCell<R> wc;
+        wc.zcd1 = M::sqrt(M::div(R(2.) * R(0.65) * K<R>::rCp0_w, zalpha * K<R>::grav * K<R>::rho0_w));     // :155
+        wc.zcd2 = M::sqrt(R(2.) * zalpha * K<R>::grav * R(1. / (0.65 * 1025.))) * R(1. / 271219.5770957547);   // :156
+        wc.dawn = wl_coare_dawn<R>(x[4], (int)par[0]);
+        R st[4] = {x[5], x[6], x[7], x[8]};
+        wl_coare<R, false>(st, wc, x[0], x[1], x[2], flag == 0);
+        y[0] = st[0]; y[1] = st[1]; y[2] = st[2]; y[3] = st[3];
+    } else if constexpr (FN == kPhWlEcmwf) {         // WL_ECMWF, mod_skin_ecmwf.f90:113-230  ( pQsw, pQnsol, pustar, pSST, dT_wl, Hz_wl, [pustk] ) -> dT_wl
+        R dT = x[4];
+        wl_ecmwf<R>(dT, x[5], wl_ecmwf_cell<R>(x[5]), x[0], x[1], x[2], alpha_sw<R>(x[3]), (present & 0x40u) ? vmax(x[6], R(0.)) : R(-1.));
+        y[0] = dT;
     }
 }
 
@@ -332,6 +353,10 @@ constexpr PhShape ph_shape(int fn)
     case kPhUStarAndreas: return {1, 1, 1};
     case kPhChN10Ncar: return {2, 2, 1};
     case kPhFirstGuessCoare: return {6, 6, 7};
+    case kPhCsCoare: return {5, 5, 1};
+    case kPhCsEcmwf: return {4, 4, 1};
+    case kPhWlCoare: return {9, 9, 4};
+    case kPhWlEcmwf: return {7, 6, 1};
     default: return {0, 0, 0};
     }
 }

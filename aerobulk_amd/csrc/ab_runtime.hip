@@ -114,6 +114,7 @@ const char *ab_strerror(int st)
     case AB_ERR_HIP: return "HIP runtime error / no usable gfx950 device";
     case AB_ERR_ARG: return "bad argument";
     case AB_ERR_STATE: return "call protocol violated";
+    case AB_ERR_NOCONV: return "e_air fixed point not converged";
     default: return "unknown status";
     }
 }
@@ -1142,6 +1143,26 @@ int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int 
     f.Qsw = Qsw; f.rad_lw = rad_lw; f.slp = slp;
     f.Cd = Cd; f.Ch = Ch; f.Ce = Ce; f.t_zu = t_zu; f.q_zu = q_zu; f.Ubzu = Ubzu;
     return ab_session_turb(s, kt, zt, zu, use_cs, use_wl, nb_iter, &f, AB_MEM_HOST, nullptr);
+}
+
+/* The warm-layer state of the process-global TURB_<algo> session after the latest ab_turb call, plane by plane (NULL: not wanted): what the
+ * reference keeps as PUBLIC module arrays of mod_skin_coare / mod_skin_ecmwf (dT_wl, Hz_wl, Qnt_ac, Tau_ac: mod_skin_coare.f90:31-36) */
+int ab_turb_get_wl_state(int algo, double *dT_wl, double *Hz_wl, double *Qnt_ac, double *Tau_ac, long n)
+{
+    if (algo < AB_ALGO_COARE3P0 || algo > AB_ALGO_ANDREAS) return fail(AB_ERR_ALGO, "bulk algorithm id %d is unknown!!!", algo);
+    ab_session *s = g_turb[algo];
+    if (!s || !s->wl[0]) return fail(AB_ERR_STATE, "TURB_%s has not been called with its warm layer on: no state", ab_algo_name(algo));
+    if (n != s->n) return fail(AB_ERR_ARG, "ab_turb_get_wl_state: %ld cells asked for, the TURB_%s session holds %ld", n, ab_algo_name(algo), (long)s->n);
+    ab::DeviceGuard dguard_;
+    AB_HIP(hipSetDevice(s->device));
+    AB_HIP(hipDeviceSynchronize());
+    double *dst[4] = {dT_wl, Hz_wl, Qnt_ac, Tau_ac};
+    for (int p = 0; p < 4; ++p) {
+        if (!dst[p]) continue;
+        if (!s->wl[p]) { for (long k = 0; k < n; ++k) dst[p][k] = 0.; continue; }
+        AB_HIP(hipMemcpy(dst[p], s->wl[p], (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return AB_OK;
 }
 
 int ab_turb_neutral_10m(int algo, int nb_iter, const void *U_N10, void *CdN10, void *ChN10, void *CeN10, void *z0, long n,

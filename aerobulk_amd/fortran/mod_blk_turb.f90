@@ -18,7 +18,7 @@ MODULE mod_ab_turb
    USE mod_const, ONLY: wp, nb_iter
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: ab_turb_generic, ab_fn_arrays, ab_fn_scalar, ab_fn_pointers
+   PUBLIC :: ab_turb_generic, ab_fn_arrays, ab_fn_scalar, ab_fn_pointers, ab_wl_fetch
 
    !! mirror of `ab_diag` (include/aerobulk_amd.h)
    TYPE, BIND(C) :: ab_diag
@@ -46,6 +46,13 @@ MODULE mod_ab_turb
          REAL(C_DOUBLE), DIMENSION(2), INTENT(out) :: info
          INTEGER(C_INT) :: istat
       END FUNCTION ab_phymbl
+      FUNCTION ab_turb_get_wl_state( algo, dT_wl, Hz_wl, Qnt_ac, Tau_ac, n ) BIND(C, NAME='ab_turb_get_wl_state') RESULT(istat)
+         IMPORT :: C_INT, C_LONG, C_PTR
+         INTEGER(C_INT),  VALUE :: algo
+         TYPE(C_PTR),     VALUE :: dT_wl, Hz_wl, Qnt_ac, Tau_ac
+         INTEGER(C_LONG), VALUE :: n
+         INTEGER(C_INT) :: istat
+      END FUNCTION ab_turb_get_wl_state
       FUNCTION ab_last_error() BIND(C, NAME='ab_last_error') RESULT(cptr)
          IMPORT :: C_PTR
          TYPE(C_PTR) :: cptr
@@ -76,18 +83,30 @@ CONTAINS
       IF( istat /= 0 ) CALL stop_with_library_message()
    END SUBROUTINE ab_fn_arrays
 
-   SUBROUTINE ab_fn_pointers( fn, n, pin, pout, par1, par2 )
-      !! any helper function on arrays handed over as C pointers (FIRST_GUESS_COARE: six in, seven out)
+   SUBROUTINE ab_fn_pointers( fn, n, pin, pout, par1, par2, iflag )
+      !! any helper function on arrays handed over as C pointers (FIRST_GUESS_COARE: six in, seven out; the skin schemes)
       INTEGER, INTENT(in) :: fn, n
       TYPE(C_PTR), DIMENSION(:), INTENT(in) :: pin, pout
       REAL(wp), INTENT(in) :: par1, par2
+      INTEGER,  INTENT(in), OPTIONAL :: iflag
       REAL(C_DOUBLE), DIMENSION(2) :: par, zinfo
-      INTEGER(C_INT) :: istat
+      INTEGER(C_INT) :: istat, kflag
       par = (/ REAL(par1,C_DOUBLE), REAL(par2,C_DOUBLE) /)
-      istat = ab_phymbl( INT(fn,C_INT), INT(n,C_LONG), pin, INT(SIZE(pin),C_INT), pout, INT(SIZE(pout),C_INT), par, 0_C_INT, 0_C_INT, &
+      kflag = 0_C_INT
+      IF( PRESENT(iflag) ) kflag = INT(iflag,C_INT)
+      istat = ab_phymbl( INT(fn,C_INT), INT(n,C_LONG), pin, INT(SIZE(pin),C_INT), pout, INT(SIZE(pout),C_INT), par, kflag, 0_C_INT, &
          &               C_NULL_PTR, zinfo )
       IF( istat /= 0 ) CALL stop_with_library_message()
    END SUBROUTINE ab_fn_pointers
+
+   SUBROUTINE ab_wl_fetch( ialgo, n, p1, p2, p3, p4 )
+      !! the warm-layer state TURB_<algo> left in the engine's session -> the caller's (module) arrays; unassociated pointers are skipped
+      INTEGER, INTENT(in) :: ialgo, n
+      TYPE(C_PTR), INTENT(in) :: p1, p2, p3, p4
+      INTEGER(C_INT) :: istat
+      istat = ab_turb_get_wl_state( INT(ialgo,C_INT), p1, p2, p3, p4, INT(n,C_LONG) )
+      IF( istat /= 0 ) CALL stop_with_library_message()
+   END SUBROUTINE ab_wl_fetch
 
    FUNCTION ab_fn_scalar( fn, x1, x2 )
       !! the scalar specifics: a one-cell array through the same kernel (the engine has no host arithmetic)
@@ -192,6 +211,125 @@ CONTAINS
 END MODULE mod_ab_turb
 
 
+MODULE mod_skin_coare
+   !! reference: src/mod_skin_coare.f90 — CS_COARE (:48-93) and WL_COARE (:97-250) standing alone, and the warm layer's state as PUBLIC module
+   !! arrays (:31-36).  Each call is ONE cell through the engine's own device functions (helper functions 57 / 59 of `ab_phymbl`,
+   !! include/aerobulk_amd.h): the arithmetic TURB_COARE3P0 / 3P6 iterate with.  The module arrays are a MIRROR of the state the engine keeps in
+   !! HBM: TURB_COARE3P0 / TURB_COARE3P6 copy it here after every call with l_use_wl (callers such as
+   !! src/tests/test_aerobulk_buoy_series_oce.f90:16,463-464 read Qnt_ac / Tau_ac between calls); WL_COARE updates the mirror like the
+   !! reference updates its arrays.  What a caller writes into them is NOT carried back into the next TURB_* call (the engine's state lives
+   !! on the device); and the arrays stay allocated after kt = nitend, where the reference frees them (mod_blk_coare3p6.f90:110).
+   USE, INTRINSIC :: ISO_C_BINDING
+   USE mod_const, ONLY: wp
+   USE mod_ab_turb
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: CS_COARE, WL_COARE, ab_mirror_wl_coare
+   REAL(wp), ALLOCATABLE, SAVE, DIMENSION(:,:), PUBLIC, TARGET :: dT_wl, Hz_wl, Qnt_ac, Tau_ac
+   REAL(wp), PARAMETER, PUBLIC :: Hwl_max = 20._wp    !: maximum depth of warm layer (mod_skin_coare.f90:38)
+CONTAINS
+   SUBROUTINE CS_COARE( pQsw, pQnsol, pustar, pSST, pQlat, pdT_cs )
+      REAL(wp), INTENT(in)  :: pQsw, pQnsol, pustar, pSST, pQlat
+      REAL(wp), INTENT(out) :: pdT_cs
+      REAL(wp), DIMENSION(1), TARGET :: a1, a2, a3, a4, a5, o1
+      a1(1) = pQsw ; a2(1) = pQnsol ; a3(1) = pustar ; a4(1) = pSST ; a5(1) = pQlat
+      CALL ab_fn_pointers( 57, 1, (/ C_LOC(a1), C_LOC(a2), C_LOC(a3), C_LOC(a4), C_LOC(a5) /), (/ C_LOC(o1) /), 0._wp, 0._wp )
+      pdT_cs = o1(1)
+   END SUBROUTINE CS_COARE
+
+   SUBROUTINE WL_COARE( ki, kj, pQsw, pQnsol, pTau, pSST, plon, isd, iwait )
+      INTEGER , INTENT(in) :: ki, kj
+      REAL(wp), INTENT(in) :: pQsw, pQnsol, pTau, pSST, plon
+      INTEGER , INTENT(in) :: isd, iwait
+      REAL(wp), DIMENSION(1), TARGET :: a1, a2, a3, a4, a5, s1, s2, s3, s4
+      IF( .NOT. ALLOCATED(dT_wl) ) THEN
+         WRITE(6,*) ' *** E R R O R :  [WL_COARE] => dT_wl, Hz_wl, Qnt_ac & Tau_ac are not allocated (the reference allocates them in COARE3P6_INIT)'
+         STOP
+      END IF
+      a1(1) = pQsw ; a2(1) = pQnsol ; a3(1) = pTau ; a4(1) = pSST ; a5(1) = plon
+      s1(1) = dT_wl(ki,kj) ; s2(1) = Hz_wl(ki,kj) ; s3(1) = Qnt_ac(ki,kj) ; s4(1) = Tau_ac(ki,kj)
+      CALL ab_fn_pointers( 59, 1, (/ C_LOC(a1), C_LOC(a2), C_LOC(a3), C_LOC(a4), C_LOC(a5), C_LOC(s1), C_LOC(s2), C_LOC(s3), C_LOC(s4) /), &
+         &                 (/ C_LOC(s1), C_LOC(s2), C_LOC(s3), C_LOC(s4) /), REAL(isd,wp), 0._wp, iflag=iwait )
+      IF( iwait == 0 ) THEN           ! mod_skin_coare.f90:239-248
+         dT_wl(ki,kj) = s1(1) ; Hz_wl(ki,kj) = s2(1) ; Qnt_ac(ki,kj) = s3(1) ; Tau_ac(ki,kj) = s4(1)
+      END IF
+   END SUBROUTINE WL_COARE
+
+   SUBROUTINE ab_mirror_wl_coare( ialgo, nx, ny )
+      !! (not part of the reference's interface) called by TURB_COARE3P0 / 3P6 after a call with the warm layer on
+      INTEGER, INTENT(in) :: ialgo, nx, ny
+      IF( ALLOCATED(dT_wl) ) THEN
+         IF( SIZE(dT_wl,1) /= nx .OR. SIZE(dT_wl,2) /= ny ) DEALLOCATE( dT_wl, Hz_wl, Qnt_ac, Tau_ac )
+      END IF
+      IF( .NOT. ALLOCATED(dT_wl) ) ALLOCATE( dT_wl(nx,ny), Hz_wl(nx,ny), Qnt_ac(nx,ny), Tau_ac(nx,ny) )
+      CALL ab_wl_fetch( ialgo, nx*ny, C_LOC(dT_wl), C_LOC(Hz_wl), C_LOC(Qnt_ac), C_LOC(Tau_ac) )
+   END SUBROUTINE ab_mirror_wl_coare
+END MODULE mod_skin_coare
+
+
+MODULE mod_skin_ecmwf
+   !! reference: src/mod_skin_ecmwf.f90 — CS_ECMWF (:68-110), WL_ECMWF (:113-230) and the warm layer's PUBLIC module arrays (:52-55), on the same
+   !! terms as mod_skin_coare above (helper functions 58 / 60; mirror filled by TURB_ECMWF and by ECMWF_INIT's initial values)
+   USE, INTRINSIC :: ISO_C_BINDING
+   USE mod_const, ONLY: wp
+   USE mod_ab_turb
+   IMPLICIT NONE
+   PRIVATE
+   PUBLIC :: CS_ECMWF, WL_ECMWF, ab_mirror_wl_ecmwf, ab_alloc_wl_ecmwf
+   REAL(wp), ALLOCATABLE, SAVE, DIMENSION(:,:), PUBLIC, TARGET :: dT_wl, Hz_wl
+   REAL(wp), PARAMETER, PUBLIC :: rd0 = 3.            !: depth scale [m] of the warm layer (mod_skin_ecmwf.f90:57)
+CONTAINS
+   SUBROUTINE CS_ECMWF( pQsw, pQnsol, pustar, pSST, pdT_cs )
+      REAL(wp), INTENT(in)  :: pQsw, pQnsol, pustar, pSST
+      REAL(wp), INTENT(out) :: pdT_cs
+      REAL(wp), DIMENSION(1), TARGET :: a1, a2, a3, a4, o1
+      a1(1) = pQsw ; a2(1) = pQnsol ; a3(1) = pustar ; a4(1) = pSST
+      CALL ab_fn_pointers( 58, 1, (/ C_LOC(a1), C_LOC(a2), C_LOC(a3), C_LOC(a4) /), (/ C_LOC(o1) /), 0._wp, 0._wp )
+      pdT_cs = o1(1)
+   END SUBROUTINE CS_ECMWF
+
+   SUBROUTINE WL_ECMWF( ki, kj, pQsw, pQnsol, pustar, pSST,  pustk )
+      INTEGER , INTENT(in) :: ki, kj
+      REAL(wp), INTENT(in) :: pQsw, pQnsol, pustar, pSST
+      REAL(wp), OPTIONAL, INTENT(in) :: pustk
+      REAL(wp), DIMENSION(1), TARGET :: a1, a2, a3, a4, a7, s1, s2
+      TYPE(C_PTR) :: c7
+      IF( .NOT. ALLOCATED(dT_wl) ) THEN
+         WRITE(6,*) ' *** E R R O R :  [WL_ECMWF] => dT_wl & Hz_wl are not allocated (the reference allocates them in ECMWF_INIT)'
+         STOP
+      END IF
+      a1(1) = pQsw ; a2(1) = pQnsol ; a3(1) = pustar ; a4(1) = pSST
+      s1(1) = dT_wl(ki,kj) ; s2(1) = Hz_wl(ki,kj)
+      c7 = C_NULL_PTR
+      IF( PRESENT(pustk) ) THEN
+         a7(1) = pustk ; c7 = C_LOC(a7)
+      END IF
+      CALL ab_fn_pointers( 60, 1, (/ C_LOC(a1), C_LOC(a2), C_LOC(a3), C_LOC(a4), C_LOC(s1), C_LOC(s2), c7 /), (/ C_LOC(s1) /), 0._wp, 0._wp )
+      dT_wl(ki,kj) = s1(1)             ! every call: mod_skin_ecmwf.f90:228
+   END SUBROUTINE WL_ECMWF
+
+   SUBROUTINE ab_alloc_wl_ecmwf( nx, ny )
+      !! (not part of the reference's interface) ECMWF_INIT's allocation and initial values, mod_blk_ecmwf.f90:401-404
+      INTEGER, INTENT(in) :: nx, ny
+      IF( ALLOCATED(dT_wl) ) THEN
+         IF( SIZE(dT_wl,1) /= nx .OR. SIZE(dT_wl,2) /= ny ) DEALLOCATE( dT_wl, Hz_wl )
+      END IF
+      IF( .NOT. ALLOCATED(dT_wl) ) THEN
+         ALLOCATE( dT_wl(nx,ny), Hz_wl(nx,ny) )
+         dT_wl(:,:) = 0._wp
+         Hz_wl(:,:) = rd0
+      END IF
+   END SUBROUTINE ab_alloc_wl_ecmwf
+
+   SUBROUTINE ab_mirror_wl_ecmwf( nx, ny )
+      !! (not part of the reference's interface) called by TURB_ECMWF after a call with the warm layer on
+      INTEGER, INTENT(in) :: nx, ny
+      CALL ab_alloc_wl_ecmwf( nx, ny )
+      CALL ab_wl_fetch( 4, nx*ny, C_LOC(dT_wl), C_LOC(Hz_wl), C_NULL_PTR, C_NULL_PTR )
+   END SUBROUTINE ab_mirror_wl_ecmwf
+END MODULE mod_skin_ecmwf
+
+
 MODULE mod_common_coare
    !! the three public names of the reference's src/mod_common_coare.f90: FIRST_GUESS_COARE :33-214 (the first block of the engine's TURB_COARE* /
    !! TURB_ECMWF kernels, here as helper function 56 of `ab_phymbl`), psi_m_coare / psi_h_coare :217-392 (src/tests/test_psi_stab.f90:26)
@@ -275,6 +413,7 @@ END MODULE mod_common_coare
 MODULE mod_blk_coare3p6
    USE mod_const, ONLY: wp
    USE mod_ab_turb
+   USE mod_skin_coare, ONLY: ab_mirror_wl_coare
    IMPLICIT NONE
    PRIVATE
    PUBLIC :: TURB_COARE3P6, charn_coare3p6
@@ -316,6 +455,7 @@ CONTAINS
       END IF
       CALL ab_turb_generic( 2, kt, zt, zu, T_s, t_zt, q_s, q_zt, U_zu, l_use_cs, l_use_wl, Cd, Ch, Ce, t_zu, q_zu, Ubzu, &
          &                  Qsw, rad_lw, slp, pdT_cs, isecday_utc, plong, pdT_wl, pHz_wl, CdN, ChN, CeN, xz0, xu_star, xL, xUN10 )
+      IF( l_use_wl ) CALL ab_mirror_wl_coare( 2, SIZE(T_s,1), SIZE(T_s,2) )     ! mod_skin_coare's PUBLIC state arrays
    END SUBROUTINE TURB_COARE3P6
 END MODULE mod_blk_coare3p6
 
@@ -323,6 +463,7 @@ END MODULE mod_blk_coare3p6
 MODULE mod_blk_coare3p0
    USE mod_const, ONLY: wp
    USE mod_ab_turb
+   USE mod_skin_coare, ONLY: ab_mirror_wl_coare
    IMPLICIT NONE
    PRIVATE
    PUBLIC :: TURB_COARE3P0, charn_coare3p0
@@ -357,6 +498,7 @@ CONTAINS
       END IF
       CALL ab_turb_generic( 1, kt, zt, zu, pT_s, pt_zt, pq_s, pq_zt, pU_zu, l_use_cs, l_use_wl, pCd, pCh, pCe, pt_zu, pq_zu, pUbzu, &
          &                  pQsw, prad_lw, pslp, pdT_cs, isecday_utc, plong, pdT_wl, pHz_wl, pCdN, pChN, pCeN, pz0, pu_star, pL, pUN10 )
+      IF( l_use_wl ) CALL ab_mirror_wl_coare( 1, SIZE(pT_s,1), SIZE(pT_s,2) )   ! mod_skin_coare's PUBLIC state arrays
    END SUBROUTINE TURB_COARE3P0
 END MODULE mod_blk_coare3p0
 
@@ -364,6 +506,7 @@ END MODULE mod_blk_coare3p0
 MODULE mod_blk_ecmwf
    USE mod_const, ONLY: wp
    USE mod_ab_turb
+   USE mod_skin_ecmwf, ONLY: ab_mirror_wl_ecmwf, ab_alloc_wl_ecmwf
    IMPLICIT NONE
    PRIVATE
    PUBLIC :: ECMWF_INIT, TURB_ECMWF, psi_m_ecmwf, psi_h_ecmwf
@@ -376,11 +519,11 @@ MODULE mod_blk_ecmwf
 CONTAINS
    SUBROUTINE ECMWF_INIT( nx, ny, l_use_wl )                                   !! reference mod_blk_ecmwf.f90:387-411
       !! The reference allocates the warm layer's module arrays here.  The engine keeps that state in its session, created by the first
-      !! TURB_ECMWF call (kt = 1): nothing to do, the routine exists so that callers of the reference's interface compile and run.
+      !! TURB_ECMWF call (kt = 1); the module arrays of mod_skin_ecmwf are a mirror of it (see there) and get their initial values here.
       INTEGER, INTENT(in) :: nx, ny
       LOGICAL, INTENT(in) :: l_use_wl
       IF( nx < 1 .OR. ny < 1 ) STOP 'ECMWF_INIT: bad shape'
-      IF( l_use_wl ) CONTINUE
+      IF( l_use_wl ) CALL ab_alloc_wl_ecmwf( nx, ny )       ! mod_skin_ecmwf's PUBLIC arrays with their initial values (0, rd0)
    END SUBROUTINE ECMWF_INIT
    FUNCTION psi_m_ecmwf_vct( pzeta )                                          !! reference mod_blk_ecmwf.f90:441-495
       REAL(wp), DIMENSION(:,:), INTENT(in) :: pzeta
@@ -420,6 +563,7 @@ CONTAINS
       CALL ab_turb_generic( 4, kt, zt, zu, pT_s, pt_zt, pq_s, pq_zt, pU_zu, l_use_cs, l_use_wl, pCd, pCh, pCe, pt_zu, pq_zu, pUbzu, &
          &                  Qsw=pQsw, rad_lw=prad_lw, slp=pslp, pdT_cs=pdT_cs, pdT_wl=pdT_wl, pHz_wl=pHz_wl,                          &
          &                  CdN=pCdN, ChN=pChN, CeN=pCeN, xz0=pz0, xu_star=pu_star, xL=pL, xUN10=pUN10 )
+      IF( l_use_wl ) CALL ab_mirror_wl_ecmwf( SIZE(pT_s,1), SIZE(pT_s,2) )      ! mod_skin_ecmwf's PUBLIC state arrays
    END SUBROUTINE TURB_ECMWF
 END MODULE mod_blk_ecmwf
 

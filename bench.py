@@ -127,6 +127,59 @@ def balanced_peer_rows(nj, world, t_cell, bytes_per_cell_on_link, link_bytes_per
     return max(1, min(int(round(f * nj)), max(nj // world, 1)))
 
 
+# top level of every JSON line, beside roofline.bound = "hbm" (the contract's vocabulary is hbm | mfma; BASELINE.json asks for the HBM fraction):
+# no reader should take a 90 %-VALU-busy kernel for a memory-bound one
+LIMITER_NOTE = ("valu_fp64: the flux kernels are bound by fp64 vector-ALU issue (hundreds of transcendentals per cell, ~90 % VALU busy in "
+                "rocprofv3), NOT by HBM and not by MFMA (pointwise, no contraction); roofline.frac is the HBM fraction BASELINE.json asks for, "
+                "roofline.fp64_frac / valu_issue_frac the binding resource")
+CALIB_REF_TFLOPS = 78.6      # what ab_calibrate's fp64 FMA chains deliver at the guide's 2.4 GHz: value_norm is `value` at that clock
+
+
+def read_sclk_mhz(dev_index):
+    """Shader clock the driver reports for the device right now (sysfs pp_dpm_sclk, the level marked '*'), or None.  Read without
+    starting a process; informational — the calibration kernel's own rate is the figure that is compared."""
+    import glob
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        path = cards[dev_index] if dev_index < len(cards) else cards[0]
+        with open(path) as fh:
+            for ln in fh:
+                if "*" in ln:
+                    return int("".join(c for c in ln.split(":")[1] if c.isdigit()))
+    except Exception:
+        pass
+    return None
+
+
+def calibrate_box(ab, dev_index, launches):
+    """The box, not the kernel: `launches` runs of ab_calibrate's fixed fp64 FMA workload (about 5 ms each; the first ones also
+    raise the clocks), median of the last five.  Called before the pre-roll and again after the timed region."""
+    try:
+        tf = [ab.calibrate("fma_f64", dev_index)[1] for _ in range(launches)]
+        tail = sorted(tf[-5:])
+        return {"fma_f64_tflops": round(tail[len(tail) // 2], 3), "sclk_mhz": read_sclk_mhz(dev_index)}
+    except Exception as e:          # a report, never a reason to lose the run
+        return {"fma_f64_tflops": None, "error": str(e)}
+
+
+def calib_record(before, after, value):
+    """`calib` of the JSON line + value_norm = value x (CALIB_REF_TFLOPS / the box's measured fp64 FMA rate): what the same kernel
+    would have delivered on a box running at the guide's clock.  Compare ROUNDS by value_norm, boxes by calib (README.md)."""
+    rates = [c["fma_f64_tflops"] for c in (before, after) if c and c.get("fma_f64_tflops")]
+    rec = {"fma_f64_tflops_before": before.get("fma_f64_tflops") if before else None,
+           "fma_f64_tflops_after": after.get("fma_f64_tflops") if after else None,
+           "sclk_mhz": (after or {}).get("sclk_mhz") or (before or {}).get("sclk_mhz"),
+           "reference_tflops": CALIB_REF_TFLOPS,
+           "workload": "ab_calibrate(AB_CALIB_FMA_F64): chains of v_fma_f64, 4 waves per SIMD, ~5 ms, HIP events; median of 5 launches "
+                       "before the pre-roll (after 15 ramp launches) and after the timed region"}
+    norm = None
+    if rates:
+        mean = sum(rates) / len(rates)
+        rec["effective_sclk_mhz"] = round(mean / CALIB_REF_TFLOPS * 2400.0, 1)
+        norm = round(value * CALIB_REF_TFLOPS / mean, 2)
+    return rec, norm
+
+
 def cpu_baseline_config1(niter, zt, zu):
     """BASELINE config 1 on the CPU, as the reference runs it: NCAR, 360x180, one aerobulk_model(jt=1,Nt=1) call incl.
     AEROBULK_INIT, the unmodified reference (oracle/_ref) in one process; the C port if _ref did not travel."""
@@ -382,12 +435,14 @@ def main_inprocess(a):
         sync()
         return time.perf_counter() - t0
 
+    calib_before = calibrate_box(ab, devs[root], 20)
     for _ in range(max(4, 40 // npass) if ni * nj <= 4320 * 3600 else 4):     # clock ramp, as the other path
         step()
     sync()
     for _ in range(a.warmup):
         step()
     elapsed = timed(a.steps, True)
+    calib_after = calibrate_box(ab, devs[root], 5)
     elapsed_resident = timed(a.steps, False)
     for s_ in sessions:
         s_.check()
@@ -450,6 +505,8 @@ def main_inprocess(a):
                      "kernel_ms": round(kms[slow], 4), "bytes_per_cell": bpc, "cells_per_launch": n_slow,
                      "note": "the slowest shard's launch of the first pass; per device, not summed over devices"},
     }
+    res["limiter"] = LIMITER_NOTE
+    res["calib"], res["value_norm"] = calib_record(calib_before, calib_after, res["value"])
     if verify_msg:
         res["verify"] = verify_msg
     if tune:
@@ -741,6 +798,7 @@ def main():
 
     # pre-roll, part of the setup: the GPU raises its clocks during the first ~100 ms of sustained work (the first
     # configuration measured after start-up runs 5-8 % slow otherwise, profiles/r1_notes.md); then the W warm-up steps
+    calib_before = calibrate_box(ab, dev_index, 20) if rank == 0 else None     # the box, before anything of the flux path runs
     for _ in range(max(4, 40 // npass) if ni * nj <= 4320 * 3600 else 4):          # the same count on every rank (step() contains the gather)
         step()
     sync()
@@ -749,6 +807,7 @@ def main():
     sync()
     # timed region: EXACTLY K steps, no host sync inside
     elapsed = timed(a.steps, True, not a.no_pipeline_gather)
+    calib_after = calibrate_box(ab, dev_index, 5) if rank == 0 else None
     verify_globs, verify_niter = None, niter
     if a.verify and gathered:                 # what the last step gathered, before the other timed runs reuse the buffers
         verify_niter = niter + ((nstep[0] - 1) % 2)
@@ -808,8 +867,8 @@ def main():
                     kms[p] += sess.last_kernel_ms() / nrep
     k_ms = kms[0]
 
-    # BASELINE config 3 is quoted at nb_iter = 5; the reference's default is nb_iter0 = 8 (mod_const.f90:25): the same K steps at 8, reported
-    # beside the headline (never as `value`)
+    # BASELINE config 3 is quoted at nb_iter = 5 (the reference's default, mod_const.f90:33); its sea-ice series driver and BASELINE config 2 use 8
+    # (src/ice/test_aerobulk_cdnf_series.f90:72): the same K steps at 8, reported beside the headline (never as `value`)
     alt8 = None
     if world == 1 and a.config == 3 and a.niter is None and not gathered and not a.no_nb_iter_8 and (head_algo, head_skin, ni, nj) == ("coare3p6", True, 4320, 3600):
         def step8():
@@ -830,7 +889,7 @@ def main():
             step8()
             k8 += work[0][0][0].last_kernel_ms() / nrep
         alt8 = {"nb_iter": 8, "value": round(npass * ni * nj * a.steps / el8 / 1e6, 2), "unit": "Mcell/s", "ms_per_step": round(el8 / a.steps * 1e3, 4),
-                "kernel_ms": round(k8, 4), "note": "the same K steps with nb_iter = 8 (the reference's default nb_iter0); `value` above is BASELINE's nb_iter = 5"}
+                "kernel_ms": round(k8, 4), "note": "the same K steps with nb_iter = 8 (as BASELINE config 2 and the reference's sea-ice series driver use); `value` above is BASELINE's nb_iter = 5, the reference's default"}
 
     verify_msg = None
     if a.verify and gathered and rank == 0:
@@ -896,6 +955,8 @@ def main():
                          "valu_issue_frac": prof["valu_issue_frac"] if prof else None,
                          "profile": prof if prof else ({"stale": "committed profile was taken with other device code: not quoted"} if pmc else None)},
         }
+        res["limiter"] = LIMITER_NOTE
+        res["calib"], res["value_norm"] = calib_record(calib_before, calib_after, value)
         if alt8:
             res["nb_iter_8"] = alt8
         if npass > 1:

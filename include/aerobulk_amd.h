@@ -53,7 +53,8 @@ enum ab_status {
     AB_ERR_TAU = 8,         /* wind stress > 10 N/m^2, mod_phymbl.f90:1250-1253 */
     AB_ERR_HIP = 9,         /* HIP runtime failure / no gfx950 device */
     AB_ERR_ARG = 10,        /* NULL pointer, size mismatch (mod_aerobulk.f90:87-95), bad enum */
-    AB_ERR_STATE = 11       /* call protocol violated (e.g. jt>1 before jt==1, mod_aerobulk.f90:246-267) */
+    AB_ERR_STATE = 11,      /* call protocol violated (e.g. jt>1 before jt==1, mod_aerobulk.f90:246-267) */
+    AB_ERR_NOCONV = 12      /* e_air's whole-array fixed point (mod_phymbl.f90:1706-1736) not converged after 200 sweeps: the reference loops for ever */
 };
 
 typedef struct ab_session ab_session; /* opaque; owns WL state + staging buffers on one GPU */
@@ -99,8 +100,9 @@ int ab_session_destroy(ab_session *s);
 int ab_session_create_sharded(ab_session **out, int algo, long ni, long nj, int nt, int use_skin,
                               int precision, const int *devices, int nshards);
 /* The same with the caller's row counts: shard r owns nj_per_shard[r] >= 1 rows (their sum must be nj), in order.  For layouts in
- * which the shards are not peers: the GPU that also receives the gathered fluxes of the others (ab_session_gather's root) is given
- * fewer rows, so that its kernel + its receives take as long as the others' kernels + their sends (bench.py: root_share). */
+ * which the shards are not peers: the rows of the GPU that receives the gathered fluxes of the others (ab_session_gather's root) never
+ * cross a link, so it is given MORE rows than its peers — until its kernel takes as long as a peer's kernel + that peer's transfer
+ * (bench.py: balanced_peer_rows). */
 int ab_session_create_sharded_rows(ab_session **out, int algo, long ni, long nj, int nt, int use_skin,
                                    int precision, const int *devices, int nshards, const long *nj_per_shard);
 int ab_session_shard_count(const ab_session *s);    /* 1 for an ordinary session */
@@ -251,6 +253,12 @@ int ab_turb(int algo, int kt, double zt, double zu, int use_cs, int use_wl, int 
             double *Cd, double *Ch, double *Ce, double *t_zu, double *q_zu, double *Ubzu,
             const ab_diag *opt, long ni, long nj);
 
+/* Warm-layer state of the process-global TURB_<algo> session after the latest ab_turb() call, copied plane by plane into host arrays of
+ * n = ni*nj doubles (a NULL plane is skipped; planes the scheme does not keep — Qnt_ac / Tau_ac for ECMWF — come back 0).  The reference
+ * holds these as PUBLIC module arrays (mod_skin_coare.f90:31-36, mod_skin_ecmwf.f90:52-55) which callers read after TURB_*
+ * (src/tests/test_aerobulk_buoy_series_oce.f90:16,463-464); aerobulk_amd/fortran/mod_blk_turb.f90 mirrors them with this call. */
+int ab_turb_get_wl_state(int algo, double *dT_wl, double *Hz_wl, double *Qnt_ac, double *Tau_ac, long n);
+
 /* TURB_NEUTRAL_10M( calgo, U_N10, CdN10, ChN10, CeN10, pz0 ) (mod_blk_neutral_10m.f90:33): neutral 10 m transfer coefficients
  * and roughness length from the neutral 10 m wind.  algo = AB_ALGO_COARE3P0 | COARE3P6 | ECMWF | NCAR (the reference STOPs for
  * andreas: AB_ERR_ALGO).  Stateless; n cells of `precision` in `mem`. */
@@ -297,6 +305,9 @@ int ab_turb_ice_easy(double zt, double zu, int nb_iter, double CdN, double ChN, 
  *   info          may be NULL; AB_PH_BULK_FORMULA: info[0] = index of the first cell whose wind stress exceeds 10 N/m^2 (-1: none),
  *                 info[1] = that stress; the call then returns AB_ERR_TAU with every output written (BULK_FORMULA_VCTR's STOP,
  *                 mod_phymbl.f90:1250-1253)
+ * n == 0 is a no-op returning AB_OK (zero-size Fortran arrays).  AB_MEM_DEVICE work runs on the device that owns the first input array.
+ * AB_PH_E_AIR / RHO_AIR_ADV / RH_AIR: AB_ERR_NOCONV if e_air's whole-array fixed point has not converged after 200 sweeps (the
+ * reference would not return); the outputs then hold the last iterate.
  * fn (arrays in ; scalar ; arrays out), reference lines in mod_phymbl.f90: */
 enum ab_phymbl_fn {
     AB_PH_POT_TEMP = 1,             /* pTa, pPz, [pPref] ; pPref ; theta                     :163-200 */
@@ -357,8 +368,14 @@ enum ab_phymbl_fn {
     AB_PH_CH_N10_NCAR = 53,         /* psqrtcdn10, pstab ; - ; ChN10                         mod_blk_ncar.f90:287-310 */
     AB_PH_CE_N10_NCAR = 54,         /* psqrtcdn10 ; - ; CeN10                                mod_blk_ncar.f90:313-330 */
     AB_PH_U_STAR_ANDREAS = 55,      /* pun10 ; - ; u*                                        mod_blk_andreas.f90:275-305 */
-    AB_PH_FIRST_GUESS_COARE = 56    /* psst, t_zt, pssq, q_zt, U_zu, pcharn ; zt, zu (par[0], par[1]) ; pus, pts, pqs, t_zu, q_zu, Ubzu, pz0
+    AB_PH_FIRST_GUESS_COARE = 56,   /* psst, t_zt, pssq, q_zt, U_zu, pcharn ; zt, zu (par[0], par[1]) ; pus, pts, pqs, t_zu, q_zu, Ubzu, pz0
                                                                                               mod_common_coare.f90:33-214 */
+    /* the skin schemes as mod_skin_coare / mod_skin_ecmwf export them: one call of the scheme per cell, on the caller's state arrays */
+    AB_PH_CS_COARE = 57,            /* pQsw, pQnsol, pustar, pSST, pQlat ; - ; pdT_cs                mod_skin_coare.f90:48-93 */
+    AB_PH_CS_ECMWF = 58,            /* pQsw, pQnsol, pustar, pSST ; - ; pdT_cs                       mod_skin_ecmwf.f90:68-110 */
+    AB_PH_WL_COARE = 59,            /* pQsw, pQnsol, pTau, pSST, plon, dT_wl, Hz_wl, Qnt_ac, Tau_ac ; isd (par[0]), iwait (flag) ;
+                                       dT_wl, Hz_wl, Qnt_ac, Tau_ac after the call (unchanged if iwait /= 0)   mod_skin_coare.f90:97-250 */
+    AB_PH_WL_ECMWF = 60             /* pQsw, pQnsol, pustar, pSST, dT_wl, Hz_wl, [pustk] ; - ; dT_wl after the call  mod_skin_ecmwf.f90:113-230 */
 };
 int ab_phymbl(int fn, long n, const double *const *in, int n_in, double *const *out, int n_out, const double *par, int flag,
               int mem, void *stream, double *info);
@@ -377,6 +394,14 @@ double ab_session_last_kernel_ms(ab_session *s);
 int ab_synth_fields_device(void *sst, void *t_zt, void *q_zt, void *u_zu, void *v_zu, void *slp,
                            void *rad_sw, void *rad_lw, long ni, long j0, long nj_local, int precision,
                            void *stream);
+
+/* Box calibration for benchmarks (bench.py `calib`; aerobulk_amd/csrc/ab_calib.hip): a fixed device workload that depends on the
+ * box alone, timed with HIP events on `stream` of `device` after one untimed launch.  AB_CALIB_FMA_F64: chains of v_fma_f64 on every
+ * lane, four waves per SIMD -> *rate = fp64 TFLOP/s (78.6 at 2.4 GHz: the resource that binds the flux kernels);
+ * AB_CALIB_HBM_COPY: dst = src over 1 GiB -> *rate = GB/s read + written.  *ms = the timed launch.  No counterpart in the
+ * reference (measurement contract). */
+enum ab_calib_workload { AB_CALIB_FMA_F64 = 0, AB_CALIB_HBM_COPY = 1 };
+int ab_calibrate(int what, int device, void *stream, double *ms, double *rate);
 
 /* Test hook: apply the engine's fp64 device math function `op` elementwise to host arrays (y may be NULL):
  * 0 div 1 rcp 2 sqrt 3 log 4 log10 5 exp 6 exp10 7 atan 8 cbrt 9 rcbrt 10 e_sat 11 pow 12 x^(-1/4) 13 e_sat through the

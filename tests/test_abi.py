@@ -88,7 +88,9 @@ def test_helper_entry_argument_errors_need_no_gpu(lib):
     ARG = 10
     assert f(0, 8, pin, 2, pout, 1, par, 0, 0, None, None) == ARG and b"unknown function" in lib.ab_last_error()
     assert f(99, 8, pin, 2, pout, 1, par, 0, 0, None, None) == ARG
-    assert f(3, 0, pin, 2, pout, 1, par, 0, 0, None, None) == ARG                      # virt_temp on no cells
+    assert f(3, 0, pin, 2, pout, 1, par, 0, 0, None, None) == 0 and not y.any()        # virt_temp on no cells: a no-op, like the reference on zero-size arrays
+    assert f(3, -1, pin, 2, pout, 1, par, 0, 0, None, None) == ARG
+    assert f(3, 8, pin, 2, pout, 1, par, 0, 1, None, None) in (ARG, 9)                 # AB_MEM_DEVICE with host pointers: refused (no device: AB_ERR_HIP)
     assert f(3, 8, None, 2, pout, 1, par, 0, 0, None, None) == ARG
     assert f(3, 8, pin, 1, pout, 1, par, 0, 0, None, None) == ARG                      # virt_temp needs two arrays
     assert f(3, 8, pin, 2, pout, 1, par, 0, 7, None, None) == ARG and b"bad mem" in lib.ab_last_error()
@@ -98,6 +100,13 @@ def test_helper_entry_argument_errors_need_no_gpu(lib):
     assert f(3, 8, pin, 2, pout_none, 1, par, 0, 0, None, None) == ARG and b"no output" in lib.ab_last_error()
     if lib.ab_device_count() == 0:      # a well-formed call without a GPU: AB_ERR_HIP, the arrays untouched
         assert f(3, 8, pin, 2, pout, 1, par, 0, 0, None, None) == 9 and not y.any()
+
+
+def test_calibrate_rejects_unknown_workloads_and_needs_a_gpu(lib):
+    ms, rate = C.c_double(-1.), C.c_double(-1.)
+    assert lib.ab_calibrate(7, 0, None, C.byref(ms), C.byref(rate)) == 10
+    if lib.ab_device_count() == 0:
+        assert lib.ab_calibrate(0, 0, None, C.byref(ms), C.byref(rate)) == 9           # AB_ERR_HIP: nothing runs on the host
 
 
 def test_no_cpu_fallback(lib):

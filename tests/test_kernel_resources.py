@@ -22,7 +22,7 @@ def remarks(tmp_path_factory):
     from aerobulk_amd import build as b
     flags = getattr(b, "HIPFLAGS", None)
     if flags is None:
-        flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-gpu-rdc", "-Wno-unused-function",
+        flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast-honor-pragmas", "-fno-gpu-rdc", "-Wno-unused-function",
                  "-mllvm", "-disable-machine-licm", "-Xclang", "-target-feature", "-Xclang", "-fmacf64-inst"]
     out = tmp_path_factory.mktemp("res") / "k.o"
     pr = subprocess.run([HIPCC, *flags, "-I", os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "aerobulk_amd", "csrc", "ab_kernels.hip"),

@@ -43,11 +43,12 @@ def test_golden_holds_the_readme_table():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
-def test_unchanged_driver_prints_what_it_prints_with_the_reference(case):
+def test_unchanged_driver_prints_what_it_prints_with_the_reference(case, tmp_path):
     exe = os.path.join(ROOT, "oracle", "_ref", "dropin", case.get("exe", "aerobulk_toy") + ".x")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/dropin not built (needs the reference tree and amdflang at build time)")
-    pr = subprocess.run([exe, *case["args"]], input=case["stdin"], capture_output=True, text=True, timeout=600)
+    # (cwd: test_ice.f90 writes z0_z0t_z0q__ustar_test.dat beside itself — not into the repository)
+    pr = subprocess.run([exe, *case["args"]], input=case["stdin"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-2000:]
     got, ref = numbers(pr.stdout), numbers(case["stdout"])
     assert len(got) == len(ref) and len(ref) > (10 if case.get("exe") == "test_phymbl" else 150), (len(got), len(ref))

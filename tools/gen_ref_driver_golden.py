@@ -6,6 +6,7 @@ the same case with the skin schemes (-S) and with relative humidity (-r).  Build
 import json
 import os
 import subprocess
+import tempfile
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +26,8 @@ def main():
         exe = os.path.join(ROOT, "oracle", "_ref", f"ref_{c['exe']}.x")
         if not os.path.exists(exe):
             sys.exit("make -C oracle all first (needs /root/reference)")
-        pr = subprocess.run([exe, *c["args"]], input=c["stdin"], capture_output=True, text=True, timeout=120)
+        with tempfile.TemporaryDirectory() as tmp:      # test_ice.f90 writes a .dat file into its working directory
+            pr = subprocess.run([exe, *c["args"]], input=c["stdin"], capture_output=True, text=True, timeout=120, cwd=tmp)
         assert pr.returncode == 0, pr.stderr
         out.append(dict(c, stdout=pr.stdout))
         print(c["name"], len(pr.stdout.splitlines()), "lines")
