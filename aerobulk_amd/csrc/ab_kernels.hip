@@ -576,15 +576,21 @@ template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipErro
     // 1 280 resident slots — two full waves and a third that holds the chip for a whole life at 37 % occupancy (0.205 ms where the
     // large-grid rate gives 0.156) — or 2 398 long tiles followed by 1 280 short ones.
     long nfull = (c.n + tile - 1) / tile, nblk = nfull;
-    if (ALGO != 3 && rounds > 1) {
-        // (AEROBULK_AMD_TAIL_X: tuning knob of the probes — one-round tiles per resident slot, default 1)
-        static const double tail_x = []{ const char *e = getenv("AEROBULK_AMD_TAIL_X"); const double v = e ? atof(e) : 1.; return v >= 0. ? v : 1.; }();
-        const long tail = std::min<long>(c.n, (long)(tail_x * (double)(resident_block_slots(T::kOcc) * (long)kBlock)) / kBlock * kBlock);
-        nfull = (c.n - tail) / tile;
-        nblk = nfull + (c.n - nfull * tile + kBlock - 1) / kBlock;
-    }
-    a.nfull = nfull;
-    a.ntail = nblk - nfull;
+    // (AEROBULK_AMD_TAIL_X: tuning knob of the probes — one-round tiles per resident slot; default: 1 for the persistent kernel's pool, 0.5 for the
+    // blocks of flux_kernel — measured on 1440x1080, where the tail is a quarter of the launch: x0 / 0.5 / 1 / 1.5 / 2 / 3 = 0.1362 / 0.1340 /
+    // 0.1381 / 0.1360 / 0.1377 / 0.1399 ms, profiles/r6_notes.md; flux_kernel_cu on 4320x450: x0.5 = x1 within 0.2 %, profiles/r5_notes.md §2)
+    static const double tail_knob = []{ const char *e = getenv("AEROBULK_AMD_TAIL_X"); const double v = e ? atof(e) : -1.; return v; }();
+    auto shape = [&](double x) {
+        nfull = (c.n + tile - 1) / tile; nblk = nfull;
+        if (ALGO != 3 && rounds > 1) {
+            const long tail = std::min<long>(c.n, (long)(x * (double)(resident_block_slots(T::kOcc) * (long)kBlock)) / kBlock * kBlock);
+            nfull = (c.n - tail) / tile;
+            nblk = nfull + (c.n - nfull * tile + kBlock - 1) / kBlock;
+        }
+        a.nfull = nfull;
+        a.ntail = nblk - nfull;
+    };
+    shape(tail_knob >= 0. ? tail_knob : 1.);
     a.queue = c.flags ? c.flags + 4 : nullptr;
     if (nblk <= 0) return hipSuccess;
     // fp64 COARE with the skin schemes on a grid that fills the chip several times over: one workgroup per CU (flux_kernel_cu)
@@ -600,10 +606,14 @@ template <class R, int ALGO, bool SKIN, class S = R, class A = R> static hipErro
 #ifdef AB_QUEUE_MEMSET      // (A/B: 4.5 us per launch, profiles/r5_notes.md)
             if (hipError_t e = hipMemsetAsync(a.queue, 0, 3 * sizeof(int), stream); e != hipSuccess) return e;
 #endif
-            hipLaunchKernelGGL((flux_kernel_cu<R, ALGO, SKIN, S>), dim3((unsigned)cus), dim3(kCuBlock), 0, stream, a, dg);
+            // (AEROBULK_AMD_CU_GRID: probe knob — fewer workgroups than CUs, profiles/r6_notes.md "an integer number of tiles per team")
+            static const long grid_knob = []{ const char *e = getenv("AEROBULK_AMD_CU_GRID"); return e ? atol(e) : 0L; }();
+            const long grid = (grid_knob > 0 && grid_knob < cus) ? grid_knob : cus;
+            hipLaunchKernelGGL((flux_kernel_cu<R, ALGO, SKIN, S>), dim3((unsigned)grid), dim3(kCuBlock), 0, stream, a, dg);
             return hipGetLastError();
         }
     }
+    if (tail_knob < 0.) shape(0.5);      // the block kernel's launch shape
     if (diag) hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, true, S, A>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     else hipLaunchKernelGGL((flux_kernel<R, ALGO, SKIN, false, S, A>), dim3((unsigned)nblk), dim3(kBlock), 0, stream, a, dg);
     return hipGetLastError();

@@ -67,6 +67,7 @@ template <> struct Mth<double> {
     static __device__ __forceinline__ R rqrt(R x) { return fm::qrqrt_mid(x); }    // x^(-1/4), 2^-100 < x < 2^100
     static __device__ __forceinline__ R div(R a, R b) { return fm::qdiv(a, b); }
     static __device__ __forceinline__ R rcp(R b) { return fm::qrcp(b); }
+    static __device__ __forceinline__ R fma(R a, R b, R c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ R abs(R x) { return __builtin_fabs(x); }
     static __device__ __forceinline__ R floor(R x) { return __builtin_floor(x); }
     static __device__ __forceinline__ R copysign(R a, R b) { return __builtin_copysign(a, b); }
@@ -84,6 +85,7 @@ template <> struct Mth<float> {
     static __device__ __forceinline__ R exp10(R x) { return exp2(x * 3.321928094887362f); }
     static __device__ __forceinline__ R rcp(R b) { return fm::f_rcp(b); }
     static __device__ __forceinline__ R div(R a, R b) { return a * fm::f_rcp(b); }
+    static __device__ __forceinline__ R fma(R a, R b, R c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ R sqrt(R x) { return fm::f_sqrt(x); }
     static __device__ __forceinline__ R sqrt_pos(R x) { return fm::f_sqrt(x); }
     static __device__ __forceinline__ R rsqrt_pos(R x) { return fm::f_rsq(x); }

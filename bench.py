@@ -132,7 +132,10 @@ def balanced_peer_rows(nj, world, t_cell, bytes_per_cell_on_link, link_bytes_per
 LIMITER_NOTE = ("valu_fp64: the flux kernels are bound by fp64 vector-ALU issue (hundreds of transcendentals per cell, ~90 % VALU busy in "
                 "rocprofv3), NOT by HBM and not by MFMA (pointwise, no contraction); roofline.frac is the HBM fraction BASELINE.json asks for, "
                 "roofline.fp64_frac / valu_issue_frac the binding resource")
-CALIB_REF_TFLOPS = 78.6      # what ab_calibrate's fp64 FMA chains deliver at the guide's 2.4 GHz: value_norm is `value` at that clock
+# What ab_calibrate's fp64 FMA workload delivered on the leases of round 6 (65.8 ... 66.05 TFLOP/s at a reported sclk of 2.37-2.40 GHz: 84 % of the
+# guide's 78.6 — the chains do not reach the peak issue rate, which is immaterial: the workload is FIXED, only its ratio between boxes is used).
+# value_norm = value x CALIB_REF_TFLOPS / measured: `value` as a box of that speed would have delivered it.
+CALIB_REF_TFLOPS = 66.0
 
 
 def read_sclk_mhz(dev_index):
@@ -164,7 +167,7 @@ def calibrate_box(ab, dev_index, launches):
 
 def calib_record(before, after, value):
     """`calib` of the JSON line + value_norm = value x (CALIB_REF_TFLOPS / the box's measured fp64 FMA rate): what the same kernel
-    would have delivered on a box running at the guide's clock.  Compare ROUNDS by value_norm, boxes by calib (README.md)."""
+    would have delivered on a box as fast as the leases the reference rate was taken on.  Compare ROUNDS by value_norm, boxes by calib (README.md)."""
     rates = [c["fma_f64_tflops"] for c in (before, after) if c and c.get("fma_f64_tflops")]
     rec = {"fma_f64_tflops_before": before.get("fma_f64_tflops") if before else None,
            "fma_f64_tflops_after": after.get("fma_f64_tflops") if after else None,
@@ -175,9 +178,52 @@ def calib_record(before, after, value):
     norm = None
     if rates:
         mean = sum(rates) / len(rates)
-        rec["effective_sclk_mhz"] = round(mean / CALIB_REF_TFLOPS * 2400.0, 1)
+        rec["box_speed"] = round(mean / CALIB_REF_TFLOPS, 4)            # 1.0 = a round-6 lease; the factor `value` was divided by
         norm = round(value * CALIB_REF_TFLOPS / mean, 2)
     return rec, norm
+
+
+def gather_model(n_gpus, cells, t_cell_slab_s, one_gpu_ms, bytes_per_cell_on_link, link_rates_GBps):
+    """What a gathered N-GPU step should cost, from three stated inputs — so that the first run on N real devices confirms or kills it.
+    Root-heavy cut (balanced_peer_rows): a peer owns the fraction f of the cells, f = t / (p + (N-1) t) with t = kernel time per cell at
+    slab size and p = max(t, bytes on the link per cell / link rate): a peer's compute + ship of its slab takes as long as the root's
+    compute of the rest.  step = t x cells x (1 - (N-1) f); speed-up = one-GPU step / that."""
+    pred = {}
+    for L in link_rates_GBps:
+        p_ = max(t_cell_slab_s, bytes_per_cell_on_link / (L * 1e9))
+        f = t_cell_slab_s / (p_ + (n_gpus - 1) * t_cell_slab_s)
+        step_ms = t_cell_slab_s * cells * (1.0 - (n_gpus - 1) * f) * 1e3
+        pred[f"{L:g} GB/s per peer"] = {"peer_share": round(f, 4), "root_share": round(1.0 - (n_gpus - 1) * f, 4), "step_ms": round(step_ms, 4),
+                                        "speedup_vs_one_gpu": round(one_gpu_ms / step_ms, 2) if step_ms > 0 else None}
+    return {"inputs": {"n_gpus": n_gpus, "cells": cells, "kernel_ns_per_cell_at_slab_size": round(t_cell_slab_s * 1e9, 5),
+                       "one_gpu_step_ms": round(one_gpu_ms, 4), "bytes_per_cell_on_link": bytes_per_cell_on_link},
+            "formula": "f = t/(max(t, b/L) + (N-1) t); step = t cells (1 - (N-1) f); speedup = one_gpu_step / step",
+            "predicted": pred,
+            "gather_free_ceiling": round(one_gpu_ms / (t_cell_slab_s * cells / n_gpus * 1e3), 2),
+            "note": "xGMI: 7 links x ~153 GB/s peak per GPU (MI355X guide); what one peer sustains into the root while six others send is the "
+                    "number the first 8-GPU run measures (split_tuning.link_GBps_per_peer) — rates above are assumptions, not measurements"}
+
+
+def host_path_leg(ab, sess, fields_dev, skin, zt, zu, niter, n, np_dtype, sync, reduce_max, records=4):
+    """The reference's own calling convention at the GCM call site (mod_aerobulk.f90:246-262): caller arrays in PAGEABLE HOST memory, every
+    record H2D | kernel | D2H through the session's AB_MEM_HOST entry (chunk-pipelined staging; a sharded session cuts the arrays by rows and
+    every device moves its rows over its own PCIe link).  Outside the timed region; never `value`.  first_record_ms includes the staging
+    buffers' allocation."""
+    import numpy as np
+    names = IN6 + (("rad_sw", "rad_lw") if skin else ())
+    h = {k: np.ascontiguousarray(fields_dev[k].cpu().numpy()) for k in names}
+    out = {k: np.zeros(n, dtype=np_dtype) for k in (("QL", "QH", "Tau_x", "Tau_y", "Evap") + (("T_s",) if skin else ()))}    # caller-owned, touched
+    ts = []
+    for _ in range(records):
+        sync()
+        t0 = time.perf_counter()
+        sess.compute(1, zt, zu, *[h[k] for k in IN6], Niter=niter, rad_sw=h.get("rad_sw"), rad_lw=h.get("rad_lw"), out=out, want_T_s=skin)
+        ts.append(reduce_max(time.perf_counter() - t0))
+    steady = min(ts[1:])
+    return {"first_record_ms": round(ts[0] * 1e3, 3), "ms_per_record": round(steady * 1e3, 3), "records": records,
+            "bytes_per_cell_over_pcie": (len(names) + len(out)) * np.dtype(np_dtype).itemsize, "checksum_QL": float(out["QL"].sum(dtype=np.float64)),
+            "what": "ab_session_compute(AB_MEM_HOST) on pageable caller arrays, one record = H2D of the inputs + kernel + D2H of the fluxes, "
+                    "best of the records after the first; the reference's AEROBULK_MODEL call site"}
 
 
 def cpu_baseline_config1(niter, zt, zu):
@@ -451,6 +497,38 @@ def main_inprocess(a):
     st1 = Setup()
     st1.sessions, st1.shards, st1.cstream, st1.c_ptr, st1.shard_in, st1.outs, st1.sync = sessions[:1], shards, cstream, c_ptr, shard_in[:1], [o[:1] for o in outs], sync
     kms = kernel_ms(st1, min(a.steps, 10))
+    kms_all = kms if npass == 1 else kernel_ms(st, min(a.steps, 10))
+
+    # the one-GPU step of the same workload on the root's device, in this very run: numerator of every speed-up quoted below
+    one_gpu_ms = None
+    host_path = None
+    try:
+        ffull = ab.synth_fields_device(ni, nj, precision=precision, device=root_dev, with_rad=True)
+        o1 = {k: torch.empty(ni * nj, dtype=tdt, device=root_dev) for k in ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")}
+        one_gpu_ms = 0.0
+        for algo, skin in passes:
+            with ab.Session(algo, ni, nj, 1, skin, precision=precision, device=devs[root]) as s1:
+                s1.set_humidity("sh")
+                kw = dict(Niter=niter, rad_sw=ffull["rad_sw"] if skin else None, rad_lw=ffull["rad_lw"] if skin else None,
+                          out={k: v for k, v in o1.items() if (k != "T_s" or skin)}, want_T_s=skin, check=False)
+                for _ in range(3):
+                    s1.compute(1, zt, zu, *[ffull[k] for k in IN6], **kw)
+                torch.cuda.synchronize(root_dev)
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    s1.compute(1, zt, zu, *[ffull[k] for k in IN6], **kw)
+                torch.cuda.synchronize(root_dev)
+                one_gpu_ms += (time.perf_counter() - t0) / a.steps * 1e3
+        if not a.no_host_path and npass == 1:
+            algo, skin = passes[0]
+            with ab.Session(algo, ni, nj, 1, skin, precision=precision, device=devs, rows=rows) as sh:
+                sh.set_humidity("sh")
+                host_path = host_path_leg(ab, sh, ffull, skin, zt, zu, niter, ni * nj, {"f64": "float64"}.get(precision, "float32"), sync, lambda x: x)
+            host_path["Mcell_s"] = round(ni * nj / host_path["ms_per_record"] / 1e3, 1)
+            host_path["layout"] = f"one sharded session, {nsh} row blocks on devices {devs}: each device stages its rows over its own PCIe link"
+        del ffull, o1
+    except Exception as e:      # reports, never a reason to lose the line
+        host_path = {"failed": str(e)}
 
     verify_msg = None
     if a.verify:
@@ -507,6 +585,16 @@ def main_inprocess(a):
     }
     res["limiter"] = LIMITER_NOTE
     res["calib"], res["value_norm"] = calib_record(calib_before, calib_after, res["value"])
+    if host_path:
+        res["host_path"] = host_path
+    if one_gpu_ms:
+        res["one_gpu"] = {"ms_per_step": round(one_gpu_ms, 4), "value": round(npass * cells / one_gpu_ms / 1e3, 2), "unit": "Mcell/s",
+                          "note": f"the same workload as ONE unsharded session on device {devs[root]}, measured in this run: the numerator of the speed-ups"}
+        res["speedup_vs_one_gpu"] = {"gathered": round(one_gpu_ms / (elapsed / a.steps * 1e3), 3), "resident": round(one_gpu_ms / (elapsed_resident / a.steps * 1e3), 3)}
+        if nsh > 1:
+            t_cell = max(kms_all[r] * 1e-3 / (ni * shards[r][1]) for r in range(1, nsh))      # a PEER's kernels, all passes, per cell, at its slab size
+            meas = [tune["link_GBps_per_peer"]] if (tune and ndist > 1) else []
+            res.setdefault("gather", {})["model"] = gather_model(nsh, cells, t_cell, one_gpu_ms, npass * len(gnames) * esz, [60.0, 100.0, 130.0] + meas)
     if verify_msg:
         res["verify"] = verify_msg
     if tune:
@@ -533,6 +621,9 @@ def main():
                     help="f32_storage: fp32 arrays with fp64 arithmetic (AB_F32_STORAGE); f32_mixed: fp32 arrays, fp64 anchors (SST, theta, "
                          "T_s, q, q_s, their differences, q_sat), fp32 transcendentals (AB_F32_MIXED: config 5's mode, inside the restated 1e-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-path", action="store_true", help="time the host-array leg for other configurations than the headline too")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-array leg (`host_path`: the reference's calling convention, pageable caller "
+                                                                "arrays through AB_MEM_HOST, outside the timed region)")
     ap.add_argument("--resident", "--no-gather", dest="resident", action="store_true",
                     help="N>1: the fluxes stay on the GPU that computed them (what a GPU-resident ocean model consumes): no gather "
                          "in the timed region.  Without this flag the gathered run is the headline and the resident rate is "
@@ -763,15 +854,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    region_events = []                       # HIP events on the launch stream around the K launches of the latest timed() call
+
     def timed(nsteps, with_gather, pipelined=True):
         drain()
         sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        e0.record()                           # (the session launches on torch's current stream: api.Session.compute)
         for _ in range(nsteps):
             step(with_gather, pipelined)
+        e1.record()
         drain()                               # the last steps' gathers belong to the timed region
         sync()
         el = time.perf_counter() - t0
+        region_events[:] = [e0, e1]
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -807,6 +904,9 @@ def main():
     sync()
     # timed region: EXACTLY K steps, no host sync inside
     elapsed = timed(a.steps, True, not a.no_pipeline_gather)
+    # average launch duration over the timed region itself: HIP events on the launch stream before the first and behind the last of the K
+    # steps' launches, / (K x launches per step).  Includes the gaps between back-to-back launches; never exceeds the step's wall time.
+    region_ms = region_events[0].elapsed_time(region_events[1]) / a.steps
     calib_after = calibrate_box(ab, dev_index, 5) if rank == 0 else None
     verify_globs, verify_niter = None, niter
     if a.verify and gathered:                 # what the last step gathered, before the other timed runs reuse the buffers
@@ -865,7 +965,35 @@ def main():
                 for p, (sess, ins, rad, out, skin) in enumerate(w):
                     sess.compute(1, zt, zu, *ins, Niter=niter, rad_sw=rad[0], rad_lw=rad[1], out=out[0], want_T_s=skin, check=False)
                     kms[p] += sess.last_kernel_ms() / nrep
-    k_ms = kms[0]
+    # the roofline's kernel duration: one launch per step (N = 1, one pass, one chunk) -> the timed region's own average; otherwise the
+    # event pair around a single launch of the first pass
+    one_launch_per_step = (npass == 1 and chunks == 1)
+    k_ms = region_ms if one_launch_per_step else kms[0]
+
+    # the host-array leg: every rank moves ITS rows over its own PCIe link, all ranks at once (max over ranks per record)
+    host_path = None
+    if not a.no_host_path and npass == 1 and njl == 0 and (a.config == 3 or a.host_path):
+        for _ in range(4):                    # a rank without rows still joins the other ranks' reductions (host_path_leg: records = 4)
+            sync()
+            t = torch.zeros(1, dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elif not a.no_host_path and npass == 1 and (a.config == 3 or a.host_path):
+        try:
+            def hp_max(x):
+                if world > 1:
+                    t = torch.tensor([x], dtype=torch.float64, device=cdev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    return float(t.item())
+                return x
+            with ab.Session(head_algo, ni, njl, 1, head_skin, precision=precision, device=dev_index) as sh:
+                sh.set_humidity("sh")
+                host_path = host_path_leg(ab, sh, {k: v[:n_local] for k, v in f.items()}, head_skin, zt, zu, niter, n_local,
+                                          {"f64": "float64"}.get(precision, "float32"), sync, hp_max)
+            host_path["Mcell_s"] = round(ni * nj / host_path["ms_per_record"] / 1e3, 1)
+            host_path["layout"] = (f"{world} ranks, each staging its {njl}-row block over its own PCIe link at the same time (max over ranks per record)"
+                                   if world > 1 else "one session, one device")
+        except Exception as e:
+            host_path = {"failed": str(e)}
 
     # BASELINE config 3 is quoted at nb_iter = 5 (the reference's default, mod_const.f90:33); its sea-ice series driver and BASELINE config 2 use 8
     # (src/ice/test_aerobulk_cdnf_series.f90:72): the same K steps at 8, reported beside the headline (never as `value`)
@@ -950,21 +1078,36 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": prof["hbm_traffic_bytes"] if prof else None,
                          "kernel": kernel_label(precision, head_algo, head_skin, n_local, ab),
-                         "kernel_ms": round(k_ms, 4), "bytes_per_cell": bpc, "cells_per_launch": n_local,
+                         "kernel_ms": round(k_ms, 4),
+                         "kernel_ms_how": ("HIP events on the launch stream around the K launches of the timed region, / K" if one_launch_per_step
+                                           else "HIP events around one launch of the first pass (separate pass over the same inputs)"),
+                         "kernel_ms_single_launch": round(kms[0], 4),
+                         "bytes_per_cell": bpc, "cells_per_launch": n_local,
                          "fp64_frac": prof["fp64_frac"] if prof else None,
                          "valu_issue_frac": prof["valu_issue_frac"] if prof else None,
                          "profile": prof if prof else ({"stale": "committed profile was taken with other device code: not quoted"} if pmc else None)},
         }
         res["limiter"] = LIMITER_NOTE
         res["calib"], res["value_norm"] = calib_record(calib_before, calib_after, value)
+        if host_path:
+            res["host_path"] = host_path
         if alt8:
             res["nb_iter_8"] = alt8
         if npass > 1:
             res["per_algorithm"] = {f"{al}{'+skin' if sk else ''}": {"kernel_ms": round(kms[p], 4),
                                                                         "Mcell_per_s": round(n_local / kms[p] / 1e3, 1) if kms[p] > 0 else None}
                                     for p, (al, sk) in enumerate(passes)}
+        if gathered and tune and "kernel_Mcell_per_s" in tune:
+            # the model's inputs are this run's own measurements: rank 0's kernel rate on ~1 M cells (a slab of a peer's size class) and the
+            # link rate of the tuning gathers; the one-GPU step is NOT measured in a torchrun launch (every rank holds its rows only):
+            # extrapolated from the same kernel rate, and said so
+            t_cell = npass * 1e-6 / tune["kernel_Mcell_per_s"]
+            gm = gather_model(world, cells, t_cell, t_cell * cells * 1e3, npass * ngat * esz, [60.0, 100.0, 130.0, float(tune["link_GBps"])])
+            gm["inputs"]["one_gpu_step_ms_is"] = "extrapolated from the kernel rate on ~1 M cells (the driver's N = 1 line holds the measured one)"
+        else:
+            gm = None
         if gathered:
-            res["gather"] = {"pipelined": not a.no_pipeline_gather,
+            res["gather"] = {"pipelined": not a.no_pipeline_gather, **({"model": gm} if gm else {}),
                              "note": ("two sets of output / receive buffers: the gathers of step t drain while step t + 1 computes; a set is "
                                       "written again only after its gathers were waited for" if not a.no_pipeline_gather else
                                       "every step ends with a wait for its own gathers")}
