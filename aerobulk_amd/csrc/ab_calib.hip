@@ -4,7 +4,8 @@
 // line taken on one lease cannot be compared with a line of another round unless both carry a number that depends on the box alone.
 //   AB_CALIB_FMA_F64 : every lane of 4 waves per SIMD runs eight independent chains of v_fma_f64 (inline assembly: the compiler has
 //                      nothing to fold).  The time is set by the fp64 VALU issue rate alone — the resource that binds the flux
-//                      kernels — so rate / 78.6 TFLOP/s x 2.4 GHz is the shader clock the box sustained.
+//                      kernels.  66 TFLOP/s on the leases of round 6 (84 % of the guide's 78.6: the chains do not
+//                      reach the peak issue rate, which does not matter — the workload is FIXED, its ratio between boxes is the figure).
 //   AB_CALIB_HBM_COPY: one coalesced pass dst[i] = src[i] over 1 GiB (grid-stride, 16-byte accesses): bytes read + written per
 //                      second, the resource that binds the sea-ice and helper kernels.
 // Nothing of the flux path is involved; the kernels are timed with HIP events on the caller's stream.
@@ -75,7 +76,7 @@ extern "C" int ab_calibrate(int what, int device, void *stream_, double *ms_out,
     double rate = 0.;
     int rc = AB_OK;
     if (what == AB_CALIB_FMA_F64) {
-        // 16 blocks of four waves per CU = four rounds of four waves per SIMD; n = 1500 x 32 FMAs per wave: ~5 ms at 2.4 GHz
+        // 16 blocks of four waves per CU = four rounds of four waves per SIMD; n = 1500 x 32 FMAs per wave: ~1.5 ms
         const int blocks = cus * 16, n = 1500;
         double *out = nullptr;
         CAL_HIP(hipMalloc((void **)&out, sizeof(double) * (size_t)blocks * 256));

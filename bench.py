@@ -37,7 +37,7 @@ FP64_VECTOR_PEAK_TF = 78.6   # fp64 vector (VALU) peak, same guide: half the 157
 IN6 = ("sst", "t_zt", "hum_zt", "U_zu", "V_zu", "slp")
 SKIN_ALGOS = ("coare3p0", "coare3p6", "ecmwf")
 ALL_ALGOS = ("coare3p0", "coare3p6", "ncar", "ecmwf", "andreas")
-PMC_JSON = os.path.join(ROOT, "profiles", "r5_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r6_pmc.json")      # this round's counter profile of the headline kernel (tools/update_pmc.py --headline)
 
 
 def kernel_label(precision, algo, skin, n_cells, ab):
@@ -84,7 +84,7 @@ def kernel_source_hash():
 
 
 def committed_pmc(algo, skin, ni, nj, niter, precision):
-    """Hardware-counter figures of the committed rocprofv3 run of exactly this workload (profiles/r5_pmc.json, written by
+    """Hardware-counter figures of the committed rocprofv3 run of exactly this workload (profiles/r6_pmc.json, written by
     tools/update_pmc.py from a tools/prof_quick.sh run), or None.  bench.py cannot collect counters itself.  They are only
     quoted when the profile was taken with the device code that is running now (source hash), and every figure derived from
     them uses the PROFILE's own kernel duration, never a live timing."""
@@ -155,7 +155,7 @@ def read_sclk_mhz(dev_index):
 
 
 def calibrate_box(ab, dev_index, launches):
-    """The box, not the kernel: `launches` runs of ab_calibrate's fixed fp64 FMA workload (about 5 ms each; the first ones also
+    """The box, not the kernel: `launches` runs of ab_calibrate's fixed fp64 FMA workload (about 1.5 ms each; the first ones also
     raise the clocks), median of the last five.  Called before the pre-roll and again after the timed region."""
     try:
         tf = [ab.calibrate("fma_f64", dev_index)[1] for _ in range(launches)]
@@ -173,7 +173,7 @@ def calib_record(before, after, value):
            "fma_f64_tflops_after": after.get("fma_f64_tflops") if after else None,
            "sclk_mhz": (after or {}).get("sclk_mhz") or (before or {}).get("sclk_mhz"),
            "reference_tflops": CALIB_REF_TFLOPS,
-           "workload": "ab_calibrate(AB_CALIB_FMA_F64): chains of v_fma_f64, 4 waves per SIMD, ~5 ms, HIP events; median of 5 launches "
+           "workload": "ab_calibrate(AB_CALIB_FMA_F64): chains of v_fma_f64, 4 waves per SIMD, ~1.5 ms, HIP events; median of 5 launches "
                        "before the pre-roll (after 15 ramp launches) and after the timed region"}
     norm = None
     if rates:

@@ -20,6 +20,22 @@ def test_calib_record_normalises_to_the_reference_clock():
     assert norm is None and rec["fma_f64_tflops_before"] is None
 
 
+def test_gather_model_gives_the_numbers_design_md_quotes():
+    """DESIGN.md §6's table of the gathered N = 8 run: the model bench.py prints (`gather.model`) from three stated inputs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cells, t_cell, one_gpu_ms = 4320 * 3600, 0.2790e-3 / (4320 * 450), 1.9473          # this round's kernel: 4320x450 in 0.279 ms, full grid 1.947 ms
+    m = bench.gather_model(8, cells, t_cell, one_gpu_ms, 40, [60.0, 100.0, 130.0])
+    sp = {k: v["speedup_vs_one_gpu"] for k, v in m["predicted"].items()}
+    assert abs(sp["60 GB/s per peer"] - 2.19) < 0.03 and abs(sp["100 GB/s per peer"] - 3.06) < 0.04 and abs(sp["130 GB/s per peer"] - 3.72) < 0.05, sp
+    assert abs(m["gather_free_ceiling"] - 6.98) < 0.02
+    assert abs(m["predicted"]["60 GB/s per peer"]["root_share"] - 0.399) < 0.003
+    # fast links: the equal split, and the gather-free ceiling
+    fast = bench.gather_model(8, cells, t_cell, one_gpu_ms, 40, [1e6])["predicted"]["1e+06 GB/s per peer"]
+    assert abs(fast["peer_share"] - 0.125) < 1e-4 and abs(fast["speedup_vs_one_gpu"] - 6.98) < 0.02
+    assert bench.balanced_peer_rows(3600, 8, t_cell, 40, 60e9) == round(0.0859 * 3600)
+
+
 def test_committed_profiles_valu_instructions_per_cell_did_not_rise():
     """The headline kernel's VALU instructions per cell of this round's committed counter profile against the previous round's: a rise of more than
     0.5 % is a regression of the kernel, whatever the box's clocks did to the Mcell/s."""
@@ -38,7 +54,7 @@ def test_calibration_kernels_report_plausible_rates():
     for _ in range(20):                                                        # ~100 ms of work: the clocks are up (the first launches of a cold
         ab.calibrate("fma_f64")                                                # device gave 50 and 57 TFLOP/s)
     ms, tf = ab.calibrate("fma_f64")
-    assert 2.0 < ms < 20.0 and 40.0 < tf < 95.0, (ms, tf)                       # 78.6 TFLOP/s is the guide's peak at 2.4 GHz; round-6 leases: 66
+    assert 0.5 < ms < 20.0 and 40.0 < tf < 95.0, (ms, tf)                       # 78.6 TFLOP/s is the guide's peak at 2.4 GHz; round-6 leases: 66
     ms2, tf2 = ab.calibrate("fma_f64")
     assert abs(tf2 - tf) < 0.03 * tf                                           # ... and repeatably
     ms, gbs = ab.calibrate("hbm_copy")

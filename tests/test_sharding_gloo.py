@@ -175,7 +175,7 @@ def test_committed_profile_is_of_this_device_code():
     h = bench.kernel_source_hash()
     assert len(h) == 16
     pmc = json.load(open(bench.PMC_JSON))
-    assert pmc["source_hash"] == h, "profiles/r5_pmc.json was taken with other kernel sources: re-take it"
+    assert pmc["source_hash"] == h, f"{bench.PMC_JSON} was taken with other kernel sources: re-take it (tools/prof_quick.sh, tools/update_pmc.py --headline)"
     got = bench.committed_pmc("coare3p6", True, 4320, 3600, 5, "f64")
     assert got and not got.get("stale") and got["valu_insts_per_cell"] > 1000
     # a header of another translation unit (the helper kernels') does not enter the hash

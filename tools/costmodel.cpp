@@ -132,6 +132,8 @@ template <> struct Mth<CD> {
     static R div(Prod a, R b) { return div(R(a), b); }
     static R div(R a, Prod b) { return div(a, R(b)); }
     static R div(Prod a, Prod b) { return div(R(a), R(b)); }
+    static R fma(R a, R b, R c) { g_acct.add(1.); return R(__builtin_fma(a.v, b.v, c.v)); }
+    static R fma(R a, R b, Prod c) { return fma(a, b, R(c)); }
     static R abs(R x) { return R(__builtin_fabs(x.v)); }                  // source modifier: free
     static R abs(Prod x) { return R(__builtin_fabs(R(x).v)); }
     static R floor(R x) { g_acct.add(1.); return R(__builtin_floor(x.v)); }

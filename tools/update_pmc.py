@@ -23,7 +23,7 @@ def main():
     ap.add_argument("name")
     ap.add_argument("--cells", type=int, default=4320 * 3600)
     ap.add_argument("--what", default="COARE3p6+skin 4320x3600 fp64 nb_iter=5")
-    ap.add_argument("--headline", action="store_true", help="also the flat record bench.py quotes (profiles/r5_pmc.json)")
+    ap.add_argument("--headline", action="store_true", help="also the flat record bench.py quotes (bench.PMC_JSON: profiles/r6_pmc.json)")
     a = ap.parse_args()
     txt = open(os.path.join(a.dir, "summary.txt")).read()
     out_txt = os.path.join(ROOT, "profiles", f"{a.name}_flux_kernel.txt")
@@ -61,7 +61,7 @@ def main():
         k = next(k for k in kernels if "flux_kernel_cu" in k) if any("flux_kernel_cu" in k for k in kernels) else kernels[0]
         flat = dict(recs[k], source=doc["source"], source_hash=doc["source_hash"], kernel=k,
                     config={"algo": "coare3p6", "skin": True, "grid": [4320, 3600], "nb_iter": 5, "precision": "f64"})
-        json.dump(flat, open(os.path.join(ROOT, "profiles", "r5_pmc.json"), "w"), indent=1)
+        json.dump(flat, open(bench.PMC_JSON, "w"), indent=1)           # (this round's file: bench.py names it)
     print(out_txt)
     print(json.dumps(doc, indent=1)[:3000])
 
