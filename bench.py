@@ -140,7 +140,8 @@ CALIB_REF_TFLOPS = 66.0
 
 def read_sclk_mhz(dev_index):
     """Shader clock the driver reports for the device right now (sysfs pp_dpm_sclk, the level marked '*'), or None.  Read without
-    starting a process; informational — the calibration kernel's own rate is the figure that is compared."""
+    starting a process; informational (calibrate_box samples it while its workload runs and keeps the highest reading) — the calibration
+    kernel's own rate is the figure that is compared."""
     import glob
     try:
         cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
@@ -158,9 +159,24 @@ def calibrate_box(ab, dev_index, launches):
     """The box, not the kernel: `launches` runs of ab_calibrate's fixed fp64 FMA workload (about 1.5 ms each; the first ones also
     raise the clocks), median of the last five.  Called before the pre-roll and again after the timed region."""
     try:
-        tf = [ab.calibrate("fma_f64", dev_index)[1] for _ in range(launches)]
+        import threading
+        samples, stop = [], threading.Event()
+
+        def sampler():      # the driver's shader clock WHILE the workload runs (read after it, the device is back at its idle level: 383 MHz)
+            while not stop.is_set():
+                v = read_sclk_mhz(dev_index)
+                if v:
+                    samples.append(v)
+                time.sleep(0.002)
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        try:
+            tf = [ab.calibrate("fma_f64", dev_index)[1] for _ in range(launches)]      # (ctypes releases the GIL during the call)
+        finally:
+            stop.set()
+            th.join(timeout=1.0)
         tail = sorted(tf[-5:])
-        return {"fma_f64_tflops": round(tail[len(tail) // 2], 3), "sclk_mhz": read_sclk_mhz(dev_index)}
+        return {"fma_f64_tflops": round(tail[len(tail) // 2], 3), "sclk_mhz": max(samples) if samples else None}
     except Exception as e:          # a report, never a reason to lose the run
         return {"fma_f64_tflops": None, "error": str(e)}
 
@@ -502,6 +518,7 @@ def main_inprocess(a):
     # the one-GPU step of the same workload on the root's device, in this very run: numerator of every speed-up quoted below
     one_gpu_ms = None
     host_path = None
+    peer_slab = None
     try:
         ffull = ab.synth_fields_device(ni, nj, precision=precision, device=root_dev, with_rad=True)
         o1 = {k: torch.empty(ni * nj, dtype=tdt, device=root_dev) for k in ("QL", "QH", "Tau_x", "Tau_y", "Evap", "T_s")}
@@ -519,6 +536,26 @@ def main_inprocess(a):
                     s1.compute(1, zt, zu, *[ffull[k] for k in IN6], **kw)
                 torch.cuda.synchronize(root_dev)
                 one_gpu_ms += (time.perf_counter() - t0) / a.steps * 1e3
+        # ... and a PEER's slab alone on the same device (the model's kernel time per cell at slab size: with several shards on one device —
+        # the one-GPU box — the per-shard timings above overlap and say nothing about a device that owns one slab)
+        if nsh > 1:
+            rows_peer_ = shards[1][1]
+            n_peer = ni * rows_peer_
+            slab_ms = 0.0
+            for algo, skin in passes:
+                with ab.Session(algo, ni, rows_peer_, 1, skin, precision=precision, device=devs[root]) as s1:
+                    s1.set_humidity("sh")
+                    kw = dict(Niter=niter, rad_sw=ffull["rad_sw"][:n_peer] if skin else None, rad_lw=ffull["rad_lw"][:n_peer] if skin else None,
+                              out={k: v[:n_peer] for k, v in o1.items() if (k != "T_s" or skin)}, want_T_s=skin, check=False)
+                    for _ in range(5):
+                        s1.compute(1, zt, zu, *[ffull[k][:n_peer] for k in IN6], **kw)
+                    torch.cuda.synchronize(root_dev)
+                    t0 = time.perf_counter()
+                    for _ in range(2 * a.steps):
+                        s1.compute(1, zt, zu, *[ffull[k][:n_peer] for k in IN6], **kw)
+                    torch.cuda.synchronize(root_dev)
+                    slab_ms += (time.perf_counter() - t0) / (2 * a.steps) * 1e3
+            peer_slab = {"rows": rows_peer_, "ms_per_step": round(slab_ms, 4), "ns_per_cell": round(slab_ms * 1e6 / n_peer, 5)}
         if not a.no_host_path and npass == 1:
             algo, skin = passes[0]
             with ab.Session(algo, ni, nj, 1, skin, precision=precision, device=devs, rows=rows) as sh:
@@ -591,10 +628,11 @@ def main_inprocess(a):
         res["one_gpu"] = {"ms_per_step": round(one_gpu_ms, 4), "value": round(npass * cells / one_gpu_ms / 1e3, 2), "unit": "Mcell/s",
                           "note": f"the same workload as ONE unsharded session on device {devs[root]}, measured in this run: the numerator of the speed-ups"}
         res["speedup_vs_one_gpu"] = {"gathered": round(one_gpu_ms / (elapsed / a.steps * 1e3), 3), "resident": round(one_gpu_ms / (elapsed_resident / a.steps * 1e3), 3)}
-        if nsh > 1:
-            t_cell = max(kms_all[r] * 1e-3 / (ni * shards[r][1]) for r in range(1, nsh))      # a PEER's kernels, all passes, per cell, at its slab size
+        if nsh > 1 and peer_slab:
+            t_cell = peer_slab["ns_per_cell"] * 1e-9          # a PEER's kernels (all passes) per cell, its slab alone on a device
             meas = [tune["link_GBps_per_peer"]] if (tune and ndist > 1) else []
             res.setdefault("gather", {})["model"] = gather_model(nsh, cells, t_cell, one_gpu_ms, npass * len(gnames) * esz, [60.0, 100.0, 130.0] + meas)
+            res["gather"]["model"]["inputs"]["peer_slab"] = peer_slab
     if verify_msg:
         res["verify"] = verify_msg
     if tune:

@@ -314,3 +314,31 @@ def test_reference_cxx_example_unchanged_runs():
     r = _run(exe)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("AeroBulk_init") == 5 and "COARE" in r.stdout.upper()
+
+
+@pytest.mark.gpu
+def test_device_arrays_on_a_device_that_is_not_current(gold):
+    """ab_phymbl(AB_MEM_DEVICE) works on the device that OWNS the caller's arrays, whatever device is current in the calling thread, and leaves
+    the current device as it found it.  Needs two visible devices; on the one-GPU box the refusal of host pointers is what is checked."""
+    import torch
+    import aerobulk_amd as ab
+    cols, rec = gold
+    x = np.ascontiguousarray(col(cols, "Ta"))
+    with pytest.raises(ab.AerobulkError) as e:          # host pointers handed over as device arrays: refused, not dereferenced
+        from aerobulk_amd import _lib
+        import ctypes as C
+        lib = _lib.load()
+        y = np.zeros_like(x)
+        pin, pout = (C.c_void_p * 1)(x.ctypes.data), (C.c_void_p * 1)(y.ctypes.data)
+        par, info = (C.c_double * 2)(0., 0.), (C.c_double * 2)(0., 0.)
+        rc = lib.ab_phymbl(pc.E_SAT, x.size, pin, 1, pout, 1, par, 0, 1, None, info)
+        assert rc == 10 and not y.any()
+        raise ab.AerobulkError(rc, "refused")
+    assert e.value.status == 10
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device: the cross-device case cannot run here")
+    torch.cuda.set_device(0)
+    xd = torch.from_numpy(x).to("cuda:1")
+    outs, _ = ab.phymbl(pc.E_SAT, [xd])
+    assert torch.cuda.current_device() == 0 and outs[0].device.index == 1
+    close(outs[0].cpu().numpy(), rec["e_sat"], "e_sat on device 1 with device 0 current")
