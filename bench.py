@@ -176,18 +176,28 @@ def calibrate_box(ab, dev_index, launches):
             stop.set()
             th.join(timeout=1.0)
         tail = sorted(tf[-5:])
-        return {"fma_f64_tflops": round(tail[len(tail) // 2], 3), "sclk_mhz": max(samples) if samples else None}
+        rec = {"fma_f64_tflops": round(tail[len(tail) // 2], 3), "sclk_mhz": max(samples) if samples else None}
+        if launches >= 10:          # once per run, before the pre-roll: the box's memory side (1 GiB device-to-device copy, read + written)
+            try:
+                rec["hbm_copy_GBps"] = round(sorted(ab.calibrate("hbm_copy", dev_index)[1] for _ in range(3))[1], 1)
+            except Exception:
+                rec["hbm_copy_GBps"] = None
+        return rec
     except Exception as e:          # a report, never a reason to lose the run
         return {"fma_f64_tflops": None, "error": str(e)}
 
 
 def calib_record(before, after, value):
     """`calib` of the JSON line + value_norm = value x (CALIB_REF_TFLOPS / the box's measured fp64 FMA rate): what the same kernel
-    would have delivered on a box as fast as the leases the reference rate was taken on.  Compare ROUNDS by value_norm, boxes by calib (README.md)."""
+    would have delivered on a box as fast as the leases the reference rate was taken on.  Compare ROUNDS by value_norm, boxes by calib (README.md).
+    What it does NOT remove: two round-6 leases 2.5 % apart in this rate ran the headline kernel 0.5 % apart the OTHER way (value_norm 8 072 and 7 849) —
+    the flux kernel's mix (LDS, quarter-rate seeds, 30 % of its cycles waiting) answers a box's power management differently from pure FMA chains.  The
+    calibration bounds a box's contribution to a few per cent; the instruction count per cell (profiles/r6_pmc.json) is the clock-free figure."""
     rates = [c["fma_f64_tflops"] for c in (before, after) if c and c.get("fma_f64_tflops")]
     rec = {"fma_f64_tflops_before": before.get("fma_f64_tflops") if before else None,
            "fma_f64_tflops_after": after.get("fma_f64_tflops") if after else None,
            "sclk_mhz": (after or {}).get("sclk_mhz") or (before or {}).get("sclk_mhz"),
+           "hbm_copy_GBps": (before or {}).get("hbm_copy_GBps"),
            "reference_tflops": CALIB_REF_TFLOPS,
            "workload": "ab_calibrate(AB_CALIB_FMA_F64): chains of v_fma_f64, 4 waves per SIMD, ~1.5 ms, HIP events; median of 5 launches "
                        "before the pre-roll (after 15 ramp launches) and after the timed region"}
