@@ -147,7 +147,7 @@ _BENCH_T2 = ("[2-extra0]", "[2-extra6]", "[2-extra8]")                     # def
 def tier_of(nodeid):
     f = nodeid.split("::")[0].rsplit("/", 1)[-1]
     name = nodeid.split("::", 1)[1] if "::" in nodeid else ""
-    if f in ("test_gpu_golden.py", "test_gpu_parity.py", "test_illcond_cells.py", "test_bistable_cells.py", "test_gpu_cu_kernel.py", "test_phymbl.py", "test_reference_drivers.py"):
+    if f in ("test_gpu_golden.py", "test_gpu_parity.py", "test_illcond_cells.py", "test_bistable_cells.py", "test_gpu_cu_kernel.py", "test_phymbl.py", "test_reference_drivers.py", "test_skin_modules.py"):
         return 1                                                           # (test_phymbl.py: the Fortran side of the drop-in boundary, incl. the reference's unchanged example)
     if f == "test_gpu_hosts.py":
         if name.startswith("test_bench_sharded_path_several_ranks_one_gpu"):
