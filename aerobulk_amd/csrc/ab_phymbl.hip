@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -72,6 +73,42 @@ template <int FN = 1> static hipError_t launch_fn(int fn, const PhArgs &a, hipSt
     } else {
         if (fn == FN) return launch_one<FN>(a, stream);
         return launch_fn<FN + 1>(fn, a, stream);
+    }
+}
+
+// ONE cell handed over by value: the scalar specifics of the Fortran modules (every `_sclr` of mod_phymbl, CS_* / WL_* of the skin modules) are calls
+// on one-cell host arrays, and the reference's sweep drivers issue them by the hundred thousand.  The general path costs such a call two to ten small
+// PCIe copies around its kernel (34 us); here the arguments travel in the kernel's argument segment and the results are written straight into a
+// pinned, device-mapped host buffer: one launch, one synchronisation.  Same ph_cell<FN>, same bits.
+struct PhScalarArgs {
+    double x[kPhMaxIn + 1];
+    double par[2];
+    double *out;                      // kPhMaxOut doubles, host memory mapped into the device's address space
+    int flag;
+    unsigned present;
+};
+template <int FN> __global__ void __launch_bounds__(kPhBlock) phymbl_scalar_kernel(const PhScalarArgs a)
+{
+    math_tables_init<double>();
+    if (threadIdx.x != 0) return;
+    constexpr PhShape sh = ph_shape(FN);
+    double x[kPhMaxIn + 1], y[kPhMaxOut];
+#pragma unroll
+    for (int i = 0; i < kPhMaxIn + 1; ++i) x[i] = a.x[i];
+    ph_cell<FN, double>(x, a.present, a.par, a.flag, y);
+#pragma unroll
+    for (int i = 0; i < sh.n_out; ++i) a.out[i] = y[i];
+}
+template <int FN = 1> static hipError_t launch_scalar(int fn, const PhScalarArgs &a, hipStream_t stream)
+{
+    if constexpr (FN >= kPhCount) {
+        return hipErrorInvalidValue;
+    } else {
+        if (fn == FN) {
+            hipLaunchKernelGGL((phymbl_scalar_kernel<FN>), dim3(1), dim3(kPhBlock), 0, stream, a);
+            return hipGetLastError();
+        }
+        return launch_scalar<FN + 1>(fn, a, stream);
     }
 }
 
@@ -175,6 +212,35 @@ extern "C" int ab_phymbl(int fn, long n, const double *const *in, int n_in, doub
     hipStream_t s = (hipStream_t)(mem == AB_MEM_DEVICE ? stream : nullptr);
     hipError_t e = hipSuccess;
     bool e_air_converged = true;
+
+    // ---- one cell of a host caller (not the two-pass functions, not BULK_FORMULA's stress check): by value, see phymbl_scalar_kernel
+    if (n == 1 && mem == AB_MEM_HOST && !two_pass && !tau_check) {
+        static std::mutex mu;
+        static double *h_out[64] = {nullptr}, *d_out[64] = {nullptr};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            std::lock_guard<std::mutex> lock(mu);         // one scalar call at a time per process: the buffer is read below, under the lock
+            if (!h_out[dev]) {
+                e = hipHostMalloc((void **)&h_out[dev], sizeof(double) * kPhMaxOut, hipHostMallocMapped);
+                if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&d_out[dev], h_out[dev], 0);
+                if (e != hipSuccess) { h_out[dev] = nullptr; return ph_hip_fail(e, "hipHostMalloc (scalar results)"); }
+            }
+            PhScalarArgs sa;
+            memset(&sa, 0, sizeof sa);
+            for (int i = 0; i < n_in; ++i)
+                if (in[i]) sa.x[i] = in[i][0];
+            sa.par[0] = par ? par[0] : 0.; sa.par[1] = par ? par[1] : 0.;
+            sa.out = d_out[dev];
+            sa.flag = flag;
+            sa.present = present;
+            e = launch_scalar<>(fn, sa, nullptr);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) return ph_hip_fail(e, "scalar kernel");
+            for (int i = 0; i < n_out; ++i)
+                if (out[i]) out[i][0] = h_out[dev][i];
+            return AB_OK;
+        }
+    }
 
     // device scratch: staged inputs / outputs of a host call, the e_air iterates, the wind-stress flag
     const int n_stage = mem == AB_MEM_HOST ? n_in + n_out : 0;

@@ -185,12 +185,16 @@ def test_device_arrays_give_the_same_bits_as_host_arrays(gold):
 def test_scalars_are_one_cell_arrays(gold):
     import aerobulk_amd as ab
     cols, rec = gold
-    for name in ("theta_from_z", "q_sat", "ri_bulk", "delta_skin_qlat_s"):
+    # every record of the call table: a one-cell host call (round 6: the arguments by value, the results through a mapped host buffer —
+    # phymbl_scalar_kernel; the two-pass functions and BULK_FORMULA keep the array path) gives the bits of the array kernel on that cell
+    for name in pc.CALLS:
         fn, par0, flag, ins, oi = pc.CALLS[name]
+        if fn in (pc.RHO_AIR_ADV, pc.RH_AIR, pc.E_AIR):
+            continue            # e_air's fixed point stops on a sum over the WHOLE array (mod_phymbl.f90:1730): a cell alone converges differently, in the reference too
         full, _ = _call_gpu(ab, cols, name)
         for k in (0, 3):
             outs, _ = ab.phymbl(fn, [None if c is None else col(cols, c)[k:k + 1] for c in ins], par0, flag, pc.N_OUT.get(fn, 1), par1=pc.PAR1.get(fn, 0.))
-            assert outs[oi][0] == full[k], (name, k)
+            assert outs[oi][0] == full[k] or (np.isnan(outs[oi][0]) and np.isnan(full[k])), (name, k)
 
 
 @pytest.mark.gpu
