@@ -252,6 +252,49 @@ def host_path_leg(ab, sess, fields_dev, skin, zt, zu, niter, n, np_dtype, sync, 
                     "best of the records after the first; the reference's AEROBULK_MODEL call site"}
 
 
+def overlapped_leg(ab, torch, passes, ni, rows, precision, dev_index, dev, f, names, tdt, niter, zt, zu, steps, sync, reduce_max):
+    """Consecutive records that do NOT depend on one another (single-record sessions: jt = 1 = Nt, as this benchmark's; ensemble members, regions),
+    issued alternately on TWO streams through TWO sessions: the persistent workgroups of record t + 1 take each CU the moment record t's
+    workgroup leaves it, which removes the start and the drain of a launch from the time per record (profiles/r6_notes.md §10).  A time loop
+    that carries the warm layer's state cannot do this; reported beside `value` / `resident`, never as them.  Returns seconds per step (max over
+    ranks) or None."""
+    n = ni * rows
+    if n <= 0:                # a rank without rows joins the other ranks' barriers and reduction
+        sync()
+        sync()
+        reduce_max(0.0)
+        return None
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    sets = []
+    for _ in range(2):
+        per = []
+        for algo, skin in passes:
+            sess = ab.Session(algo, ni, rows, 1, skin, precision=precision, device=dev_index)
+            sess.set_humidity("sh")
+            out = {k: torch.empty(n, dtype=tdt, device=dev) for k in names if (k != "T_s" or skin)}
+            per.append((sess, skin, out))
+        sets.append(per)
+
+    def step(i):
+        with torch.cuda.stream(streams[i & 1]):
+            for sess, skin, out in sets[i & 1]:
+                sess.compute(1, zt, zu, *[f[k][:n] for k in IN6], Niter=niter, rad_sw=f["rad_sw"][:n] if skin else None,
+                             rad_lw=f["rad_lw"][:n] if skin else None, out=out, want_T_s=skin, check=False)
+    for i in range(6):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    el = reduce_max(time.perf_counter() - t0)
+    for per in sets:
+        for sess, _, _ in per:
+            sess.check()
+            sess.close()
+    return el / steps
+
+
 def cpu_baseline_config1(niter, zt, zu):
     """BASELINE config 1 on the CPU, as the reference runs it: NCAR, 360x180, one aerobulk_model(jt=1,Nt=1) call incl.
     AEROBULK_INIT, the unmodified reference (oracle/_ref) in one process; the C port if _ref did not travel."""
@@ -669,6 +712,7 @@ def main():
                     help="f32_storage: fp32 arrays with fp64 arithmetic (AB_F32_STORAGE); f32_mixed: fp32 arrays, fp64 anchors (SST, theta, "
                          "T_s, q, q_s, their differences, q_sat), fp32 transcendentals (AB_F32_MIXED: config 5's mode, inside the restated 1e-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlapped", action="store_true", help="skip the `overlapped` leg (independent consecutive records alternating on two streams)")
     ap.add_argument("--host-path", action="store_true", help="time the host-array leg for other configurations than the headline too")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-array leg (`host_path`: the reference's calling convention, pageable caller "
                                                                 "arrays through AB_MEM_HOST, outside the timed region)")
@@ -1003,6 +1047,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_resident_whole = float(t.item())
 
+    # the same whole-block launches with consecutive records alternating on two streams (N = 1: the headline's workload; N > 1: every rank its block)
+    def ov_max(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+    overlapped_s = None
+    if not a.no_overlapped and (world == 1 or gathered):
+        try:
+            overlapped_s = overlapped_leg(ab, torch, passes, ni, njl, precision, dev_index, dev, f, names, tdt, niter, zt, zu, max(a.steps, 20) * 2, sync, ov_max)
+        except Exception as e:      # a report, never a reason to lose the line
+            overlapped_s = None
+            if rank == 0:
+                print(f"bench.py: overlapped leg failed: {e}", file=sys.stderr)
+
     # per-launch kernel duration: HIP events recorded by the library around each launch, on the launch stream.
     # Reading an event pair synchronises, so this is a separate pass over the same inputs (not in `elapsed`).
     kms = [0.0] * npass
@@ -1137,6 +1197,12 @@ def main():
         }
         res["limiter"] = LIMITER_NOTE
         res["calib"], res["value_norm"] = calib_record(calib_before, calib_after, value)
+        if overlapped_s:
+            res["overlapped"] = {"value": round(npass * cells / overlapped_s / 1e6, 2), "unit": "Mcell/s", "ms_per_step": round(overlapped_s * 1e3, 4),
+                                 "note": ("consecutive INDEPENDENT records (single-record sessions) alternating on two streams through two sessions"
+                                          + (", every rank its whole block, fluxes left where they were computed (no gather)" if world > 1 else "")
+                                          + ": the next record's workgroups take each CU as the previous record's leave it — throughput of independent records, "
+                                            "not the wall time of one record (`value`); a time loop carrying the warm layer's state cannot overlap its records")}
         if host_path:
             res["host_path"] = host_path
         if alt8:

@@ -71,3 +71,5 @@ def test_bench_line_carries_calib_value_norm_and_limiter():
     assert 40.0 < c["fma_f64_tflops_before"] < 95.0 and 40.0 < c["fma_f64_tflops_after"] < 95.0 and c["reference_tflops"] == 66.0
     assert abs(res["value_norm"] - res["value"] * 66.0 / (0.5 * (c["fma_f64_tflops_before"] + c["fma_f64_tflops_after"]))) < 0.02 * res["value"]
     assert res["limiter"].startswith("valu_fp64") and res["roofline"]["bound"] == "hbm"
+    # independent records alternating on two streams: never slower than one record after the other (a 0.14 ms launch gains most)
+    assert res["overlapped"]["value"] > 0.97 * res["value"] and "not the wall time of one record" in res["overlapped"]["note"]

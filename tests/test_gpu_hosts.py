@@ -181,6 +181,7 @@ def test_bench_sharded_path_several_ranks_one_gpu(world, extra):
     assert res["limiter"].startswith("valu_fp64") and res["calib"]["fma_f64_tflops_after"] > 30 and res["value_norm"] > 0
     if not extra:
         assert res["host_path"]["ms_per_record"] > 0 and str(world) + " ranks" in res["host_path"]["layout"]      # every rank stages its own rows
+        assert res["overlapped"]["value"] > 0 and "every rank its whole block" in res["overlapped"]["note"]
         assert res["gather"]["model"]["inputs"]["n_gpus"] == world and len(res["gather"]["model"]["predicted"]) == 4
     if "--config" in extra and extra[extra.index("--config") + 1] == "4":
         assert len(res["per_algorithm"]) == 5 and all(v["Mcell_per_s"] > 0 for v in res["per_algorithm"].values())

@@ -7,7 +7,7 @@ tag=$1; shift
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd $R
-ARGS="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-nb-iter-8 --no-host-path $*"
+ARGS="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-nb-iter-8 --no-host-path --no-overlapped $*"
 rocprofv3 --kernel-trace --stats -d $O/stats -o bench -- python3 $ARGS > $O/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_sq -o bench -- python3 $ARGS > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM --kernel-trace -d $O/pmc_f64 -o bench -- python3 $ARGS > $O/pmc_f64.log 2>&1
